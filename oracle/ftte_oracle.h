@@ -1,0 +1,101 @@
+/* ftte_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement, in plain C, of the reference's diffuse radiative-transfer
+ * sweep (razoumov/radiativeTransfer: transportRoutinesModule.f90,
+ * rotateIndicesModule.f90 and the runUVBTransfer block of equiSources.f90).
+ * It exists to check the HIP path; nothing under radiativetransfer_amd/ may
+ * include, link or call it.  Allowed users: tests/, __graft_entry__.smoke(),
+ * and the cpu_baseline leg of bench.py.
+ *
+ * Pinning: tests/test_oracle_golden.py checks every function here against
+ * vectors produced by the reference's own compiled modules
+ * (oracle/_ref/ref_harness, tests/golden/make_golden.py).
+ */
+#ifndef FTTE_ORACLE_H
+#define FTTE_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* segment-end codes, definitionsModule.f90:159 */
+enum { FO_XY_END = 1, FO_YZ_END = 2, FO_XZ_END = 3 };
+
+/* one layer's ray pattern, definitionsModule.f90:123-152 */
+typedef struct {
+    double xy_x0, xy_y0, xy_len;
+    double xz_x0, xz_z0, xz_len;
+    double yz_y0, yz_z0, yz_len;
+    int32_t xz_active, yz_active;
+    int32_t xy_top, xz_top, yz_top;
+    int32_t pad_;
+} fo_pattern;
+
+/* arithmetic flavour of the sweep */
+enum {
+    FO_ARITH_REFERENCE = 0, /* libm exp/log, (Iin-Iout)/log(Iin/Iout): the reference's formulae */
+    FO_ARITH_DEVICE = 1     /* radiativetransfer_amd/csrc/ftte_math.h: what the GPU evaluates    */
+};
+/* order in which directions are summed into J */
+enum {
+    FO_ORDER_SERIAL = 0, /* one accumulator, directions in list order (the reference)          */
+    FO_ORDER_CLASSED = 1 /* three accumulators by march axis (storage i, j, k), summed at the
+                            end as (Ji + Jj) + Jk: the order the device uses                    */
+};
+
+double fo_pi(void);      /* definitionsModule.f90:8  (float32-rounded literal)  */
+double fo_half_pi(void); /* :9 */
+double fo_two_pi(void);  /* :10 */
+
+/* rotateIndicesModule.f90:7-113.  1-based indices, returns 0 or -1 (bad izone). */
+int fo_rotate_indices(int i, int j, int k, int nx, int ny, int nz, int izone, int *ic, int *jc, int *kc);
+
+/* equiSources.f90:2118-2231 (+ rotateAngles :2297-2335, getAngle :2337-2361). */
+int fo_pix2ang_nest(int nside, int64_t ipix, double *phi, double *theta);
+
+/* equiSources.f90:1395-1454.  Returns 0, or -1/-2/-3 where the reference stops
+ * (phi on a quadrant boundary / theta on a boundary / tie of dominant axes). */
+int fo_fold_direction(double phi_large, double theta_large, double *phi, double *theta, int *izone);
+
+/* transportRoutinesModule.f90:7-85.  p->xy_x0, p->xy_y0 are inputs.
+ * Returns 0, or -1 where the reference stops (:33-36, :60-63). */
+int fo_set_pattern(fo_pattern *p, double phi, double theta);
+
+/* equiSources.f90:1495-1534: patterns of layers 1..n for a folded direction. */
+int fo_layer_patterns(int n, double phi, double theta, fo_pattern *layers);
+
+/* One diffuse-transfer iteration on a uniform n^3 grid (equiSources.f90:1385-1806
+ * with every base cell unrefined).  kappa, J: [nnu][n^3] in cell-array order
+ * (flat = ((i-1)*n + (j-1))*n + (k-1), definitionsModule.f90:323-326).
+ * J is overwritten (the reference zeroes it in computeOpacities,
+ * equiSources.f90:4964-4966).  eta may be NULL (the reference's hard-wired
+ * zero emissivity, transportRoutinesModule.f90:673-675).
+ * noise (may be NULL): [nnu][n^3], receives a per-cell bound on the rounding noise the
+ * REFERENCE formula (Iin-Iout)/log(Iin/Iout) carries: sum over directions and segments of
+ * (w/nseg) * Iin * (eps/2)/tau_seg, eps/2 = 2^-53.  The quotient Iin/Iout is rounded before the
+ * logarithm is taken, which perturbs log by eps/2 absolute and the mean by a relative eps/(2 tau);
+ * the parity tests use it as the tau-aware part of their tolerance.
+ * Returns 0 or the negative code of the first direction that cannot be folded. */
+int fo_diffuse_sweep_uniform(int n, int nnu, const double *kappa, const double *eta, double box, int ndir,
+                             const double *phi, const double *theta, const double *w, const double *uvb,
+                             double *J, int arith, int order, double *noise);
+
+/* Same on an AMR cell array: level[ncell] is the depth-first leaf list
+ * (readCellArray.f90:154-187); kappa, J: [nnu][ncell].  Restates
+ * setRaysRefined / findNeighbours / get??Neighbour / transport
+ * (transportRoutinesModule.f90:121-218, 264-558, 560-963). */
+int fo_diffuse_sweep_tree(int n, int64_t ncell, const int32_t *level, int nnu, const double *kappa, double box,
+                          int ndir, const double *phi, const double *theta, const double *w, const double *uvb,
+                          double *J, int arith, int order, double *noise);
+
+/* equiSources.f90:4956-4983 generalised to nnu groups: kappa[g][c] = sum_s n_s[c]*beta[s][g],
+ * summed in species order HI, HeI, HeII. beta: [3][nnu]. */
+void fo_compute_opacities(int64_t ncell, int nnu, const double *HI, const double *HeI, const double *HeII,
+                          const double *beta, double *kappa);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,120 @@
+/* ftte_math.h -- the segment arithmetic of the device sweep, written once.
+ *
+ * One ray segment of optical depth tau = kappa*dpath attenuates the incoming
+ * intensity and contributes its path-mean intensity to the cell:
+ *
+ *     Iout = Iin * exp(-tau)                 transportRoutinesModule.f90:651-678 (eta == 0)
+ *     mean = (Iin - Iout)/log(Iin/Iout)      transportRoutinesModule.f90:1036-1054
+ *
+ * With zero emissivity log(Iin/Iout) == tau identically, so the log-mean is
+ * Iin * g(tau), g(tau) = (1 - exp(-tau))/tau.  The device evaluates g without a
+ * logarithm (and, below tau = ln2/2, without the cancellation the reference's
+ * quotient suffers: the reference's own rounding noise is ~eps/tau, see
+ * tests/test_parity_gpu.py for the tolerance this implies).
+ *
+ * Everything here is plain IEEE binary64 with explicit fused multiply-adds, no
+ * library call whose rounding is unspecified: the same source compiled by gcc
+ * for the host (-ffp-contract=off -mfma) and by hipcc for gfx950
+ * (-ffp-contract=off) produces identical bits, which is what lets the parity
+ * tests compare the GPU against a CPU evaluation bit for bit.
+ *
+ * Coefficients: tools/fit_exp_poly.py (degree 9, |r| <= ln2/2: approximation
+ * error 4.1e-17 in g, 1.6e-17 in exp, before rounding).
+ */
+#ifndef FTTE_MATH_H
+#define FTTE_MATH_H
+
+#if defined(__HIPCC__)
+#define FTTE_HD __host__ __device__ __forceinline__
+#define FTTE_FMA(a, b, c) __builtin_fma((a), (b), (c))
+#define FTTE_RINT(a) __builtin_rint(a)
+#define FTTE_LDEXP(a, n) __builtin_ldexp((a), (n))
+#define FTTE_FMAX(a, b) __builtin_fmax((a), (b))
+#else
+#include <math.h>
+#define FTTE_HD static inline
+#define FTTE_FMA(a, b, c) fma((a), (b), (c))
+#define FTTE_RINT(a) rint(a)
+#define FTTE_LDEXP(a, n) ldexp((a), (n))
+#define FTTE_FMAX(a, b) fmax((a), (b))
+#endif
+
+#define FTTE_LOG2E 0x1.71547652b82fep+0   /* 1/ln2 */
+#define FTTE_LN2_HI 0x1.62e42fee00000p-1  /* ln2, low 21 bits clear: n*LN2_HI exact for |n| < 2^21 */
+#define FTTE_LN2_LO 0x1.a39ef35793c76p-33 /* ln2 - LN2_HI */
+#define FTTE_X_FLOOR (-1000.0)            /* exp(-1000) == 0 in binary64; keeps n inside int range */
+
+#define FTTE_EXPQ_C0 0x1.0000000000001p-1
+#define FTTE_EXPQ_C1 0x1.5555555555556p-3
+#define FTTE_EXPQ_C2 0x1.5555555553d63p-5
+#define FTTE_EXPQ_C3 0x1.11111111109b3p-7
+#define FTTE_EXPQ_C4 0x1.6c16c1788bd90p-10
+#define FTTE_EXPQ_C5 0x1.a01a01a7c41d5p-13
+#define FTTE_EXPQ_C6 0x1.a019b90d2ae7ap-16
+#define FTTE_EXPQ_C7 0x1.71de0dae63bb3p-19
+#define FTTE_EXPQ_C8 0x1.289185613a3d6p-22
+#define FTTE_EXPQ_C9 0x1.af38a9b0ec855p-26
+
+/* e = exp(-tau), g = (1-exp(-tau))/tau  (g(0) = 1).  tau >= 0 expected; a
+ * negative tau (unphysical opacity) still evaluates, up to overflow. */
+FTTE_HD void ftte_attenuation(double tau, double *e_out, double *g_out)
+{
+    const double x = FTTE_FMAX(-tau, FTTE_X_FLOOR);
+    const double nf = FTTE_RINT(x * FTTE_LOG2E);
+    double r = FTTE_FMA(nf, -FTTE_LN2_HI, x);
+    r = FTTE_FMA(nf, -FTTE_LN2_LO, r);
+
+    double q = FTTE_EXPQ_C9;
+    q = FTTE_FMA(q, r, FTTE_EXPQ_C8);
+    q = FTTE_FMA(q, r, FTTE_EXPQ_C7);
+    q = FTTE_FMA(q, r, FTTE_EXPQ_C6);
+    q = FTTE_FMA(q, r, FTTE_EXPQ_C5);
+    q = FTTE_FMA(q, r, FTTE_EXPQ_C4);
+    q = FTTE_FMA(q, r, FTTE_EXPQ_C3);
+    q = FTTE_FMA(q, r, FTTE_EXPQ_C2);
+    q = FTTE_FMA(q, r, FTTE_EXPQ_C1);
+    q = FTTE_FMA(q, r, FTTE_EXPQ_C0);
+
+    const double g0 = FTTE_FMA(r, q, 1.0);  /* expm1(r)/r */
+    const double e0 = FTTE_FMA(r, g0, 1.0); /* exp(r)     */
+    const int n = (int)nf;
+    const double e = FTTE_LDEXP(e0, n);
+    const double gd = (1.0 - e) / tau; /* n != 0: tau >= ln2/2, 1-e >= 0.29, no cancellation */
+    *e_out = e;
+    *g_out = (n == 0) ? g0 : gd;
+}
+
+/* One segment: advances the ray intensity and returns the path-mean intensity
+ * the cell receives from it.  Iout == 0 (underflow) yields a zero mean, as the
+ * reference's (Iin-0)/log(Iin/0) does. */
+FTTE_HD double ftte_segment(double *I, double tau)
+{
+    double e, g;
+    ftte_attenuation(tau, &e, &g);
+    const double Iin = *I;
+    const double Iout = Iin * e;
+    *I = Iout;
+    return (Iout == 0.0) ? 0.0 : Iin * g;
+}
+
+/* (acc/nseg)*w with acc/nseg correctly rounded for nseg in {1,2,3} without a
+ * division: q = acc*(1/3) refined by one residual step is the correctly
+ * rounded quotient (Markstein), as an IEEE division would give.
+ * transportRoutinesModule.f90:953-955. */
+FTTE_HD double ftte_cell_mean(double acc, int nseg, double w)
+{
+    double q;
+    if (nseg == 3) {
+        const double third = 0x1.5555555555555p-2;
+        q = acc * third;
+        const double res = FTTE_FMA(-3.0, q, acc);
+        q = FTTE_FMA(res, third, q);
+    } else if (nseg == 2) {
+        q = acc * 0.5;
+    } else {
+        q = acc;
+    }
+    return q * w;
+}
+
+#endif /* FTTE_MATH_H */

@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/*.npz from the reference's own compiled modules.
+
+Runs only in the build container (needs /root/reference and amdflang):
+
+    make -C oracle ref && python tests/golden/make_golden.py
+
+Each .npz holds DATA only: the synthetic inputs (level list, kappa, directions, inflow,
+box) and what oracle/_ref/ref_harness -- i.e. the reference's setPattern / setRaysRefined /
+localizeCellFindNeighbours / transport / rotateIndices -- produced for them.  Three
+frequency groups throughout, because the reference hard-wires three
+(definitionsModule.f90:169-171).
+"""
+from __future__ import annotations
+
+import os
+import struct
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import _oracle  # noqa: E402  (only for the HEALPix direction lists fed to the reference)
+from radiativetransfer_amd import synthetic  # noqa: E402
+
+HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+GEOM_REC = np.dtype([("xy", "<f8", 3), ("xz", "<f8", 3), ("yz", "<f8", 3), ("flags", "<i4", 5)])
+
+
+def run_reference(n, level, kappa3, box, uvb3, phi, theta, w, dump_geometry=0):
+    """dump_geometry: 0 J only; 1 J + geometry records; 2 geometry records only (no grid needed)."""
+    ncell, ndir = len(level), len(phi)
+    with tempfile.TemporaryDirectory() as tmp:
+        case, out = os.path.join(tmp, "case.bin"), os.path.join(tmp, "out.bin")
+        with open(case, "wb") as f:
+            f.write(struct.pack("<4i", n, ncell, ndir, int(dump_geometry)))
+            f.write(struct.pack("<d", box))
+            f.write(np.asarray(uvb3, "<f8").tobytes())
+            f.write(np.asarray(level, "<i4").tobytes())
+            f.write(np.ascontiguousarray(kappa3, "<f8").tobytes())  # [3][ncell] == Fortran kap(ncell,3)
+            for a in (phi, theta, w):
+                f.write(np.asarray(a, "<f8").tobytes())
+        subprocess.check_call([HARNESS, case, out], stderr=subprocess.DEVNULL)
+        raw = open(out, "rb").read()
+    J = None if dump_geometry == 2 else np.frombuffer(raw, "<f8", 3 * ncell).reshape(3, ncell).copy()
+    geo = None
+    if dump_geometry:
+        off = 0 if dump_geometry == 2 else 3 * ncell * 8
+        geo = {"izone": np.empty(ndir, np.int32), "phi": np.empty(ndir), "theta": np.empty(ndir),
+               "layers": np.empty((ndir, n), GEOM_REC)}
+        for d in range(ndir):
+            geo["izone"][d], geo["phi"][d], geo["theta"][d] = struct.unpack_from("<idd", raw, off)
+            off += 20
+            geo["layers"][d] = np.frombuffer(raw, GEOM_REC, n, off)
+            off += n * GEOM_REC.itemsize
+        assert off == len(raw)
+    return J, geo
+
+
+def one_per_izone():
+    """First direction of the 192-direction set that folds into each of the 24 zones."""
+    phi, theta, _ = _oracle.healpix_directions(3)
+    pick = {}
+    for p, t in zip(phi, theta):
+        z = _oracle.fold_direction(p, t)[2]
+        pick.setdefault(z, (p, t))
+    assert sorted(pick) == list(range(1, 25))
+    a = np.array([pick[z] for z in range(1, 25)])
+    return a[:, 0].copy(), a[:, 1].copy(), np.full(24, 1.0 / 24)
+
+
+def save(name, **kw):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **kw)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def main():
+    if not os.path.exists(HARNESS):
+        sys.exit("build oracle/_ref/ref_harness first: make -C oracle ref")
+
+    # rotateIndices table (A4)
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "rot.bin")
+        subprocess.check_call([HARNESS, "--rotate-table", out], stderr=subprocess.DEVNULL)
+        table = np.fromfile(out, "<i4").reshape(24, 3, 4, 5, 3)
+    save("rotate_indices", table=table, extents=np.array([7, 11, 13], np.int32))
+
+    uvb3 = synthetic.frequency_groups(3)[2]
+
+    def uniform_case(name, n, kappa, dirs, box=1.0):
+        level = np.zeros(n ** 3, np.int32)
+        J, _ = run_reference(n, level, kappa, box, uvb3, *dirs)
+        save(name, n=n, level=level, kappa=kappa, box=box, uvb=uvb3, phi=dirs[0], theta=dirs[1], w=dirs[2], J=J)
+
+    # (1) transparent box: J must equal uvb * sum(w)
+    uniform_case("uniform8_transparent", 8, np.zeros((3, 512)), _oracle.healpix_directions(1))
+    # (2) homogeneous medium, 12 directions
+    uniform_case("uniform16_constant", 16, np.repeat(np.array([[2.0], [0.7], [0.1]]), 4096, axis=1) * 16,
+                 _oracle.healpix_directions(1))
+    # (3) log-normal medium, one direction per izone (all 24 rotations, pattern classes A-E)
+    kap16, _, _ = synthetic.uniform_workload(16, 3, seed=2024, tau_median=0.2)
+    uniform_case("uniform16_lognormal_24zones", 16, kap16, one_per_izone())
+    # (4) log-normal medium, the 48-direction set, optically thicker
+    kap24, _, _ = synthetic.uniform_workload(24, 3, seed=777, tau_median=0.5)
+    uniform_case("uniform24_lognormal_48dir", 24, kap24, _oracle.healpix_directions(2))
+
+    # (5) AMR: 8^3 base, a 2x2x2 block of base cells refined once; one direction per izone
+    blocks = [(3 + a, 3 + b, 4 + c) for a in range(2) for b in range(2) for c in range(2)]
+    level = synthetic.refine_levels(8, blocks, depth=1)
+    rho = synthetic.lognormal_density(len(level), seed=99)
+    kap = (0.3 * 8) * synthetic.frequency_groups(3)[1][:, None] * rho[None, :]
+    dirs = one_per_izone()
+    J, _ = run_reference(8, level, kap, 1.0, uvb3, *dirs)
+    save("amr8_block_level1", n=8, level=level, kappa=kap, box=1.0, uvb=uvb3, phi=dirs[0], theta=dirs[1], w=dirs[2], J=J)
+    # (6) AMR: two nested levels in three scattered base cells, 48 directions
+    level = synthetic.refine_levels(6, [(1, 1, 1), (2, 3, 4), (4, 4, 1)], depth=2)
+    rho = synthetic.lognormal_density(len(level), seed=5)
+    kap = (0.4 * 6) * synthetic.frequency_groups(3)[1][:, None] * rho[None, :]
+    dirs = _oracle.healpix_directions(2)
+    J, _ = run_reference(6, level, kap, 1.0, uvb3, *dirs)
+    save("amr6_scattered_level2", n=6, level=level, kappa=kap, box=1.0, uvb=uvb3, phi=dirs[0], theta=dirs[1], w=dirs[2], J=J)
+
+    # (7) geometry: fold + per-layer patterns. All 192 directions x 16 layers, 12 directions x 256 layers.
+    for name, n, dirs in (("geometry_192dir_16layers", 16, _oracle.healpix_directions(3)),
+                          ("geometry_12dir_256layers", 256, _oracle.healpix_directions(1))):
+        _, geo = run_reference(n, np.zeros(0, np.int32), np.zeros((3, 0)), 1.0, uvb3, *dirs, dump_geometry=2)
+        save(name, n=n, phi_in=dirs[0], theta_in=dirs[1], izone=geo["izone"], phi=geo["phi"], theta=geo["theta"],
+             layers=geo["layers"])
+
+
+if __name__ == "__main__":
+    main()
