@@ -1,0 +1,147 @@
+/* ftte.h -- C ABI of the MI355X diffuse radiative-transfer sweep.
+ *
+ * The reference (razoumov/radiativeTransfer, "FTTE") has no FFI of its own: its hot path
+ * is reached through `use transportRoutinesModule` (equiSources.f90:25) and through code
+ * inlined in the main program (equiSources.f90:1372-1808), with state in module globals
+ * (definitionsModule.f90:55-62,104,182,256).  This header is the seam cut at
+ * equiSources.f90:1383-1806: everything between `computeOpacities` and the chemistry.
+ * Each entry point names the reference code it stands in for.
+ *
+ *   in : the cell array (definitionsModule.f90:323-326: depth-first leaf list, `level` per
+ *        leaf, k fastest on the base grid), per-leaf opacities kappa_nu (or species densities
+ *        + cross-sections), the inflow uvb_nu, a direction list (phi, theta, weight) BEFORE
+ *        folding, the box size
+ *   out: J_nu per leaf, same order, overwritten (the reference zeroes J in computeOpacities,
+ *        equiSources.f90:4964-4966, then accumulates one term per direction,
+ *        transportRoutinesModule.f90:953-955)
+ *
+ * Conventions: plain C types, caller owns every host array, the library owns its device
+ * buffers, every function returns 0 on success or a negative ftte_status (it never calls
+ * exit: where the reference executes `stop`, the status says which `stop`).  All arithmetic
+ * is IEEE binary64.  A context is not thread-safe; use one per host thread / per GPU.
+ *
+ * The library is linked against the HIP runtime and needs a gfx950 device for every call
+ * that computes on the grid; the host-only geometry helpers at the end work without one.
+ */
+#ifndef FTTE_H
+#define FTTE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ftte_ctx ftte_ctx;
+
+typedef enum {
+    FTTE_OK = 0,
+    FTTE_ERR_ARG = -1,            /* null pointer, non-positive size, ...                         */
+    FTTE_ERR_STATE = -2,          /* call order: grid / opacity not set                           */
+    FTTE_ERR_NO_DEVICE = -3,      /* no usable HIP device, or a HIP call failed                    */
+    FTTE_ERR_UNSUPPORTED = -4,    /* valid request this build does not implement (see message)     */
+    FTTE_ERR_NOT_CUBIC = -5,      /* equiSources.f90:436-439 'base grid needs to be of size n^3'   */
+    FTTE_ERR_LEVELS = -6,         /* readCellArray.f90:182 'error in levels'                       */
+    FTTE_ERR_PHI = -7,            /* equiSources.f90:1412 'error in phi' (on a quadrant boundary)  */
+    FTTE_ERR_THETA = -8,          /* equiSources.f90:1426 'error in theta'                         */
+    FTTE_ERR_DOMINANT_AXIS = -9,  /* equiSources.f90:1450 'error in theta or phi' (tie)            */
+    FTTE_ERR_PATTERN = -10,       /* transportRoutinesModule.f90:33-36,60-63; equiSources.f90:1523 */
+    FTTE_ERR_IZONE = -11,         /* rotateIndices called with izone outside 1..24                 */
+    FTTE_ERR_PIXEL = -12          /* equiSources.f90:2152-2160 'nside/ipix out of range'           */
+} ftte_status;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+
+/* One context drives one device. ndev must be 1 (dev_ids[0] = HIP device ordinal; dev_ids may
+ * be NULL for the current device): multi-GPU runs use one process and one context per GPU and
+ * reduce J with RCCL in the host driver. */
+int ftte_create(ftte_ctx **ctx, int ndev, const int *dev_ids);
+int ftte_destroy(ftte_ctx *ctx);
+/* Message of the last failing call on this context ("" if none); ctx may be NULL for the
+ * message of the last failing ftte_create. */
+const char *ftte_last_error(const ftte_ctx *ctx);
+
+/* ---- inputs -------------------------------------------------------------------------------- */
+
+/* The grid: stands in for the tree the reference builds from the cell array
+ * (readCellArray.f90:154-187 createFullyThreadedStructure) and for physicalBoxSize
+ * (definitionsModule.f90:256).  nx == ny == nz is required, as in the reference.
+ * level[ncell]: depth-first leaf list, 0 = base cell.  A list of all zeros (ncell = nx^3) is a
+ * uniform grid; refined cell arrays are validated and then refused with FTTE_ERR_UNSUPPORTED
+ * by this build (scope). */
+int ftte_set_grid(ftte_ctx *ctx, int nx, int ny, int nz, int64_t ncell, const int32_t *level, double box_cm);
+
+/* Opacities kappa[nnu][ncell] in cell-array order (host memory), cm^-1.  Stands in for the
+ * kappa1..3 fields filled by computeOpacities (equiSources.f90:4977-4980); nnu is free
+ * (the reference hard-wires 3 groups, definitionsModule.f90:169-171). */
+int ftte_set_opacity(ftte_ctx *ctx, int nnu, const double *kappa);
+/* Same, kappa already resident in device memory (not retained beyond the call). */
+int ftte_set_opacity_device(ftte_ctx *ctx, int nnu, const double *kappa_dev);
+/* computeOpacities itself (equiSources.f90:4956-4983) for nnu groups, on the device:
+ * kappa_g = HI*beta[0][g] + HeI*beta[1][g] + HeII*beta[2][g] (left to right).
+ * HI/HeI/HeII: [ncell] host arrays, beta: [3][nnu] host array (rows: HI = beta24,
+ * HeI = beta26, HeII = beta25 of the reference's group tables). */
+int ftte_set_species(ftte_ctx *ctx, int nnu, const double *HI, const double *HeI, const double *HeII,
+                     const double *beta);
+/* Emissivity eta[nnu][ncell]; NULL selects the reference's hard-wired zero emissivity
+ * (transportRoutinesModule.f90:673-675).  A non-NULL eta is refused with
+ * FTTE_ERR_UNSUPPORTED by this build. */
+int ftte_set_emissivity(ftte_ctx *ctx, const double *eta);
+
+/* ---- the sweep ----------------------------------------------------------------------------- */
+
+/* One diffuse-transfer iteration = equiSources.f90:1385-1806 for a caller-supplied direction
+ * list: for every direction, fold it (:1395-1454), build the per-layer ray patterns
+ * (:1495-1534, setPattern), and sweep all cells (:1572-1796 / transport), accumulating
+ * J_nu += w * mean-over-segments(log-mean intensity).
+ * phi[ndir] in (0, 2 pi), theta[ndir] in (-pi/2, pi/2) (the reference's un-folded angles, as
+ * pix2ang_nest returns them), w[ndir], uvb[nnu] (inflow on every upstream boundary face,
+ * definitionsModule.f90:55-56), J[nnu][ncell] host memory, overwritten. */
+int ftte_diffuse_sweep(ftte_ctx *ctx, int ndir, const double *phi, const double *theta, const double *w,
+                       const double *uvb, double *J);
+/* Same with J in device memory.  `stream` is a hipStream_t (NULL = the context's own stream);
+ * the call is asynchronous with respect to the host, ordered on that stream. */
+int ftte_diffuse_sweep_device(ftte_ctx *ctx, int ndir, const double *phi, const double *theta, const double *w,
+                              const double *uvb, double *J_dev, void *stream);
+
+/* ---- tuning and instrumentation ------------------------------------------------------------- */
+
+/* Tuning knobs: "rows" (rays per lane: 4, 8 or 16), "slots" (directions in flight per
+ * launch, 1..16).  Unknown keys return FTTE_ERR_ARG. */
+int ftte_set_option(ftte_ctx *ctx, const char *key, int value);
+/* Launch records of the last sweep (valid after the sweep's stream has been synchronised).
+ * Each sweep-kernel launch is bracketed by HIP events on the stream it runs on. */
+int ftte_launch_count(const ftte_ctx *ctx);
+/* ms: device time of launch `idx`; updates: cell.direction.frequency updates it performed. */
+int ftte_launch_info(ftte_ctx *ctx, int idx, double *ms, int64_t *updates);
+
+/* ---- host geometry, the reference's callable surface (no device needed) ---------------------- */
+
+/* one layer's ray pattern: patternType of definitionsModule.f90:141-152 without the tree link */
+typedef struct {
+    double xy_x0, xy_y0, xy_len;
+    double xz_x0, xz_z0, xz_len;
+    double yz_y0, yz_z0, yz_len;
+    int32_t xz_active, yz_active;
+    int32_t xy_top, xz_top, yz_top; /* 0 none, 1 xy segment, 2 yz segment, 3 xz segment (:159) */
+    int32_t reserved_;
+} ftte_pattern;
+
+/* rotateIndices(i,j,k,nx,ny,nz,izone,icell,jcell,kcell), rotateIndicesModule.f90:7-113 */
+int ftte_rotate_indices(int i, int j, int k, int nx, int ny, int nz, int izone, int *icell, int *jcell, int *kcell);
+/* pix2ang_nest + rotateAngles, equiSources.f90:2118-2231, 2297-2335: rotated centre of NESTED
+ * pixel ipix; phi in [0, 2 pi), theta = colatitude - pi/2 */
+int ftte_pix2ang_nest(int nside, int64_t ipix, double *phi, double *theta);
+/* direction folding, equiSources.f90:1395-1454: canonical (phi, theta) and izone 1..24 */
+int ftte_fold_direction(double phi_large, double theta_large, double *phi, double *theta, int *izone);
+/* setPattern(pattern, phi, theta), transportRoutinesModule.f90:7-85; xy_x0, xy_y0 are inputs */
+int ftte_set_pattern(ftte_pattern *pattern, double phi, double theta);
+/* patterns of layers 1..n of a folded direction, equiSources.f90:1495-1534 */
+int ftte_layer_patterns(int n, double phi, double theta, ftte_pattern *layers);
+/* computeCellIntensity(Jmean, Iin, Iout), transportRoutinesModule.f90:1036-1054 */
+void ftte_compute_cell_intensity(double *Jmean, double Iin, double Iout);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FTTE_H */

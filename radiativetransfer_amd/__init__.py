@@ -1,0 +1,8 @@
+"""radiativetransfer_amd -- MI355X-native diffuse radiative-transfer sweep (FTTE hot path).
+
+The package is a thin host layer over libftte.so (HIP kernels for gfx950 + the C ABI of
+include/ftte.h).  Importing it never compiles anything and never substitutes a CPU path.
+"""
+from . import synthetic  # noqa: F401
+from .api import (DiffuseTransfer, FtteError, Pattern, compute_cell_intensity, fold_direction,  # noqa: F401
+                  healpix_directions, layer_patterns, pix2ang_nest, rotate_indices, set_pattern)

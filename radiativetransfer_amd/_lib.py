@@ -1,0 +1,75 @@
+"""ctypes binding of libftte.so (include/ftte.h).  No fallback: a missing library is an error."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libftte.so")
+
+STATUS = {
+    0: "FTTE_OK", -1: "FTTE_ERR_ARG", -2: "FTTE_ERR_STATE", -3: "FTTE_ERR_NO_DEVICE", -4: "FTTE_ERR_UNSUPPORTED",
+    -5: "FTTE_ERR_NOT_CUBIC", -6: "FTTE_ERR_LEVELS", -7: "FTTE_ERR_PHI", -8: "FTTE_ERR_THETA",
+    -9: "FTTE_ERR_DOMINANT_AXIS", -10: "FTTE_ERR_PATTERN", -11: "FTTE_ERR_IZONE", -12: "FTTE_ERR_PIXEL",
+}
+
+
+class FtteError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"{STATUS.get(code, code)}: {message}")
+        self.code = code
+        self.status = STATUS.get(code, str(code))
+
+
+class Pattern(C.Structure):
+    """ftte_pattern == patternType of definitionsModule.f90:141-152 (without the tree link)."""
+    _fields_ = [(n, C.c_double) for n in
+                ("xy_x0", "xy_y0", "xy_len", "xz_x0", "xz_z0", "xz_len", "yz_y0", "yz_z0", "yz_len")] + \
+               [(n, C.c_int32) for n in ("xz_active", "yz_active", "xy_top", "xz_top", "yz_top", "reserved_")]
+
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes): every symbol include/ftte.h declares
+SIGNATURES = {
+    "ftte_create": (C.c_int, [C.POINTER(_vp), C.c_int, _ip]),
+    "ftte_destroy": (C.c_int, [_vp]),
+    "ftte_last_error": (C.c_char_p, [_vp]),
+    "ftte_set_grid": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int32), C.c_double]),
+    "ftte_set_opacity": (C.c_int, [_vp, C.c_int, _dp]),
+    "ftte_set_opacity_device": (C.c_int, [_vp, C.c_int, _vp]),
+    "ftte_set_species": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp]),
+    "ftte_set_emissivity": (C.c_int, [_vp, _dp]),
+    "ftte_diffuse_sweep": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, _dp]),
+    "ftte_diffuse_sweep_device": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, _vp, _vp]),
+    "ftte_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+    "ftte_launch_count": (C.c_int, [_vp]),
+    "ftte_launch_info": (C.c_int, [_vp, C.c_int, _dp, C.POINTER(C.c_int64)]),
+    "ftte_rotate_indices": (C.c_int, [C.c_int] * 7 + [_ip, _ip, _ip]),
+    "ftte_pix2ang_nest": (C.c_int, [C.c_int, C.c_int64, _dp, _dp]),
+    "ftte_fold_direction": (C.c_int, [C.c_double, C.c_double, _dp, _dp, _ip]),
+    "ftte_set_pattern": (C.c_int, [C.POINTER(Pattern), C.c_double, C.c_double]),
+    "ftte_layer_patterns": (C.c_int, [C.c_int, C.c_double, C.c_double, C.POINTER(Pattern)]),
+    "ftte_compute_cell_intensity": (None, [_dp, C.c_double, C.c_double]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libftte.so; raises if it has not been built (python -m radiativetransfer_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `python -m radiativetransfer_amd.build`); there is no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib

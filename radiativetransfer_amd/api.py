@@ -1,0 +1,196 @@
+"""Host-side mirror of the reference's diffuse-transfer interface, on top of the C ABI.
+
+The reference has no API object: its driver (equiSources.f90:1372-1808) calls
+`computeOpacities`, then per direction `pix2ang_nest`, the folding block, `setPattern`,
+`localizeCellFindNeighbours` and `transport`.  The names below follow that vocabulary.
+Everything that touches cells runs in libftte.so on the GPU; there is no Python or CPU
+implementation of the sweep in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import FtteError, Pattern
+
+__all__ = ["DiffuseTransfer", "FtteError", "Pattern", "pix2ang_nest", "healpix_directions", "fold_direction",
+           "rotate_indices", "set_pattern", "layer_patterns", "compute_cell_intensity"]
+
+
+def _f64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _dp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _check(code: int, what: str):
+    if code:
+        raise FtteError(code, what)
+
+
+# ---- host geometry: the reference's callable surface ----------------------------------------------------
+
+def rotate_indices(i: int, j: int, k: int, nx: int, ny: int, nz: int, izone: int) -> Tuple[int, int, int]:
+    """rotateIndices (rotateIndicesModule.f90:7): sweep indices -> storage indices, 1-based."""
+    a, b, c = C.c_int(), C.c_int(), C.c_int()
+    _check(_lib.load().ftte_rotate_indices(i, j, k, nx, ny, nz, izone, C.byref(a), C.byref(b), C.byref(c)),
+           f"izone {izone} outside 1..24")
+    return a.value, b.value, c.value
+
+
+def pix2ang_nest(nside: int, ipix: int) -> Tuple[float, float]:
+    """pix2ang_nest + rotateAngles (equiSources.f90:2118, 2297): rotated centre of a NESTED pixel."""
+    p, t = C.c_double(), C.c_double()
+    _check(_lib.load().ftte_pix2ang_nest(nside, ipix, C.byref(p), C.byref(t)), "nside/ipix out of range")
+    return p.value, t.value
+
+
+def healpix_directions(angular_level: int, count: Optional[int] = None):
+    """(phi, theta, weight) of the first `count` pixels of angular level L (12*4^(L-1) pixels),
+    equal weights 1/count: the direction loop header of equiSources.f90:1385-1391."""
+    nside = 2 ** (angular_level - 1)
+    npix = 12 * nside * nside
+    count = npix if count is None else count
+    if not 0 < count <= npix:
+        raise ValueError("count out of range")
+    ang = np.array([pix2ang_nest(nside, i) for i in range(count)])
+    return ang[:, 0].copy(), ang[:, 1].copy(), np.full(count, 1.0 / count)
+
+
+def fold_direction(phi: float, theta: float) -> Tuple[float, float, int]:
+    """The folding block equiSources.f90:1395-1454: canonical (phi, theta) and izone."""
+    p, t, z = C.c_double(), C.c_double(), C.c_int()
+    _check(_lib.load().ftte_fold_direction(phi, theta, C.byref(p), C.byref(t), C.byref(z)),
+           f"direction ({phi}, {theta}) cannot be folded")
+    return p.value, t.value, z.value
+
+
+def set_pattern(x0: float, y0: float, phi: float, theta: float) -> Pattern:
+    """setPattern (transportRoutinesModule.f90:7) for a ray entering the unit cell at (x0, y0)."""
+    p = Pattern()
+    p.xy_x0, p.xy_y0 = x0, y0
+    _check(_lib.load().ftte_set_pattern(C.byref(p), phi, theta), "ray pattern left the unit cell")
+    return p
+
+
+def layer_patterns(n: int, phi: float, theta: float):
+    """Patterns of layers 1..n of a folded direction (equiSources.f90:1495-1534)."""
+    arr = (Pattern * n)()
+    _check(_lib.load().ftte_layer_patterns(n, phi, theta, arr), "ray pattern left the unit cell")
+    return arr
+
+
+def compute_cell_intensity(jmean: float, i_in: float, i_out: float) -> float:
+    """computeCellIntensity (transportRoutinesModule.f90:1036): returns the updated Jmean."""
+    j = C.c_double(jmean)
+    _lib.load().ftte_compute_cell_intensity(C.byref(j), i_in, i_out)
+    return j.value
+
+
+# ---- the sweep ---------------------------------------------------------------------------------------------
+
+class DiffuseTransfer:
+    """One GPU's diffuse-transfer engine: the `if (runUVBTransfer)` block of the reference driver.
+
+        rt = DiffuseTransfer(device=0)
+        rt.set_grid(n, level, box_cm)            # the cell array (definitionsModule.f90:323-326)
+        rt.compute_opacities(HI, HeI, HeII, beta)  # or rt.set_opacity(kappa)
+        J = rt.transport(phi, theta, weight, uvb)  # J[nnu][ncell], cell-array order
+    """
+
+    def __init__(self, device: Optional[int] = None):
+        self._lib = _lib.load()
+        self._ctx = C.c_void_p()
+        ids = (C.c_int * 1)(device) if device is not None else None
+        code = self._lib.ftte_create(C.byref(self._ctx), 1, ids)
+        if code:
+            raise FtteError(code, self._lib.ftte_last_error(None).decode())
+        self.n = 0
+        self.ncell = 0
+        self.nnu = 0
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.ftte_destroy(self._ctx)
+            self._ctx = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _ok(self, code: int):
+        if code:
+            raise FtteError(code, self._lib.ftte_last_error(self._ctx).decode())
+
+    # -- inputs
+    def set_grid(self, n, level: Sequence[int], box_cm: float):
+        """n: base grid size (int, or (nx, ny, nz)); level: depth-first leaf levels; box_cm: physicalBoxSize."""
+        nx, ny, nz = (n, n, n) if np.isscalar(n) else n
+        level = np.ascontiguousarray(level, dtype=np.int32)
+        self._ok(self._lib.ftte_set_grid(self._ctx, nx, ny, nz, level.size, level.ctypes.data_as(C.POINTER(C.c_int32)),
+                                         float(box_cm)))
+        self.n, self.ncell = int(nx), int(level.size)
+
+    def set_uniform_grid(self, n: int, box_cm: float):
+        self.set_grid(n, np.zeros(n ** 3, np.int32), box_cm)
+
+    def set_opacity(self, kappa):
+        """kappa[nnu][ncell] (numpy, host)."""
+        kappa = _f64(kappa)
+        if kappa.ndim != 2 or kappa.shape[1] != self.ncell:
+            raise ValueError("kappa must have shape [nnu][ncell]")
+        self._ok(self._lib.ftte_set_opacity(self._ctx, kappa.shape[0], _dp(kappa)))
+        self.nnu = kappa.shape[0]
+
+    def set_opacity_device(self, nnu: int, device_ptr: int):
+        """kappa[nnu][ncell] already in device memory (e.g. torch.Tensor.data_ptr())."""
+        self._ok(self._lib.ftte_set_opacity_device(self._ctx, nnu, C.c_void_p(device_ptr)))
+        self.nnu = nnu
+
+    def compute_opacities(self, HI, HeI, HeII, beta):
+        """computeOpacities (equiSources.f90:4956): beta[3][nnu], rows HI, HeI, HeII."""
+        HI, HeI, HeII, beta = map(_f64, (HI, HeI, HeII, beta))
+        if beta.ndim != 2 or beta.shape[0] != 3:
+            raise ValueError("beta must have shape [3][nnu]")
+        self._ok(self._lib.ftte_set_species(self._ctx, beta.shape[1], _dp(HI), _dp(HeI), _dp(HeII), _dp(beta)))
+        self.nnu = beta.shape[1]
+
+    def set_emissivity(self, eta=None):
+        self._ok(self._lib.ftte_set_emissivity(self._ctx, None if eta is None else _dp(_f64(eta))))
+
+    def set_option(self, key: str, value: int):
+        self._ok(self._lib.ftte_set_option(self._ctx, key.encode(), int(value)))
+
+    # -- the sweep
+    def transport(self, phi, theta, weight, uvb) -> np.ndarray:
+        """One diffuse-transfer iteration; returns J[nnu][ncell] (host)."""
+        phi, theta, weight, uvb = map(_f64, (phi, theta, weight, uvb))
+        if not (len(phi) == len(theta) == len(weight)) or len(uvb) != self.nnu:
+            raise ValueError("direction arrays must have equal length and uvb one value per frequency group")
+        J = np.empty((self.nnu, self.ncell))
+        self._ok(self._lib.ftte_diffuse_sweep(self._ctx, len(phi), _dp(phi), _dp(theta), _dp(weight), _dp(uvb), _dp(J)))
+        return J
+
+    def transport_device(self, phi, theta, weight, uvb, j_device_ptr: int, stream: int = 0):
+        """Same with J[nnu][ncell] in device memory; asynchronous on `stream` (a hipStream_t handle, 0 = own)."""
+        phi, theta, weight, uvb = map(_f64, (phi, theta, weight, uvb))
+        self._ok(self._lib.ftte_diffuse_sweep_device(self._ctx, len(phi), _dp(phi), _dp(theta), _dp(weight), _dp(uvb),
+                                                     C.c_void_p(j_device_ptr), C.c_void_p(stream)))
+
+    def launch_records(self):
+        """[(ms, updates)] of the sweep-kernel launches of the last sweep (synchronise first)."""
+        out = []
+        for i in range(self._lib.ftte_launch_count(self._ctx)):
+            ms, upd = C.c_double(), C.c_int64()
+            self._ok(self._lib.ftte_launch_info(self._ctx, i, C.byref(ms), C.byref(upd)))
+            out.append((ms.value, upd.value))
+        return out

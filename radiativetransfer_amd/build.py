@@ -1,0 +1,60 @@
+"""Build radiativetransfer_amd/libftte.so (HIP kernels + C ABI) for gfx950, in-tree.
+
+    python -m radiativetransfer_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  The shared object is git-ignored but travels to the GPU box
+with the repository snapshot; the Python side never builds at import time and never falls back to
+anything else if the library is missing.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "libftte.so")
+SOURCES = ["ftte_kernels.hip", "ftte_api.cpp", "ftte_geometry.cpp"]
+HEADERS = ["ftte_internal.h", "ftte_kernels.h", "ftte_geometry.h", "ftte_math.h", os.path.join("..", "..", "include", "ftte.h")]
+# -ffp-contract=off: the sweep arithmetic spells out its fused multiply-adds (ftte_math.h); nothing else may be fused,
+# so that the device rounds exactly like the host evaluation the parity tests compare against.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-gpu-rdc", "-Wall"]
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the HIP extension cannot be built")
+    return exe
+
+
+def stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    if not force and not stale():
+        return LIB
+    objs = []
+    for s in SOURCES:
+        obj = os.path.join(CSRC, os.path.splitext(s)[0] + ".o")
+        cmd = [hipcc(), *FLAGS, "-x", "hip", "-c", os.path.join(CSRC, s), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,656 @@
+// ftte_api.cpp -- the C ABI of include/ftte.h: context, device buffers, the per-sweep host
+// planner (directions -> layer tables, tiles, launches) and the launch sequence.
+//
+// There is no CPU fallback in this file: every entry point that computes on the grid needs a
+// HIP device and fails with FTTE_ERR_NO_DEVICE otherwise.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ftte.h"
+#include "ftte_geometry.h"
+#include "ftte_internal.h"
+#include "ftte_kernels.h"
+
+using namespace ftte;
+
+namespace {
+
+std::string g_create_error;
+
+// one planned direction
+struct DirPlan {
+    int izone = 0, layout = 0;
+    double phi = 0, theta = 0, w = 0;
+    int64_t org = 0;
+    int si = 0, sv = 0, su = 0;
+    int u_lo = 1, v_lo = 1, ntu = 0, ntv = 0;
+    size_t layer_off = 0; // into the layer table
+    int slot = 0;
+};
+
+struct LaunchPlan {
+    int layout = 0;
+    bool first = false;
+    std::vector<int> dirs; // indices into Plan::dirs, position = slot
+    size_t item_off = 0;
+    int nitems = 0;
+    int64_t updates = 0;
+};
+
+struct Plan {
+    bool valid = false;
+    // key
+    int n = 0, rows = 0, slots = 0;
+    double box = 0;
+    std::vector<double> phi, theta, w;
+    // content
+    std::vector<DirPlan> dirs;
+    std::vector<LayerRec> layers;
+    std::vector<WorkItem> items;
+    std::vector<LaunchPlan> launches;
+    bool used[3][kMaxSlots] = {};
+};
+
+struct LaunchTiming {
+    hipEvent_t start = nullptr, stop = nullptr;
+    int64_t updates = 0;
+};
+
+} // namespace
+
+struct ftte_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    bool grid_set = false;
+    int n = 0;
+    int64_t ncell = 0;
+    double box = 0;
+
+    int nnu = 0;
+    double *kappa[3] = {nullptr, nullptr, nullptr}; // layouts 0,1,2
+    bool kappa_ready[3] = {false, false, false};
+    size_t kappa_cap = 0; // elements per layout buffer
+
+    double *acc[3][kMaxSlots] = {};
+    size_t acc_cap = 0; // elements per accumulator
+
+    int rows = 8, slots = 4;
+
+    Plan plan;
+    LayerRec *d_layers = nullptr; size_t d_layers_cap = 0;
+    WorkItem *d_items = nullptr;  size_t d_items_cap = 0;
+    double *d_uvb = nullptr;      size_t d_uvb_cap = 0;
+    bool plan_uploaded = false;
+
+    std::vector<LaunchTiming> timing;
+    int timing_used = 0;
+};
+
+namespace {
+
+int fail(ftte_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+#define FTTE_HIP(c, call)                                                                                          \
+    do {                                                                                                           \
+        hipError_t e_ = (call);                                                                                    \
+        if (e_ != hipSuccess)                                                                                      \
+            return fail((c), FTTE_ERR_NO_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_));               \
+    } while (0)
+
+int fold_status(int rc)
+{
+    return rc == 1 ? FTTE_ERR_PHI : rc == 2 ? FTTE_ERR_THETA : FTTE_ERR_DOMINANT_AXIS;
+}
+
+// ---- planner ------------------------------------------------------------------------------------
+// Turns the direction list into what the kernel consumes.  O(ndir * (n + tiles)) host work,
+// cached in the context for as long as the directions, the grid and the tuning stay the same.
+int build_plan(ftte_ctx *c, int ndir, const double *phi, const double *theta, const double *w)
+{
+    Plan &P = c->plan;
+    const int n = c->n, rows = c->rows, slots = c->slots;
+    if (P.valid && P.n == n && P.rows == rows && P.slots == slots && P.box == c->box && (int)P.phi.size() == ndir &&
+        (ndir == 0 || (!std::memcmp(P.phi.data(), phi, sizeof(double) * ndir) &&
+                       !std::memcmp(P.theta.data(), theta, sizeof(double) * ndir) &&
+                       !std::memcmp(P.w.data(), w, sizeof(double) * ndir))))
+        return FTTE_OK;
+
+    P = Plan();
+    P.n = n; P.rows = rows; P.slots = slots; P.box = c->box;
+    P.phi.assign(phi, phi + ndir); P.theta.assign(theta, theta + ndir); P.w.assign(w, w + ndir);
+    P.dirs.resize(ndir);
+    P.layers.resize((size_t)ndir * n);
+    c->plan_uploaded = false;
+
+    const double cell = c->box / (double)n; // cellSizeAbsoluteUnits, equiSources.f90:1570
+    std::vector<ftte_pattern> pat(n);
+    std::vector<int> du_cum(n + 1), dv_cum(n + 1);
+    int in_layout[3] = {0, 0, 0};
+    const long nn = (long)n * n;
+
+    for (int d = 0; d < ndir; ++d) {
+        DirPlan &D = P.dirs[d];
+        D.w = w[d];
+        int rc = fold_direction(phi[d], theta[d], &D.phi, &D.theta, &D.izone);
+        if (rc) {
+            char buf[160];
+            std::snprintf(buf, sizeof buf, "direction %d (phi=%.17g, theta=%.17g) cannot be folded: %s", d, phi[d], theta[d],
+                          rc == 1 ? "phi on a quadrant boundary" : rc == 2 ? "theta outside (-pi/2,0)u(0,pi/2)"
+                                                                           : "tie between dominant axes");
+            return fail(c, fold_status(rc), buf);
+        }
+        if (layer_patterns(n, D.phi, D.theta, pat.data())) {
+            char buf[128];
+            std::snprintf(buf, sizeof buf, "direction %d: ray pattern left the unit cell (setPattern consistency check)", d);
+            return fail(c, FTTE_ERR_PATTERN, buf);
+        }
+
+        // memory frame of this izone: which storage axis the march runs along decides the layout;
+        // within it u = the sweep axis that lands on the contiguous storage axis
+        ZoneMap zm;
+        zone_map(D.izone, &zm);
+        int march_c = 0;
+        for (int a = 0; a < 3; ++a) if (zm.src[a] == 0) march_c = a;
+        D.layout = march_c;
+        const int fast_c = (march_c == 2) ? 1 : 2;
+        const int mid_c = (march_c == 0) ? 1 : 0;
+        const bool u_is_k = zm.src[fast_c] == 2;
+        D.su = zm.mirror[fast_c] ? -1 : 1;
+        D.sv = zm.mirror[mid_c] ? -n : n;
+        D.si = (int)(zm.mirror[march_c] ? -nn : nn);
+        D.org = (zm.mirror[fast_c] ? n : -1) + (zm.mirror[mid_c] ? (long)n * n : -(long)n) +
+                (zm.mirror[march_c] ? (long)n * nn : -nn);
+
+        // layers: reference chain -> kernel-frame class, lengths in chain order, cumulative drift
+        D.layer_off = (size_t)d * n;
+        int du = 0, dv = 0;
+        for (int i = 0; i < n; ++i) {
+            const ftte_pattern &p = pat[i];
+            LayerRec &R = P.layers[D.layer_off + i];
+            R.dpath[0] = cell * p.xy_len;
+            R.dpath[1] = R.dpath[2] = 0.0;
+            int rc_class = RC_ONE, third_first = 0, step_k = 0, step_j = 0;
+            if (p.xz_active && p.yz_active) {
+                step_k = step_j = 1;
+                if (p.xy_top == 3) { // xy -> yz -> xz (the xz piece reaches the top)
+                    R.dpath[1] = cell * p.yz_len; R.dpath[2] = cell * p.xz_len;
+                    rc_class = u_is_k ? RC_THREE_U : RC_THREE_V;
+                    third_first = 1; // mean adds xy, xz, yz: the chain's third piece before its second
+                } else {             // xy -> xz -> yz
+                    R.dpath[1] = cell * p.xz_len; R.dpath[2] = cell * p.yz_len;
+                    rc_class = u_is_k ? RC_THREE_V : RC_THREE_U;
+                }
+            } else if (p.yz_active) { // xy -> yz: one cell further along sweep-k
+                step_k = 1;
+                R.dpath[1] = cell * p.yz_len;
+                rc_class = u_is_k ? RC_TWO_U : RC_TWO_V;
+            } else if (p.xz_active) { // xy -> xz: one cell further along sweep-j
+                step_j = 1;
+                R.dpath[1] = cell * p.xz_len;
+                rc_class = u_is_k ? RC_TWO_V : RC_TWO_U;
+            }
+            R.info = rc_class | (third_first << 3);
+            R.drift = (du & 0xffff) | (dv << 16);
+            du_cum[i] = du; dv_cum[i] = dv;
+            du += u_is_k ? step_k : step_j;
+            dv += u_is_k ? step_j : step_k;
+        }
+        // rays present at the last layer start at label -drift (base cell 0, second piece in cell 1)
+        D.u_lo = 1 - du_cum[n - 1];
+        D.v_lo = 1 - dv_cum[n - 1];
+        D.ntu = (n - D.u_lo + 1 + 62) / 63;
+        D.ntv = (n - D.v_lo + 1 + rows - 2) / (rows - 1);
+        D.slot = in_layout[D.layout]++ % slots;
+    }
+
+    // launches: per layout, batches of `slots` directions in input order
+    for (int layout = 0; layout < 3; ++layout) {
+        std::vector<int> members;
+        for (int d = 0; d < ndir; ++d) if (P.dirs[d].layout == layout) members.push_back(d);
+        for (size_t b = 0; b < members.size(); b += slots) {
+            LaunchPlan LP;
+            LP.layout = layout;
+            LP.first = (b == 0);
+            LP.item_off = P.items.size();
+            for (size_t s = b; s < std::min(members.size(), b + (size_t)slots); ++s) {
+                const int d = members[s];
+                const DirPlan &D = P.dirs[d];
+                const int slot = (int)(s - b);
+                LP.dirs.push_back(d);
+                P.used[layout][slot] = true;
+                const LayerRec *Ls = &P.layers[D.layer_off];
+                for (int tv = 0; tv < D.ntv; ++tv) {
+                    for (int tu = 0; tu < D.ntu; ++tu) {
+                        // owned labels of this tile; a layer is active when any owned ray, or the cell one
+                        // step beyond it, is inside the domain
+                        const int ul_min = D.u_lo + 63 * tu, ul_max = ul_min + 62;
+                        const int vl_min = D.v_lo + (rows - 1) * tv, vl_max = vl_min + rows - 2;
+                        int i_first = 0, i_last = -1;
+                        for (int i = 1; i <= n; ++i) {
+                            const int cu_d = (int)(short)(Ls[i - 1].drift & 0xffff), cv_d = Ls[i - 1].drift >> 16;
+                            const bool act = ul_min + cu_d <= n && ul_max + cu_d + 1 >= 1 && vl_min + cv_d <= n &&
+                                             vl_max + cv_d + 1 >= 1;
+                            if (act) { if (!i_first) i_first = i; i_last = i; }
+                        }
+                        if (!i_first) continue;
+                        WorkItem it;
+                        it.slot = (int16_t)slot; it.tu = (int16_t)tu; it.tv = (int16_t)tv;
+                        it.i_first = (int16_t)i_first; it.i_last = (int16_t)i_last; it.pad = 0;
+                        P.items.push_back(it);
+                    }
+                }
+                LP.updates += (int64_t)n * n * n;
+            }
+            LP.nitems = (int)(P.items.size() - LP.item_off);
+            // longest marches first, so that the short corner tiles fill the tail of the launch
+            std::stable_sort(P.items.begin() + LP.item_off, P.items.end(), [](const WorkItem &a, const WorkItem &b) {
+                return (a.i_last - a.i_first) > (b.i_last - b.i_first);
+            });
+            P.launches.push_back(LP);
+        }
+    }
+    P.valid = true;
+    return FTTE_OK;
+}
+
+template <typename T> int ensure(ftte_ctx *c, T **p, size_t *cap, size_t need)
+{
+    if (*cap >= need && *p) return FTTE_OK;
+    if (*p) FTTE_HIP(c, hipFree(*p));
+    *p = nullptr; *cap = 0;
+    FTTE_HIP(c, hipMalloc((void **)p, std::max<size_t>(need, 1) * sizeof(T)));
+    *cap = need;
+    return FTTE_OK;
+}
+
+int ensure_kappa(ftte_ctx *c, int nnu)
+{
+    const size_t need = (size_t)nnu * c->ncell;
+    if (c->kappa[0] && c->kappa_cap >= need) return FTTE_OK;
+    for (int l = 0; l < 3; ++l) if (c->kappa[l]) { FTTE_HIP(c, hipFree(c->kappa[l])); c->kappa[l] = nullptr; }
+    FTTE_HIP(c, hipMalloc((void **)&c->kappa[0], need * sizeof(double)));
+    c->kappa_cap = need;
+    return FTTE_OK;
+}
+
+int check_ready(ftte_ctx *c, bool need_kappa)
+{
+    if (!c) return FTTE_ERR_ARG;
+    if (!c->grid_set) return fail(c, FTTE_ERR_STATE, "ftte_set_grid has not been called");
+    if (need_kappa && (!c->nnu || !c->kappa[0])) return fail(c, FTTE_ERR_STATE, "no opacities: call ftte_set_opacity / ftte_set_species first");
+    return FTTE_OK;
+}
+
+} // namespace
+
+// =================================================================================================
+extern "C" {
+
+int ftte_create(ftte_ctx **out, int ndev, const int *dev_ids)
+{
+    if (!out) return fail(nullptr, FTTE_ERR_ARG, "ftte_create: ctx is NULL");
+    *out = nullptr;
+    if (ndev != 1)
+        return fail(nullptr, FTTE_ERR_UNSUPPORTED,
+                    "ftte_create: one context drives one device (ndev must be 1); run one process per GPU and reduce J "
+                    "with RCCL in the host driver");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, FTTE_ERR_NO_DEVICE, std::string("ftte_create: no HIP device (") +
+                                                     (e != hipSuccess ? hipGetErrorString(e) : "device count is 0") + ")");
+    int dev = 0;
+    if (dev_ids) dev = dev_ids[0];
+    else if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (dev < 0 || dev >= count) return fail(nullptr, FTTE_ERR_ARG, "ftte_create: device ordinal out of range");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(nullptr, FTTE_ERR_NO_DEVICE, "hipGetDeviceProperties failed");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, FTTE_ERR_NO_DEVICE, std::string("ftte_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+    ftte_ctx *c = new ftte_ctx;
+    c->device = dev;
+    if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return fail(nullptr, FTTE_ERR_NO_DEVICE, "ftte_create: cannot create a stream on the device");
+    }
+    *out = c;
+    return FTTE_OK;
+}
+
+int ftte_destroy(ftte_ctx *c)
+{
+    if (!c) return FTTE_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int l = 0; l < 3; ++l) {
+        if (c->kappa[l]) (void)hipFree(c->kappa[l]);
+        for (int s = 0; s < kMaxSlots; ++s) if (c->acc[l][s]) (void)hipFree(c->acc[l][s]);
+    }
+    if (c->d_layers) (void)hipFree(c->d_layers);
+    if (c->d_items) (void)hipFree(c->d_items);
+    if (c->d_uvb) (void)hipFree(c->d_uvb);
+    for (auto &t : c->timing) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return FTTE_OK;
+}
+
+const char *ftte_last_error(const ftte_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int ftte_set_grid(ftte_ctx *c, int nx, int ny, int nz, int64_t ncell, const int32_t *level, double box_cm)
+{
+    if (!c) return FTTE_ERR_ARG;
+    if (nx < 1 || !level || ncell < 1 || !(box_cm > 0.0)) return fail(c, FTTE_ERR_ARG, "ftte_set_grid: bad argument");
+    if (nx != ny || nx != nz) return fail(c, FTTE_ERR_NOT_CUBIC, "base grid needs to be of size n^3");
+    if (nx > 32000) return fail(c, FTTE_ERR_UNSUPPORTED, "ftte_set_grid: n > 32000");
+    // walk the depth-first leaf list exactly as createFullyThreadedStructure does
+    // (readCellArray.f90:154-187): each base cell consumes one subtree
+    const int64_t nbase = (int64_t)nx * nx * nx;
+    int64_t cur = 0;
+    bool refined = false;
+    for (int64_t b = 0; b < nbase; ++b) {
+        // iterative subtree walk: `open[l]` children still expected at level l
+        int open[64];
+        int depth = 0;
+        open[0] = 1;
+        while (depth >= 0) {
+            if (open[depth] == 0) { --depth; continue; }
+            if (cur >= ncell) return fail(c, FTTE_ERR_LEVELS, "error in levels: level list ends inside a refined cell");
+            const int lv = level[cur];
+            if (lv == depth) { ++cur; --open[depth]; }
+            else if (lv > depth) {
+                if (depth + 1 >= 63) return fail(c, FTTE_ERR_LEVELS, "error in levels: more than 62 levels");
+                --open[depth]; open[++depth] = 8; refined = true;
+            } else return fail(c, FTTE_ERR_LEVELS, "error in levels: level list is not a depth-first leaf list");
+        }
+    }
+    if (cur != ncell) return fail(c, FTTE_ERR_LEVELS, "error in levels: level list longer than the tree it describes");
+    if (refined)
+        return fail(c, FTTE_ERR_UNSUPPORTED,
+                    "ftte_set_grid: refined cell arrays (AMR) are valid input but the device sweep of this build handles "
+                    "uniform grids only");
+    if (c->grid_set && (c->n != nx || c->ncell != ncell)) {
+        // a different grid: drop everything sized by the old one
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        for (int l = 0; l < 3; ++l) {
+            if (c->kappa[l]) { (void)hipFree(c->kappa[l]); c->kappa[l] = nullptr; }
+            for (int s = 0; s < kMaxSlots; ++s) if (c->acc[l][s]) { (void)hipFree(c->acc[l][s]); c->acc[l][s] = nullptr; }
+        }
+        c->kappa_cap = c->acc_cap = 0;
+        c->nnu = 0;
+    }
+    c->n = nx; c->ncell = ncell; c->box = box_cm; c->grid_set = true;
+    c->kappa_ready[0] = c->kappa_ready[1] = c->kappa_ready[2] = false;
+    c->plan.valid = false;
+    return FTTE_OK;
+}
+
+int ftte_set_opacity(ftte_ctx *c, int nnu, const double *kappa)
+{
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (nnu < 1 || !kappa) return fail(c, FTTE_ERR_ARG, "ftte_set_opacity: bad argument");
+    FTTE_HIP(c, hipSetDevice(c->device));
+    FTTE_HIP(c, hipStreamSynchronize(c->stream));
+    if ((rc = ensure_kappa(c, nnu))) return rc;
+    FTTE_HIP(c, hipMemcpyAsync(c->kappa[0], kappa, sizeof(double) * nnu * c->ncell, hipMemcpyHostToDevice, c->stream));
+    FTTE_HIP(c, hipStreamSynchronize(c->stream));
+    c->nnu = nnu;
+    c->kappa_ready[0] = true; c->kappa_ready[1] = c->kappa_ready[2] = false;
+    return FTTE_OK;
+}
+
+int ftte_set_opacity_device(ftte_ctx *c, int nnu, const double *kappa_dev)
+{
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (nnu < 1 || !kappa_dev) return fail(c, FTTE_ERR_ARG, "ftte_set_opacity_device: bad argument");
+    FTTE_HIP(c, hipSetDevice(c->device));
+    if ((rc = ensure_kappa(c, nnu))) return rc;
+    FTTE_HIP(c, hipMemcpyAsync(c->kappa[0], kappa_dev, sizeof(double) * nnu * c->ncell, hipMemcpyDeviceToDevice, c->stream));
+    c->nnu = nnu;
+    c->kappa_ready[0] = true; c->kappa_ready[1] = c->kappa_ready[2] = false;
+    return FTTE_OK;
+}
+
+int ftte_set_species(ftte_ctx *c, int nnu, const double *HI, const double *HeI, const double *HeII, const double *beta)
+{
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (nnu < 1 || !HI || !HeI || !HeII || !beta) return fail(c, FTTE_ERR_ARG, "ftte_set_species: bad argument");
+    FTTE_HIP(c, hipSetDevice(c->device));
+    FTTE_HIP(c, hipStreamSynchronize(c->stream));
+    if ((rc = ensure_kappa(c, nnu))) return rc;
+    double *tmp = nullptr;
+    const size_t nc = (size_t)c->ncell;
+    FTTE_HIP(c, hipMalloc((void **)&tmp, sizeof(double) * (3 * nc + 3 * (size_t)nnu)));
+    hipError_t e = hipMemcpyAsync(tmp, HI, sizeof(double) * nc, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(tmp + nc, HeI, sizeof(double) * nc, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(tmp + 2 * nc, HeII, sizeof(double) * nc, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(tmp + 3 * nc, beta, sizeof(double) * 3 * nnu, hipMemcpyHostToDevice, c->stream);
+    int lrc = 0;
+    if (e == hipSuccess) lrc = launch_opacity(tmp, tmp + nc, tmp + 2 * nc, tmp + 3 * nc, c->kappa[0], (long)nc, nnu, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(c, FTTE_ERR_NO_DEVICE, std::string("ftte_set_species: ") + hipGetErrorString(e));
+    if (lrc) return fail(c, FTTE_ERR_NO_DEVICE, "ftte_set_species: kernel launch failed");
+    c->nnu = nnu;
+    c->kappa_ready[0] = true; c->kappa_ready[1] = c->kappa_ready[2] = false;
+    return FTTE_OK;
+}
+
+int ftte_set_emissivity(ftte_ctx *c, const double *eta)
+{
+    if (!c) return FTTE_ERR_ARG;
+    if (eta)
+        return fail(c, FTTE_ERR_UNSUPPORTED,
+                    "ftte_set_emissivity: only the reference's zero emissivity (eta = NULL, transportRoutinesModule.f90:673-675) "
+                    "is implemented in this build");
+    return FTTE_OK;
+}
+
+int ftte_set_option(ftte_ctx *c, const char *key, int value)
+{
+    if (!c || !key) return FTTE_ERR_ARG;
+    if (!std::strcmp(key, "rows")) {
+        if (value != 4 && value != 8 && value != 16) return fail(c, FTTE_ERR_ARG, "rows must be 4, 8 or 16");
+        c->rows = value;
+    } else if (!std::strcmp(key, "slots")) {
+        if (value < 1 || value > kMaxSlots) return fail(c, FTTE_ERR_ARG, "slots must be 1..16");
+        c->slots = value;
+    } else return fail(c, FTTE_ERR_ARG, std::string("unknown option: ") + key);
+    c->plan.valid = false;
+    return FTTE_OK;
+}
+
+int ftte_diffuse_sweep_device(ftte_ctx *c, int ndir, const double *phi, const double *theta, const double *w,
+                              const double *uvb, double *J_dev, void *stream_v)
+{
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (ndir < 0 || (ndir > 0 && (!phi || !theta || !w)) || !uvb || !J_dev)
+        return fail(c, FTTE_ERR_ARG, "ftte_diffuse_sweep: bad argument");
+    FTTE_HIP(c, hipSetDevice(c->device));
+    hipStream_t stream = stream_v ? (hipStream_t)stream_v : c->stream;
+    const int n = c->n, nnu = c->nnu;
+    const size_t per_acc = (size_t)nnu * c->ncell;
+
+    if ((rc = build_plan(c, ndir, phi, theta, w))) return rc;
+    Plan &P = c->plan;
+
+    // everything below overwrites device tables the previous sweep may still be reading
+    FTTE_HIP(c, hipStreamSynchronize(stream));
+    if (stream != c->stream) FTTE_HIP(c, hipStreamSynchronize(c->stream));
+
+    if (!c->plan_uploaded) {
+        if ((rc = ensure(c, &c->d_layers, &c->d_layers_cap, P.layers.size()))) return rc;
+        if ((rc = ensure(c, &c->d_items, &c->d_items_cap, P.items.size()))) return rc;
+        if (!P.layers.empty())
+            FTTE_HIP(c, hipMemcpy(c->d_layers, P.layers.data(), sizeof(LayerRec) * P.layers.size(), hipMemcpyHostToDevice));
+        if (!P.items.empty())
+            FTTE_HIP(c, hipMemcpy(c->d_items, P.items.data(), sizeof(WorkItem) * P.items.size(), hipMemcpyHostToDevice));
+        c->plan_uploaded = true;
+    }
+    if ((rc = ensure(c, &c->d_uvb, &c->d_uvb_cap, (size_t)nnu))) return rc;
+    FTTE_HIP(c, hipMemcpy(c->d_uvb, uvb, sizeof(double) * nnu, hipMemcpyHostToDevice));
+
+    // accumulators sized for this nnu
+    if (c->acc_cap < per_acc) {
+        for (int l = 0; l < 3; ++l)
+            for (int s = 0; s < kMaxSlots; ++s)
+                if (c->acc[l][s]) { FTTE_HIP(c, hipFree(c->acc[l][s])); c->acc[l][s] = nullptr; }
+        c->acc_cap = per_acc;
+    }
+    for (int l = 0; l < 3; ++l) {
+        bool any = false;
+        for (int s = 0; s < kMaxSlots; ++s) {
+            if (!P.used[l][s]) continue;
+            any = true;
+            if (!c->acc[l][s]) FTTE_HIP(c, hipMalloc((void **)&c->acc[l][s], sizeof(double) * c->acc_cap));
+        }
+        // opacity in the layout this march axis needs
+        if (any && !c->kappa_ready[l]) {
+            if (!c->kappa[l]) FTTE_HIP(c, hipMalloc((void **)&c->kappa[l], sizeof(double) * c->kappa_cap));
+            if (launch_to_layout(l, c->kappa[0], c->kappa[l], n, nnu, (long)c->ncell, stream))
+                return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
+            c->kappa_ready[l] = true;
+        }
+    }
+
+    // events for the launch records
+    while (c->timing.size() < P.launches.size()) {
+        LaunchTiming t;
+        FTTE_HIP(c, hipEventCreate(&t.start));
+        FTTE_HIP(c, hipEventCreate(&t.stop));
+        c->timing.push_back(t);
+    }
+    c->timing_used = 0;
+
+    for (size_t li = 0; li < P.launches.size(); ++li) {
+        const LaunchPlan &LP = P.launches[li];
+        LaunchRec L;
+        std::memset(&L, 0, sizeof L);
+        for (size_t s = 0; s < LP.dirs.size(); ++s) {
+            const DirPlan &D = P.dirs[LP.dirs[s]];
+            DirRec &R = L.dir[s];
+            R.layers = c->d_layers + D.layer_off;
+            R.kappa = c->kappa[LP.layout];
+            R.J = c->acc[LP.layout][s];
+            R.org = D.org;
+            R.si = D.si; R.sv = D.sv; R.su = D.su;
+            R.u_lo = D.u_lo; R.v_lo = D.v_lo;
+            R.first = LP.first ? 1 : 0;
+            R.w = D.w;
+        }
+        L.items = c->d_items + LP.item_off;
+        L.uvb = c->d_uvb;
+        L.group_stride = c->ncell;
+        L.n = n;
+        L.nitems = LP.nitems;
+        LaunchTiming &T = c->timing[li];
+        T.updates = LP.updates * nnu;
+        FTTE_HIP(c, hipEventRecord(T.start, stream));
+        if (launch_sweep(L, c->rows, nnu, stream)) return fail(c, FTTE_ERR_NO_DEVICE, "sweep kernel launch failed");
+        FTTE_HIP(c, hipEventRecord(T.stop, stream));
+        c->timing_used = (int)li + 1;
+    }
+
+    // J = sum of the accumulators, layout 0 first, slots in order
+    const double *accs[3 * kMaxSlots];
+    int layouts[3 * kMaxSlots], count = 0;
+    for (int l = 0; l < 3; ++l)
+        for (int s = 0; s < kMaxSlots; ++s)
+            if (P.used[l][s]) { accs[count] = c->acc[l][s]; layouts[count++] = l; }
+    if (launch_merge(accs, layouts, count, J_dev, n, nnu, (long)c->ncell, stream))
+        return fail(c, FTTE_ERR_NO_DEVICE, "merge kernel launch failed");
+    return FTTE_OK;
+}
+
+int ftte_diffuse_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, const double *w, const double *uvb,
+                       double *J)
+{
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (!J) return fail(c, FTTE_ERR_ARG, "ftte_diffuse_sweep: J is NULL");
+    FTTE_HIP(c, hipSetDevice(c->device));
+    double *J_dev = nullptr;
+    const size_t bytes = sizeof(double) * (size_t)c->nnu * c->ncell;
+    FTTE_HIP(c, hipMalloc((void **)&J_dev, bytes));
+    rc = ftte_diffuse_sweep_device(c, ndir, phi, theta, w, uvb, J_dev, nullptr);
+    hipError_t e = hipSuccess;
+    if (!rc) e = hipMemcpyAsync(J, J_dev, bytes, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e2 = hipStreamSynchronize(c->stream);
+    (void)hipFree(J_dev);
+    if (rc) return rc;
+    if (e != hipSuccess || e2 != hipSuccess)
+        return fail(c, FTTE_ERR_NO_DEVICE, std::string("ftte_diffuse_sweep: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+    return FTTE_OK;
+}
+
+int ftte_launch_count(const ftte_ctx *c) { return c ? c->timing_used : 0; }
+
+int ftte_launch_info(ftte_ctx *c, int idx, double *ms, int64_t *updates)
+{
+    if (!c || idx < 0 || idx >= c->timing_used) return FTTE_ERR_ARG;
+    float t = 0.f;
+    FTTE_HIP(c, hipEventElapsedTime(&t, c->timing[idx].start, c->timing[idx].stop));
+    if (ms) *ms = t;
+    if (updates) *updates = c->timing[idx].updates;
+    return FTTE_OK;
+}
+
+// ---- host geometry ----------------------------------------------------------------------------------
+int ftte_rotate_indices(int i, int j, int k, int nx, int ny, int nz, int izone, int *ic, int *jc, int *kc)
+{
+    if (!ic || !jc || !kc) return FTTE_ERR_ARG;
+    return rotate_indices(i, j, k, nx, ny, nz, izone, ic, jc, kc) ? FTTE_ERR_IZONE : FTTE_OK;
+}
+
+int ftte_pix2ang_nest(int nside, int64_t ipix, double *phi, double *theta)
+{
+    if (!phi || !theta) return FTTE_ERR_ARG;
+    return pix2ang_nest(nside, ipix, phi, theta) ? FTTE_ERR_PIXEL : FTTE_OK;
+}
+
+int ftte_fold_direction(double phi_large, double theta_large, double *phi, double *theta, int *izone)
+{
+    if (!phi || !theta || !izone) return FTTE_ERR_ARG;
+    const int rc = fold_direction(phi_large, theta_large, phi, theta, izone);
+    return rc ? fold_status(rc) : FTTE_OK;
+}
+
+int ftte_set_pattern(ftte_pattern *pattern, double phi, double theta)
+{
+    if (!pattern) return FTTE_ERR_ARG;
+    return set_pattern(pattern, phi, theta) ? FTTE_ERR_PATTERN : FTTE_OK;
+}
+
+int ftte_layer_patterns(int n, double phi, double theta, ftte_pattern *layers)
+{
+    if (n < 1 || !layers) return FTTE_ERR_ARG;
+    return layer_patterns(n, phi, theta, layers) ? FTTE_ERR_PATTERN : FTTE_OK;
+}
+
+void ftte_compute_cell_intensity(double *Jmean, double Iin, double Iout)
+{
+    // transportRoutinesModule.f90:1044-1048, the reference's own formula (host helper; the device
+    // evaluates the same mean through ftte_math.h)
+    if (Iout < Iin) *Jmean += (Iin - Iout) / std::log(Iin / Iout);
+    else *Jmean += 0.5 * (Iin + Iout);
+}
+
+} // extern "C"

@@ -1,0 +1,65 @@
+// ftte_internal.h -- records shared by the host planner (ftte_plan.cpp) and the kernels
+// (ftte_kernels.hip).  Plain structs, no HIP types.
+#pragma once
+#include <cstdint>
+
+namespace ftte {
+
+// ---- kernel-frame ray classes --------------------------------------------------------------
+// In the sweep frame of the reference a layer's ray is one of five chains
+// (setPattern, transportRoutinesModule.f90:7-85):  xy | xy->yz | xy->xz | xy->yz->xz | xy->xz->yz,
+// a yz segment living one cell further along sweep-k, an xz segment one cell further along
+// sweep-j.  The kernel works in a (u, v) frame: u = whichever of sweep-j / sweep-k is contiguous
+// in memory for the direction's izone (the wave's lane axis), v = the other one (rows held in
+// registers).  In that frame a chain is described by where its 2nd/3rd segments sit:
+enum RayClass : int {
+    RC_ONE = 0,     // xy only
+    RC_TWO_U = 1,   // 2nd segment in cell (v, u+1)
+    RC_TWO_V = 2,   // 2nd segment in cell (v+1, u)
+    RC_THREE_U = 3, // 2nd in (v, u+1), 3rd in (v+1, u+1)
+    RC_THREE_V = 4  // 2nd in (v+1, u), 3rd in (v+1, u+1)
+};
+
+// One layer of one direction, 32 bytes, read with a single scalar load.
+struct LayerRec {
+    double dpath[3];  // cell size * segment length, chain order (transportRoutinesModule.f90:651)
+    int32_t info;     // bits 0-2 RayClass; bit 3: the cell's mean adds the 3rd segment before the 2nd
+                      // (reference order is xy, xz, yz whatever the chain order)
+    int32_t drift;    // cumulative drift of the rays up to this layer: low 16 bits along u, high 16 along v
+};
+static_assert(sizeof(LayerRec) == 32, "LayerRec must be 32 bytes");
+
+// One direction as a launch sees it.
+struct DirRec {
+    const LayerRec *layers; // [n], device memory
+    const double *kappa;    // opacity in the layout of this direction's march axis, group 0
+    double *J;              // accumulator of this direction's slot, same layout, group 0
+    int64_t org;            // element offset of the virtual cell (i,v,u) = (0,0,0)
+    int32_t si, sv, su;     // element strides along march, v, u (signed: reflections)
+    int32_t u_lo, v_lo;     // label of the first owned ray along u / v
+    int32_t first;          // 1: J receives a plain store (first direction into this accumulator)
+    double w;               // quadrature weight
+};
+
+// One wave's work: a tile of 64 x ROWS rays (lane 0 and row 0 are read-only halo) of one
+// direction, marched from layer i_first to i_last.
+struct WorkItem {
+    int16_t slot;    // index into LaunchRec::dir
+    int16_t tu, tv;  // tile coordinates
+    int16_t i_first, i_last;
+    int16_t pad;
+};
+static_assert(sizeof(WorkItem) == 12, "WorkItem must be 12 bytes");
+
+constexpr int kMaxSlots = 16;
+
+struct LaunchRec {
+    DirRec dir[kMaxSlots];
+    const WorkItem *items;
+    const double *uvb;  // [nnu], device memory
+    int64_t group_stride; // elements between consecutive frequency groups (= ncell)
+    int32_t n;          // grid size
+    int32_t nitems;
+};
+
+} // namespace ftte

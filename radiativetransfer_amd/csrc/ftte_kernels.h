@@ -1,0 +1,19 @@
+// ftte_kernels.h -- launch wrappers of ftte_kernels.hip (all asynchronous on `stream`;
+// return 0, -1 bad argument, -2 launch failure)
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include "ftte_internal.h"
+
+namespace ftte {
+
+int launch_sweep(const LaunchRec &L, int rows, int nnu, hipStream_t stream);
+// cell-array order -> layout 1 ([jc][ic][kc]) or 2 ([kc][ic][jc]); nnu groups, group_stride apart
+int launch_to_layout(int layout, const double *src, double *dst, int n, int nnu, long group_stride, hipStream_t stream);
+// J (cell-array order) = acc[0] + acc[1] + ... in list order; layout[a] in {0,1,2}
+int launch_merge(const double *const *acc, const int *layout, int count, double *J, int n, int nnu, long group_stride,
+                 hipStream_t stream);
+int launch_opacity(const double *HI, const double *HeI, const double *HeII, const double *beta, double *kappa, long ncell,
+                   int nnu, hipStream_t stream);
+
+} // namespace ftte

@@ -1,0 +1,359 @@
+// ftte_kernels.hip -- CDNA4 (gfx950) kernels of the diffuse long-characteristics sweep.
+//
+// What is computed (per direction, per frequency group): the reference's cell transfer,
+//   transportRoutinesModule.f90:587-961  /  equiSources.f90:1580-1788,
+// on a uniform grid.  How it is organised has nothing in common with the reference's serial
+// pointer walk:
+//
+//  * After the izone rotation (rotateIndicesModule.f90) the march axis is sweep-i and every cell
+//    of a layer shares one ray pattern, so a physical ray is a chain of 1-3 segments per layer
+//    that drifts by at most one cell per layer along sweep-j and sweep-k, identically for all
+//    rays of the direction.  Chains never interact: the only coupling is that a cell's mean
+//    collects the segments of up to three different rays.
+//  * One wavefront owns a tile of 64 x ROWS rays: 64 lanes along u, the storage-contiguous axis
+//    of this direction's layout (every kappa/J access is a 512-byte coalesced row), ROWS rays
+//    per lane along v.  The ray intensities never leave registers for the whole march.
+//  * A cell's mean needs the 2nd/3rd segments of the rays one step lower in u and/or v: from
+//    lane-1 through a DPP wave shift, from the previous row through registers.  Lane 0 and row
+//    0 of every tile are therefore a read-only halo, recomputed by the neighbouring tile: no
+//    LDS, no barrier, no atomics, no inter-wave communication of any kind, and every cell of
+//    the grid is owned by exactly one lane of one wave per direction, which makes J a plain,
+//    deterministic read-modify-write.
+//  * The host turns each direction into a 32-byte-per-layer table (segment lengths, chain
+//    class, cumulative drift) that the wave reads with scalar loads; per-layer control flow is
+//    wave-uniform.
+//
+// Roofline: 24 algorithmic bytes per cell.direction.frequency update (kappa 8 B read, J 8 B
+// read + 8 B write), ~2 segments of ~45 fp64 VALU instructions each: HBM-bound by design,
+// with the fp64 pipe at 60-80 % when HBM saturates.
+#include <hip/hip_runtime.h>
+
+#include "ftte_internal.h"
+#include "ftte_kernels.h"
+#include "ftte_math.h"
+
+namespace ftte {
+
+// value held by lane-1 (lane 0 receives its own value back; it is a halo lane and never uses it)
+__device__ __forceinline__ double from_lane_below(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    // DPP wave_shr:1 -- a full-rate VALU move, no LDS crossbar
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// One segment of one ray.  EDGE: the cell may lie outside the domain, where the ray is
+// re-initialised with the inflow (transportRoutinesModule.f90:594-597) and adds nothing.
+template <bool EDGE>
+__device__ __forceinline__ double segment(double &I, double kap, double dpath, bool inside, double uvb)
+{
+    if (EDGE) {
+        double It = I;
+        const double m = ftte_segment(&It, kap * dpath);
+        I = inside ? It : uvb;
+        return inside ? m : 0.0;
+    }
+    return ftte_segment(&I, kap * dpath);
+}
+
+// One layer of one tile.  RC: chain class (ftte_internal.h).  I[r]: intensity of ray r of this
+// lane on entry to the layer / on exit.
+//   krow0 / jrow0 : pointers to the virtual element (row cv0 = row of ray 0, column 0) of this
+//                   layer's kappa / J plane; rows are sv elements apart, columns su.
+template <int ROWS, int RC, bool EDGE>
+__device__ __forceinline__ void layer_step(double (&I)[ROWS], const double *__restrict__ kplane,
+                                           double *__restrict__ jplane, int cv0, int cu, int n, int sv, int su,
+                                           double d0, double d1, double d2, bool third_first, double w, double uvb,
+                                           bool first, bool lane_owned)
+{
+    constexpr bool HAS_U = (RC == RC_TWO_U || RC == RC_THREE_U || RC == RC_THREE_V); // touches column u+1
+    constexpr bool HAS_V = (RC == RC_TWO_V || RC == RC_THREE_U || RC == RC_THREE_V); // touches row v+1
+    constexpr int NSEG = (RC == RC_ONE) ? 1 : (RC <= RC_TWO_V ? 2 : 3);
+
+    // lane-varying column offsets (elements), clamped into the domain for EDGE tiles
+    const int c0 = EDGE ? clampi(cu, 1, n) : cu;
+    const int c1 = EDGE ? clampi(cu + 1, 1, n) : cu + 1;
+    const int off0 = c0 * su, off1 = c1 * su;
+    const bool in_u0 = !EDGE || (cu >= 1 && cu <= n);
+    const bool in_u1 = !EDGE || (cu + 1 >= 1 && cu + 1 <= n);
+
+    // ---- issue every load of the layer up front ------------------------------------------------
+    double K0[ROWS + 1], K1[ROWS + 1], Jold[ROWS];
+#pragma unroll
+    for (int r = 0; r <= ROWS; ++r) {
+        const int row = EDGE ? clampi(cv0 + r, 1, n) : cv0 + r;
+        const double *rp = kplane + (long)row * sv;
+        const bool need0 = (r < ROWS) || (RC == RC_TWO_V || RC == RC_THREE_V);
+        const bool need1 = HAS_U && ((RC == RC_TWO_U) ? (r < ROWS) : (RC == RC_THREE_U) ? true : (r >= 1));
+        if (need0) K0[r] = rp[off0];
+        if (need1) K1[r] = rp[off1];
+    }
+#pragma unroll
+    for (int r = 1; r < ROWS; ++r) {
+        const int row = cv0 + r;
+        const bool own = lane_owned && in_u0 && (!EDGE || (row >= 1 && row <= n));
+        Jold[r] = 0.0;
+        if (!first && own) Jold[r] = jplane[(long)row * sv + off0];
+    }
+
+    // ---- march the rays of this lane through the layer, row by row -----------------------------
+    double prev1 = 0.0, prev2 = 0.0; // 2nd / 3rd segment means of the previous row (for HAS_V gathers)
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int row = cv0 + r;
+        const bool in_v0 = !EDGE || (row >= 1 && row <= n);
+        const bool in_v1 = !EDGE || (row + 1 >= 1 && row + 1 <= n);
+
+        double m0, m1 = 0.0, m2 = 0.0;
+        m0 = segment<EDGE>(I[r], K0[r], d0, in_v0 && in_u0, uvb);
+        if (RC == RC_TWO_U) m1 = segment<EDGE>(I[r], K1[r], d1, in_v0 && in_u1, uvb);
+        if (RC == RC_TWO_V) m1 = segment<EDGE>(I[r], K0[r + 1], d1, in_v1 && in_u0, uvb);
+        if (RC == RC_THREE_U) {
+            m1 = segment<EDGE>(I[r], K1[r], d1, in_v0 && in_u1, uvb);
+            m2 = segment<EDGE>(I[r], K1[r + 1], d2, in_v1 && in_u1, uvb);
+        }
+        if (RC == RC_THREE_V) {
+            m1 = segment<EDGE>(I[r], K0[r + 1], d1, in_v1 && in_u0, uvb);
+            m2 = segment<EDGE>(I[r], K1[r + 1], d2, in_v1 && in_u1, uvb);
+        }
+
+        // the cell (row, cu) collects: its own xy segment, and the 2nd / 3rd segments that end
+        // up in it, which belong to the rays one step lower in u and/or v
+        if (r >= 1) {
+            double g1 = 0.0, g2 = 0.0;
+            if (RC == RC_TWO_U) g1 = from_lane_below(m1);
+            if (RC == RC_TWO_V) g1 = prev1;
+            if (RC == RC_THREE_U) { g1 = from_lane_below(m1); g2 = from_lane_below(prev2); }
+            if (RC == RC_THREE_V) { g1 = prev1; g2 = from_lane_below(prev2); }
+            double acc = m0;
+            if (NSEG == 2) acc += g1;
+            if (NSEG == 3) {
+                // reference order: xy + xz + yz (transportRoutinesModule.f90:695-941)
+                const double a = third_first ? g2 : g1, b = third_first ? g1 : g2;
+                acc += a;
+                acc += b;
+            }
+            const bool own = lane_owned && in_u0 && in_v0;
+            if (own) jplane[(long)row * sv + off0] = Jold[r] + ftte_cell_mean(acc, NSEG, w);
+        }
+        if (HAS_V) { prev1 = m1; prev2 = m2; }
+        if (RC == RC_THREE_U) prev2 = m2;
+    }
+}
+
+template <int ROWS, bool EDGE>
+__device__ __forceinline__ void layer_dispatch(double (&I)[ROWS], int rc, const double *kplane, double *jplane, int cv0,
+                                               int cu, int n, int sv, int su, double d0, double d1, double d2,
+                                               bool third_first, double w, double uvb, bool first, bool lane_owned)
+{
+    switch (rc) {
+    case RC_ONE:
+        layer_step<ROWS, RC_ONE, EDGE>(I, kplane, jplane, cv0, cu, n, sv, su, d0, d1, d2, third_first, w, uvb, first, lane_owned);
+        break;
+    case RC_TWO_U:
+        layer_step<ROWS, RC_TWO_U, EDGE>(I, kplane, jplane, cv0, cu, n, sv, su, d0, d1, d2, third_first, w, uvb, first, lane_owned);
+        break;
+    case RC_TWO_V:
+        layer_step<ROWS, RC_TWO_V, EDGE>(I, kplane, jplane, cv0, cu, n, sv, su, d0, d1, d2, third_first, w, uvb, first, lane_owned);
+        break;
+    case RC_THREE_U:
+        layer_step<ROWS, RC_THREE_U, EDGE>(I, kplane, jplane, cv0, cu, n, sv, su, d0, d1, d2, third_first, w, uvb, first, lane_owned);
+        break;
+    default:
+        layer_step<ROWS, RC_THREE_V, EDGE>(I, kplane, jplane, cv0, cu, n, sv, su, d0, d1, d2, third_first, w, uvb, first, lane_owned);
+        break;
+    }
+}
+
+// grid: (nitems, nnu), block: one wavefront
+template <int ROWS>
+__global__ void __launch_bounds__(64) sweep_kernel(const LaunchRec L)
+{
+    const WorkItem item = L.items[blockIdx.x];
+    const int nu = blockIdx.y;
+    const DirRec &D = L.dir[item.slot];
+    const int lane = threadIdx.x;
+    const int n = L.n;
+
+    const double uvb = L.uvb[nu];
+    const double w = D.w;
+    const int sv = D.sv, su = D.su, si = D.si;
+    const bool first = D.first != 0;
+    const double *kbase = D.kappa + (long)nu * L.group_stride + D.org;
+    double *jbase = D.J + (long)nu * L.group_stride + D.org;
+
+    // labels of this lane's rays: u label of the lane, v label of its row 0 (both halo for index 0)
+    const int ul = D.u_lo + 63 * (int)item.tu + lane - 1;
+    const int vl0 = D.v_lo + (ROWS - 1) * (int)item.tv - 1;
+    const bool lane_owned = lane != 0;
+
+    double I[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) I[r] = uvb;
+
+    const LayerRec *__restrict__ layers = D.layers;
+    for (int i = item.i_first; i <= item.i_last; ++i) {
+        const LayerRec rec = layers[i - 1];
+        const int du = (int)(short)(rec.drift & 0xffff), dv = rec.drift >> 16;
+        const int cu = ul + du;
+        const int cv0 = vl0 + dv;
+        const int rc = rec.info & 7;
+        const bool third_first = (rec.info & 8) != 0;
+        const double *kplane = kbase + (long)i * si;
+        double *jplane = jbase + (long)i * si;
+
+        // interior test (wave-uniform): every cell any lane of the tile may touch, halo and +1
+        // offsets included, lies inside the domain
+        const int u_min = D.u_lo + 63 * (int)item.tu - 1 + du, v_min = cv0;
+        const bool interior = u_min >= 1 && u_min + 64 <= n && v_min >= 1 && v_min + ROWS <= n;
+        if (interior)
+            layer_dispatch<ROWS, false>(I, rc, kplane, jplane, cv0, cu, n, sv, su, rec.dpath[0], rec.dpath[1], rec.dpath[2],
+                                        third_first, w, uvb, first, lane_owned);
+        else
+            layer_dispatch<ROWS, true>(I, rc, kplane, jplane, cv0, cu, n, sv, su, rec.dpath[0], rec.dpath[1], rec.dpath[2],
+                                       third_first, w, uvb, first, lane_owned);
+    }
+}
+
+int launch_sweep(const LaunchRec &L, int rows, int nnu, hipStream_t stream)
+{
+    const dim3 grid(L.nitems, nnu), block(64);
+    if (L.nitems <= 0) return 0;
+    switch (rows) {
+    case 4: hipLaunchKernelGGL(sweep_kernel<4>, grid, block, 0, stream, L); break;
+    case 8: hipLaunchKernelGGL(sweep_kernel<8>, grid, block, 0, stream, L); break;
+    case 16: hipLaunchKernelGGL(sweep_kernel<16>, grid, block, 0, stream, L); break;
+    default: return -1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Layouts.  Cell-array order is [ic][jc][kc] (kc fastest).  A direction whose march axis is
+// storage-j reads layout 1 = [jc][ic][kc]; storage-k reads layout 2 = [kc][ic][jc], so that the
+// march axis is always the slowest and a sweep plane is always made of contiguous rows.
+// ------------------------------------------------------------------------------------------------
+
+// dst[jc][ic][kc] = src[ic][jc][kc]   (rows of n doubles move as they are)
+__global__ void __launch_bounds__(256) to_layout1_kernel(const double *__restrict__ src, double *__restrict__ dst, int n,
+                                                         long group_stride)
+{
+    const long g = blockIdx.z;
+    const int ic = blockIdx.y / n, jc = blockIdx.y % n;
+    const double *s = src + g * group_stride + ((long)ic * n + jc) * n;
+    double *d = dst + g * group_stride + ((long)jc * n + ic) * n;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) d[k] = s[k];
+}
+
+// dst[kc][ic][jc] = src[ic][jc][kc]   (per ic plane, a 32x32 tiled transpose through LDS)
+__global__ void __launch_bounds__(256) to_layout2_kernel(const double *__restrict__ src, double *__restrict__ dst, int n,
+                                                         long group_stride)
+{
+    __shared__ double tile[32][33];
+    const long g = blockIdx.z / n;
+    const int ic = blockIdx.z % n;
+    const int j0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
+    const double *s = src + g * group_stride + (long)ic * n * n;
+    double *d = dst + g * group_stride + (long)ic * n;
+    for (int r = ty; r < 32; r += 8)
+        if (j0 + r < n && k0 + tx < n) tile[r][tx] = s[(long)(j0 + r) * n + k0 + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (k0 + r < n && j0 + tx < n) d[(long)(k0 + r) * n * n + j0 + tx] = tile[tx][r];
+}
+
+int launch_to_layout(int layout, const double *src, double *dst, int n, int nnu, long group_stride, hipStream_t stream)
+{
+    if (layout == 1) {
+        const dim3 grid((n + 255) / 256, n * n, nnu);
+        hipLaunchKernelGGL(to_layout1_kernel, grid, dim3(256), 0, stream, src, dst, n, group_stride);
+    } else if (layout == 2) {
+        const dim3 grid((n + 31) / 32, (n + 31) / 32, n * nnu);
+        hipLaunchKernelGGL(to_layout2_kernel, grid, dim3(256), 0, stream, src, dst, n, group_stride);
+    } else return -1;
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// J[ic][jc][kc] = sum over the accumulators in list order (layout 0 first, then 1, then 2; within
+// a layout by slot).  One block per (32 jc x 32 kc) tile of one ic plane of one group.
+struct MergeRec {
+    const double *acc[3 * kMaxSlots];
+    int layout[3 * kMaxSlots];
+    int count;
+};
+
+__global__ void __launch_bounds__(256) merge_kernel(const MergeRec M, double *__restrict__ J, int n, long group_stride)
+{
+    __shared__ double tile[32][33];
+    const long g = blockIdx.z / n;
+    const int ic = blockIdx.z % n;
+    const int j0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    double sum[4] = {0.0, 0.0, 0.0, 0.0};
+    bool have = false;
+    for (int a = 0; a < M.count; ++a) {
+        const double *s = M.acc[a] + g * group_stride;
+        if (M.layout[a] == 2) {
+            // element (ic, jc, kc) sits at [kc][ic][jc]: read rows along jc, transpose through LDS
+            __syncthreads();
+            for (int q = 0; q < 4; ++q) {
+                const int r = ty + 8 * q; // kc offset
+                if (k0 + r < n && j0 + tx < n) tile[r][tx] = s[((long)(k0 + r) * n + ic) * n + j0 + tx];
+            }
+            __syncthreads();
+        }
+        for (int q = 0; q < 4; ++q) {
+            const int r = ty + 8 * q; // jc offset
+            const int jc = j0 + r, kc = k0 + tx;
+            if (jc >= n || kc >= n) continue;
+            double v;
+            if (M.layout[a] == 0) v = s[((long)ic * n + jc) * n + kc];
+            else if (M.layout[a] == 1) v = s[((long)jc * n + ic) * n + kc];
+            else v = tile[tx][r];
+            sum[q] = have ? sum[q] + v : v;
+        }
+        have = true;
+    }
+    for (int q = 0; q < 4; ++q) {
+        const int jc = j0 + ty + 8 * q, kc = k0 + tx;
+        if (jc < n && kc < n) J[g * group_stride + ((long)ic * n + jc) * n + kc] = sum[q];
+    }
+}
+
+int launch_merge(const double *const *acc, const int *layout, int count, double *J, int n, int nnu, long group_stride,
+                 hipStream_t stream)
+{
+    if (count > 3 * kMaxSlots) return -1;
+    MergeRec M;
+    M.count = count;
+    for (int a = 0; a < count; ++a) { M.acc[a] = acc[a]; M.layout[a] = layout[a]; }
+    const dim3 grid((n + 31) / 32, (n + 31) / 32, n * nnu);
+    hipLaunchKernelGGL(merge_kernel, grid, dim3(256), 0, stream, M, J, n, group_stride);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// kappa[g][c] = HI[c]*beta[0][g] + HeI[c]*beta[1][g] + HeII[c]*beta[2][g]   (equiSources.f90:4977-4980)
+__global__ void __launch_bounds__(256) opacity_kernel(const double *__restrict__ HI, const double *__restrict__ HeI,
+                                                      const double *__restrict__ HeII, const double *__restrict__ beta,
+                                                      double *__restrict__ kappa, long ncell, int nnu)
+{
+    for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < ncell; c += (long)gridDim.x * blockDim.x) {
+        const double a = HI[c], b = HeI[c], d = HeII[c];
+        for (int g = 0; g < nnu; ++g) kappa[(long)g * ncell + c] = a * beta[g] + b * beta[nnu + g] + d * beta[2 * nnu + g];
+    }
+}
+
+int launch_opacity(const double *HI, const double *HeI, const double *HeII, const double *beta, double *kappa, long ncell,
+                   int nnu, hipStream_t stream)
+{
+    const int blocks = (int)((ncell + 255) / 256 < 8192 ? (ncell + 255) / 256 : 8192);
+    hipLaunchKernelGGL(opacity_kernel, dim3(blocks), dim3(256), 0, stream, HI, HeI, HeII, beta, kappa, ncell, nnu);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+} // namespace ftte
