@@ -679,3 +679,14 @@ void fo_compute_opacities(int64_t ncell, int nnu, const double *HI, const double
         for (int64_t c = 0; c < ncell; ++c)
             kappa[(size_t)g * ncell + c] = HI[c] * beta[0 * nnu + g] + HeI[c] * beta[1 * nnu + g] + HeII[c] * beta[2 * nnu + g];
 }
+
+/* ----------------------------------------------------- device arithmetic, exposed for tests */
+void fo_device_attenuation(int64_t count, const double *tau, double *e, double *g)
+{
+    for (int64_t i = 0; i < count; ++i) ftte_attenuation(tau[i], &e[i], &g[i]);
+}
+
+void fo_device_cell_mean(int64_t count, const double *acc, int nseg, double w, double *out)
+{
+    for (int64_t i = 0; i < count; ++i) out[i] = ftte_cell_mean(acc[i], nseg, w);
+}

@@ -95,6 +95,11 @@ int fo_diffuse_sweep_tree(int n, int64_t ncell, const int32_t *level, int nnu, c
 void fo_compute_opacities(int64_t ncell, int nnu, const double *HI, const double *HeI, const double *HeII,
                           const double *beta, double *kappa);
 
+/* radiativetransfer_amd/csrc/ftte_math.h evaluated on the host, element-wise (for tests of the
+ * device arithmetic itself): e = exp(-tau), g = (1-exp(-tau))/tau; out = (acc/nseg)*w. */
+void fo_device_attenuation(int64_t count, const double *tau, double *e, double *g);
+void fo_device_cell_mean(int64_t count, const double *acc, int nseg, double w, double *out);
+
 #ifdef __cplusplus
 }
 #endif

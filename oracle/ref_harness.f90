@@ -48,6 +48,7 @@ program ref_harness
   real(kind=RealKind) :: box, uvbIn(3)
   character(len=512) :: caseName, outName
   integer :: bi, bj, bk
+  integer(kind=8) :: tick0, tick1, tickRate
 
   call get_command_argument(1, caseName)
   call get_command_argument(2, outName)
@@ -100,9 +101,13 @@ program ref_harness
 
   open(12, file=trim(outName), access='stream', form='unformatted', status='replace')
 
+  call system_clock(tick0, tickRate)
   do idir = 1, ndir
      call sweepOneDirection(phiIn(idir), thetaIn(idir), wIn(idir))
   enddo
+  call system_clock(tick1)
+  ! wall time of the direction loop alone (patterns + neighbour links + transport), for bench.py
+  write(*,'(a,1x,es16.8)') 'SWEEP_SECONDS', dble(tick1-tick0)/dble(tickRate)
 
   cursor = 0
   do bi = 1, n

@@ -146,7 +146,7 @@ class DiffuseTransfer:
     def set_opacity(self, kappa):
         """kappa[nnu][ncell] (numpy, host)."""
         kappa = _f64(kappa)
-        if kappa.ndim != 2 or kappa.shape[1] != self.ncell:
+        if kappa.ndim != 2 or (self.ncell and kappa.shape[1] != self.ncell):
             raise ValueError("kappa must have shape [nnu][ncell]")
         self._ok(self._lib.ftte_set_opacity(self._ctx, kappa.shape[0], _dp(kappa)))
         self.nnu = kappa.shape[0]

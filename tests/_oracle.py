@@ -49,6 +49,10 @@ def lib():
                                             C.c_int, dp, dp, dp, dp, dp, C.c_int, C.c_int, dp]
         L.fo_compute_opacities.argtypes = [C.c_int64, C.c_int, dp, dp, dp, dp, dp]
         L.fo_compute_opacities.restype = None
+        L.fo_device_attenuation.argtypes = [C.c_int64, dp, dp, dp]
+        L.fo_device_attenuation.restype = None
+        L.fo_device_cell_mean.argtypes = [C.c_int64, dp, C.c_int, C.c_double, dp]
+        L.fo_device_cell_mean.restype = None
         _lib = L
     return _lib
 
@@ -142,3 +146,17 @@ def compute_opacities(HI, HeI, HeII, beta):
     kappa = np.empty((nnu, len(HI)))
     lib().fo_compute_opacities(len(HI), nnu, _dp(HI), _dp(HeI), _dp(HeII), _dp(beta), _dp(kappa))
     return kappa
+
+
+def device_attenuation(tau):
+    tau = _f64(tau)
+    e, g = np.empty_like(tau), np.empty_like(tau)
+    lib().fo_device_attenuation(tau.size, _dp(tau), _dp(e), _dp(g))
+    return e, g
+
+
+def device_cell_mean(acc, nseg, w):
+    acc = _f64(acc)
+    out = np.empty_like(acc)
+    lib().fo_device_cell_mean(acc.size, _dp(acc), nseg, w, _dp(out))
+    return out

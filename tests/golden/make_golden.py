@@ -131,6 +131,10 @@ def main():
     for name, n, dirs in (("geometry_192dir_16layers", 16, _oracle.healpix_directions(3)),
                           ("geometry_12dir_256layers", 256, _oracle.healpix_directions(1))):
         _, geo = run_reference(n, np.zeros(0, np.int32), np.zeros((3, 0)), 1.0, uvb3, *dirs, dump_geometry=2)
+        # inactive pieces hold whatever the reference's freshly allocated pattern had in memory: blank them
+        lay = geo["layers"]
+        lay["xz"][lay["flags"][..., 0] == 0] = 0.0
+        lay["yz"][lay["flags"][..., 1] == 0] = 0.0
         save(name, n=n, phi_in=dirs[0], theta_in=dirs[1], izone=geo["izone"], phi=geo["phi"], theta=geo["theta"],
              layers=geo["layers"])
 

@@ -1,0 +1,227 @@
+"""Parity of the HIP path, through the C ABI (radiativetransfer_amd.api is a ctypes veneer over include/ftte.h),
+against the oracle and against the vectors the reference's own modules produced.
+
+Tolerances (fp64), all stated here:
+  * bitwise  -- against the oracle evaluated with the device arithmetic (csrc/ftte_math.h on the host), whenever the
+                order in which directions are summed is the same on both sides (single direction; or slots = 1
+                and all directions in one memory layout);
+  * SUM_RTOL -- same arithmetic, different summation order of the per-direction terms (slots, three layouts);
+  * reference-- against the reference formula (Iin-Iout)/log(Iin/Iout) (goldens, oracle REFERENCE arithmetic):
+                |J - Jref| <= 8 * noise + 12 n eps |Jref|, where `noise` is the per-cell rounding noise of the reference's
+                own quotient, eps/(2 tau) per segment (oracle/ftte_oracle.h), and 12 n eps covers 1-ulp differences of
+                exp along a chain of <= 3n segments.  For inputs whose segments all have tau >= 1e-3 this is < 1e-12 relative.
+"""
+import numpy as np
+import pytest
+
+import _oracle as O
+from radiativetransfer_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+EPS = np.finfo(np.float64).eps
+SUM_RTOL = 64 * EPS
+
+
+def one_per_izone():
+    phi, theta, _ = O.healpix_directions(3)
+    pick = {}
+    for p, t in zip(phi, theta):
+        pick.setdefault(O.fold_direction(p, t)[2], (p, t))
+    return [pick[z] for z in range(1, 25)]
+
+
+def reference_bound(n, J_ref, noise):
+    return 8 * noise + 12 * n * EPS * np.abs(J_ref)
+
+
+@pytest.mark.parametrize("rows", [4, 8, 16])
+@pytest.mark.parametrize("n", [5, 16, 70])
+def test_every_izone_bitwise(engine, rows, n):
+    """One direction per izone (all 24 rotations, all five ray classes), every row variant of the kernel, grids
+    smaller than a tile (5), one tile wide (16) and several tiles wide with ragged edges (70)."""
+    kappa, uvb, box = synthetic.uniform_workload(n, 2, seed=n, tau_median=0.3)
+    engine.set_option("rows", rows)
+    engine.set_uniform_grid(n, box)
+    engine.set_opacity(kappa)
+    for p, t in one_per_izone():
+        phi, theta, w = np.array([p]), np.array([t]), np.array([0.37])
+        J = engine.transport(phi, theta, w, uvb)
+        ref = O.sweep_uniform(n, kappa, box, phi, theta, w, uvb, arith=O.ARITH_DEVICE)
+        assert np.array_equal(J, ref), f"izone {O.fold_direction(p, t)[2]}"
+    engine.set_option("rows", 8)
+
+
+GOLDEN_UNIFORM = ["uniform8_transparent", "uniform16_constant", "uniform16_lognormal_24zones", "uniform24_lognormal_48dir"]
+
+
+@pytest.mark.parametrize("slots", [1, 4])
+@pytest.mark.parametrize("name", GOLDEN_UNIFORM)
+def test_reference_goldens(engine, golden, name, slots):
+    """The reference's own outputs (3 frequency groups, tests/golden/) within the tau-aware tolerance."""
+    g = golden(name)
+    n = int(g["n"])
+    args = (g["kappa"], float(g["box"]), g["phi"], g["theta"], g["w"], g["uvb"])
+    engine.set_option("slots", slots)
+    engine.set_grid(n, g["level"], float(g["box"]))
+    engine.set_opacity(g["kappa"])
+    J = engine.transport(g["phi"], g["theta"], g["w"], g["uvb"])
+    engine.set_option("slots", 4)
+    _, noise = O.sweep_uniform(n, *args, with_noise=True)
+    assert np.all(np.abs(J - g["J"]) <= reference_bound(n, g["J"], noise))
+    # and against the same arithmetic on the host: only the summation order differs
+    Jd = O.sweep_uniform(n, *args, arith=O.ARITH_DEVICE)
+    assert np.allclose(J, Jd, rtol=SUM_RTOL, atol=0)
+
+
+def test_eight_groups_as_three_reference_runs(engine):
+    """BASELINE's 8 frequency groups: groups are independent inside the sweep, so 8 groups must equal three
+    oracle runs on group triples (the reference hard-wires three groups)."""
+    n = 20
+    kappa, uvb, box = synthetic.uniform_workload(n, 8, seed=7, tau_median=0.4)
+    phi, theta, w = O.healpix_directions(2)
+    engine.set_uniform_grid(n, box)
+    engine.set_opacity(kappa)
+    J = engine.transport(phi, theta, w, uvb)
+    for lo in (0, 3, 5):
+        sl = slice(lo, lo + 3)
+        ref, noise = O.sweep_uniform(n, kappa[sl], box, phi, theta, w, uvb[sl], with_noise=True)
+        assert np.all(np.abs(J[sl] - ref) <= reference_bound(n, ref, noise))
+
+
+def test_transparent_and_empty(engine):
+    n = 33
+    engine.set_uniform_grid(n, 2.5)
+    engine.set_opacity(np.zeros((2, n ** 3)))
+    phi, theta, w = O.healpix_directions(2)
+    uvb = np.array([3e-21, 1e-22])
+    J = engine.transport(phi, theta, w, uvb)
+    assert np.allclose(J, (uvb * w.sum())[:, None], rtol=8 * EPS, atol=0)  # kappa = 0: J = uvb * sum(w)
+    J0 = engine.transport(phi[:0], theta[:0], w[:0], uvb)  # no directions: J = 0
+    assert J0.shape == (2, n ** 3) and not J0.any()
+
+
+def test_single_cell_grid(engine):
+    kappa = np.array([[0.7], [0.0]])
+    engine.set_uniform_grid(1, 1.0)
+    engine.set_opacity(kappa)
+    phi, theta, w = O.healpix_directions(1)
+    uvb = np.array([1e-21, 2e-21])
+    J = engine.transport(phi, theta, w, uvb)
+    ref = O.sweep_uniform(1, kappa, 1.0, phi, theta, w, uvb, arith=O.ARITH_DEVICE)
+    assert np.allclose(J, ref, rtol=SUM_RTOL, atol=0)
+
+
+def test_opaque_medium_underflows_like_the_reference(engine):
+    """tau ~ 100 per cell: intensities underflow to exactly 0 deep inside; J must stay finite, non-negative and
+    agree with the reference arithmetic wherever J is a normal number."""
+    n = 12
+    kappa = np.full((1, n ** 3), 100.0 * n)
+    phi, theta, w = O.healpix_directions(1)
+    uvb = np.array([1e-21])
+    engine.set_uniform_grid(n, 1.0)
+    engine.set_opacity(kappa)
+    J = engine.transport(phi, theta, w, uvb)
+    ref = O.sweep_uniform(n, kappa, 1.0, phi, theta, w, uvb)
+    assert np.all(np.isfinite(J)) and np.all(J >= 0)
+    big = ref > 1e-290
+    assert np.allclose(J[big], ref[big], rtol=1e-11, atol=0)
+    assert np.all(J[~big] <= 1e-289)
+
+
+def test_species_opacities(engine):
+    n = 9
+    rng = np.random.default_rng(5)
+    HI, HeI, HeII = rng.lognormal(0, 1, (3, n ** 3)) * 3.0
+    beta = rng.random((3, 4))
+    engine.set_uniform_grid(n, 1.0)
+    engine.compute_opacities(HI, HeI, HeII, beta)
+    phi, theta, w = O.healpix_directions(1)
+    uvb = np.full(4, 1e-21)
+    J = engine.transport(phi, theta, w, uvb)
+    kappa = O.compute_opacities(HI, HeI, HeII, beta)
+    ref = O.sweep_uniform(n, kappa, 1.0, phi, theta, w, uvb, arith=O.ARITH_DEVICE)
+    assert np.allclose(J, ref, rtol=SUM_RTOL, atol=0)
+
+
+def test_call_order_and_refusals(engine):
+    import radiativetransfer_amd as rt
+    with rt.DiffuseTransfer() as e:
+        with pytest.raises(rt.FtteError) as err:
+            e.set_opacity(np.zeros((1, 8)))
+        assert err.value.status == "FTTE_ERR_STATE"
+        with pytest.raises(rt.FtteError) as err:
+            e.set_grid((4, 4, 5), np.zeros(80, np.int32), 1.0)
+        assert err.value.status == "FTTE_ERR_NOT_CUBIC"
+        with pytest.raises(rt.FtteError) as err:
+            e.set_grid(2, np.array([0, 0, 0, 1, 0, 0, 0, 0], np.int32), 1.0)  # a lone level-1 leaf list that runs out
+        assert err.value.status == "FTTE_ERR_LEVELS"
+        with pytest.raises(rt.FtteError) as err:
+            e.set_grid(2, synthetic.refine_levels(2, [(0, 0, 0)]), 1.0)  # valid AMR: refused, not mis-computed
+        assert err.value.status == "FTTE_ERR_UNSUPPORTED"
+        e.set_uniform_grid(4, 1.0)
+        with pytest.raises(rt.FtteError) as err:
+            e.transport([0.3], [0.4], [1.0], [1e-21])
+        assert err.value.status == "FTTE_ERR_STATE"
+        e.set_opacity(np.ones((1, 64)))
+        with pytest.raises(rt.FtteError) as err:
+            e.transport([0.0], [0.4], [1.0], [1e-21])  # phi on a quadrant boundary: the reference stops
+        assert err.value.status == "FTTE_ERR_PHI"
+        with pytest.raises(rt.FtteError) as err:
+            e.set_emissivity(np.ones((1, 64)))
+        assert err.value.status == "FTTE_ERR_UNSUPPORTED"
+
+
+# ---- BASELINE size: properties that need no oracle run ------------------------------------------------------------
+
+@pytest.fixture(scope="module")
+def big(engine):
+    import torch
+    n, nnu = 256, 8
+    kappa, uvb, box = synthetic.uniform_workload(n, nnu, seed=12345, tau_median=0.1)
+    engine.set_uniform_grid(n, box)
+    dev = torch.device("cuda", 0)
+    k = torch.from_numpy(kappa).to(dev)
+    engine.set_opacity_device(nnu, k.data_ptr())
+    torch.cuda.synchronize()
+    import radiativetransfer_amd as rt
+    nside = 4
+    ang = np.array([rt.pix2ang_nest(nside, i) for i in range(96)])
+    return dict(n=n, nnu=nnu, kappa=kappa, uvb=uvb, box=box, phi=ang[:, 0].copy(), theta=ang[:, 1].copy(),
+                w=np.full(96, 1 / 96), k_dev=k)
+
+
+def _sweep_dev(engine, b, uvb, ndir=96):
+    import torch
+    J = torch.empty((b["nnu"], b["n"] ** 3), dtype=torch.float64, device="cuda:0")
+    engine.transport_device(b["phi"][:ndir], b["theta"][:ndir], b["w"][:ndir], uvb, J.data_ptr(),
+                            torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return J
+
+
+def test_baseline_size_deterministic_and_linear(engine, big):
+    """256^3 x 8 groups x 96 directions: two runs agree bit for bit (every cell has one owner, no atomics), J is
+    bounded by the inflow, and J is exactly linear in the inflow (scaling uvb by 2 is exact in binary64)."""
+    import torch
+    J1 = _sweep_dev(engine, big, big["uvb"])
+    J2 = _sweep_dev(engine, big, big["uvb"])
+    assert torch.equal(J1, J2)
+    Jd = _sweep_dev(engine, big, 2.0 * big["uvb"])
+    assert torch.equal(Jd, 2.0 * J1)
+    cap = torch.from_numpy(big["uvb"]).to(J1.device)[:, None] * (1 + 1e-12)
+    assert bool(torch.all(J1 > 0)) and bool(torch.all(J1 <= cap))
+
+
+def test_baseline_size_slab_against_oracle(engine, big):
+    """One direction at 256^3 against the oracle (device arithmetic), bit for bit, on two frequency groups."""
+    n = big["n"]
+    for d in (0, 57):
+        phi, theta, w = big["phi"][d:d + 1], big["theta"][d:d + 1], big["w"][d:d + 1]
+        import torch
+        J = torch.empty((big["nnu"], n ** 3), dtype=torch.float64, device="cuda:0")
+        engine.transport_device(phi, theta, w, big["uvb"], J.data_ptr(), 0)
+        torch.cuda.synchronize()
+        Jh = J[[0, 7]].cpu().numpy()
+        ref = O.sweep_uniform(n, big["kappa"][[0, 7]], big["box"], phi, theta, w, big["uvb"][[0, 7]], arith=O.ARITH_DEVICE)
+        assert np.array_equal(Jh, ref)
