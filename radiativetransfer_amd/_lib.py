@@ -66,6 +66,13 @@ def load() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} is missing: the HIP extension has not been built "
                 "(run `python -m radiativetransfer_amd.build`); there is no CPU fallback")
+        # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.so.7 and resolve it by file
+        # name, so if the system copy were mapped first (through libftte.so) a later `import torch` would map a second
+        # runtime and find no devices.  Mapping torch's first makes libftte.so bind to that same instance by soname.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol

@@ -174,9 +174,9 @@ class DiffuseTransfer:
     def transport(self, phi, theta, weight, uvb) -> np.ndarray:
         """One diffuse-transfer iteration; returns J[nnu][ncell] (host)."""
         phi, theta, weight, uvb = map(_f64, (phi, theta, weight, uvb))
-        if not (len(phi) == len(theta) == len(weight)) or len(uvb) != self.nnu:
+        if not (len(phi) == len(theta) == len(weight)) or (self.nnu and len(uvb) != self.nnu):
             raise ValueError("direction arrays must have equal length and uvb one value per frequency group")
-        J = np.empty((self.nnu, self.ncell))
+        J = np.empty((max(self.nnu, 1), max(self.ncell, 1)))
         self._ok(self._lib.ftte_diffuse_sweep(self._ctx, len(phi), _dp(phi), _dp(theta), _dp(weight), _dp(uvb), _dp(J)))
         return J
 
