@@ -1,0 +1,127 @@
+! ftte_binding.f90 -- ISO_C_BINDING view of include/ftte.h for the Fortran host.
+!
+! The reference is a Fortran program; its diffuse-transfer block (equiSources.f90:1372-1808) is
+! replaced by calls into libftte.so through these interfaces.  Nothing here computes: it is the
+! thin shim the north star asks for.  Status codes are those of ftte_status in ftte.h; the
+! wrapper `ftteCheck` reproduces the reference's behaviour on inconsistency (`write; stop`).
+module ftte_binding
+
+  use, intrinsic :: iso_c_binding
+  implicit none
+
+  integer(c_int), parameter :: FTTE_OK = 0
+
+  interface
+
+     integer(c_int) function ftte_create(ctx, ndev, dev_ids) bind(C, name='ftte_create')
+       import :: c_ptr, c_int
+       type(c_ptr), intent(out) :: ctx
+       integer(c_int), value :: ndev
+       type(c_ptr), value :: dev_ids            ! const int*, may be c_null_ptr
+     end function ftte_create
+
+     integer(c_int) function ftte_destroy(ctx) bind(C, name='ftte_destroy')
+       import :: c_ptr, c_int
+       type(c_ptr), value :: ctx
+     end function ftte_destroy
+
+     type(c_ptr) function ftte_last_error(ctx) bind(C, name='ftte_last_error')
+       import :: c_ptr
+       type(c_ptr), value :: ctx
+     end function ftte_last_error
+
+     integer(c_int) function ftte_set_grid(ctx, nx, ny, nz, ncell, level, box_cm) bind(C, name='ftte_set_grid')
+       import :: c_ptr, c_int, c_int64_t, c_int32_t, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: nx, ny, nz
+       integer(c_int64_t), value :: ncell
+       integer(c_int32_t), intent(in) :: level(*)
+       real(c_double), value :: box_cm
+     end function ftte_set_grid
+
+     integer(c_int) function ftte_set_opacity(ctx, nnu, kappa) bind(C, name='ftte_set_opacity')
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: nnu
+       real(c_double), intent(in) :: kappa(*)   ! (ncell, nnu) in Fortran order == [nnu][ncell] in C
+     end function ftte_set_opacity
+
+     integer(c_int) function ftte_set_species(ctx, nnu, HI, HeI, HeII, beta) bind(C, name='ftte_set_species')
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: nnu
+       real(c_double), intent(in) :: HI(*), HeI(*), HeII(*)
+       real(c_double), intent(in) :: beta(*)    ! (nnu, 3) in Fortran order == [3][nnu] in C
+     end function ftte_set_species
+
+     integer(c_int) function ftte_set_emissivity(ctx, eta) bind(C, name='ftte_set_emissivity')
+       import :: c_ptr, c_int
+       type(c_ptr), value :: ctx
+       type(c_ptr), value :: eta                ! c_null_ptr: the reference's zero emissivity
+     end function ftte_set_emissivity
+
+     integer(c_int) function ftte_diffuse_sweep(ctx, ndir, phi, theta, w, uvb, J) bind(C, name='ftte_diffuse_sweep')
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: ndir
+       real(c_double), intent(in) :: phi(*), theta(*), w(*), uvb(*)
+       real(c_double), intent(out) :: J(*)      ! (ncell, nnu)
+     end function ftte_diffuse_sweep
+
+     integer(c_int) function ftte_set_option(ctx, key, val) bind(C, name='ftte_set_option')
+       import :: c_ptr, c_int, c_char
+       type(c_ptr), value :: ctx
+       character(kind=c_char), intent(in) :: key(*)
+       integer(c_int), value :: val
+     end function ftte_set_option
+
+     integer(c_int) function ftte_pix2ang_nest(nside, ipix, phi, theta) bind(C, name='ftte_pix2ang_nest')
+       import :: c_int, c_int64_t, c_double
+       integer(c_int), value :: nside
+       integer(c_int64_t), value :: ipix
+       real(c_double), intent(out) :: phi, theta
+     end function ftte_pix2ang_nest
+
+     integer(c_int) function ftte_fold_direction(phi_large, theta_large, phi, theta, izone) bind(C, name='ftte_fold_direction')
+       import :: c_int, c_double
+       real(c_double), value :: phi_large, theta_large
+       real(c_double), intent(out) :: phi, theta
+       integer(c_int), intent(out) :: izone
+     end function ftte_fold_direction
+
+     integer(c_int) function ftte_rotate_indices(i, j, k, nx, ny, nz, izone, icell, jcell, kcell) &
+          bind(C, name='ftte_rotate_indices')
+       import :: c_int
+       integer(c_int), value :: i, j, k, nx, ny, nz, izone
+       integer(c_int), intent(out) :: icell, jcell, kcell
+     end function ftte_rotate_indices
+
+  end interface
+
+contains
+
+  ! the reference's error convention: print and stop (e.g. equiSources.f90:1412, transportRoutinesModule.f90:33-36)
+  subroutine ftteCheck(ctx, status, where)
+    type(c_ptr), intent(in) :: ctx
+    integer(c_int), intent(in) :: status
+    character(len=*), intent(in) :: where
+    character(kind=c_char), pointer :: msg(:)
+    type(c_ptr) :: p
+    integer :: n
+    if (status == FTTE_OK) return
+    p = ftte_last_error(ctx)
+    if (c_associated(p)) then
+       call c_f_pointer(p, msg, [1024])
+       n = 0
+       do while (n < 1024)
+          if (msg(n+1) == c_null_char) exit
+          n = n + 1
+       enddo
+       write(*,*) 'ftte error in ', where, ': status', status, ' ', msg(1:n)
+    else
+       write(*,*) 'ftte error in ', where, ': status', status
+    endif
+    stop 1
+  end subroutine ftteCheck
+
+end module ftte_binding
