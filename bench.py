@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--ndir", type=int, default=96, help="directions per GPU")
     ap.add_argument("--rows", type=int, default=0, help="rays per lane (4/8/16); 0 = library default")
     ap.add_argument("--slots", type=int, default=0, help="directions in flight per launch; 0 = library default")
+    ap.add_argument("--waves", type=int, default=0, help="waves per SIMD the kernel is compiled for; 0 = library default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=0, help="grid size of the CPU sample (default: --n)")
     return ap.parse_args()
@@ -142,6 +143,8 @@ def main():
         eng.set_option("rows", a.rows)
     if a.slots:
         eng.set_option("slots", a.slots)
+    if a.waves:
+        eng.set_option("waves", a.waves)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():

@@ -107,7 +107,9 @@ int ftte_diffuse_sweep_device(ftte_ctx *ctx, int ndir, const double *phi, const 
 /* ---- tuning and instrumentation ------------------------------------------------------------- */
 
 /* Tuning knobs: "rows" (rays per lane: 4, 8 or 16), "slots" (directions in flight per
- * launch, 1..16).  Unknown keys return FTTE_ERR_ARG. */
+ * launch, 1..16), "waves" (waves per SIMD the sweep kernel's register allocation is held to:
+ * 2, 3, 4, 5, 6 or 8).  Results do not depend on any of them except through the order in
+ * which "slots" sums directions.  Unknown keys return FTTE_ERR_ARG. */
 int ftte_set_option(ftte_ctx *ctx, const char *key, int value);
 /* Launch records of the last sweep (valid after the sweep's stream has been synchronised).
  * Each sweep-kernel launch is bracketed by HIP events on the stream it runs on. */

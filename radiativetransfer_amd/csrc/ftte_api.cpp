@@ -82,7 +82,7 @@ struct ftte_ctx {
     double *acc[3][kMaxSlots] = {};
     size_t acc_cap = 0; // elements per accumulator
 
-    int rows = 8, slots = 4;
+    int rows = 8, slots = 4, waves = 4;
 
     Plan plan;
     LayerRec *d_layers = nullptr; size_t d_layers_cap = 0;
@@ -171,7 +171,8 @@ int build_plan(ftte_ctx *c, int ndir, const double *phi, const double *theta, co
         D.su = zm.mirror[fast_c] ? -1 : 1;
         D.sv = zm.mirror[mid_c] ? -n : n;
         D.si = (int)(zm.mirror[march_c] ? -nn : nn);
-        D.org = (zm.mirror[fast_c] ? n : -1) + (zm.mirror[mid_c] ? (long)n * n : -(long)n) +
+        // the column enters as a position p = u (or n+1-u when mirrored) with stride +1: offset p - 1
+        D.org = -1 + (zm.mirror[mid_c] ? (long)n * n : -(long)n) +
                 (zm.mirror[march_c] ? (long)n * nn : -nn);
 
         // layers: reference chain -> kernel-frame class, lengths in chain order, cumulative drift
@@ -182,13 +183,12 @@ int build_plan(ftte_ctx *c, int ndir, const double *phi, const double *theta, co
             LayerRec &R = P.layers[D.layer_off + i];
             R.dpath[0] = cell * p.xy_len;
             R.dpath[1] = R.dpath[2] = 0.0;
-            int rc_class = RC_ONE, third_first = 0, step_k = 0, step_j = 0;
+            int rc_class = RC_ONE, step_k = 0, step_j = 0;
             if (p.xz_active && p.yz_active) {
                 step_k = step_j = 1;
                 if (p.xy_top == 3) { // xy -> yz -> xz (the xz piece reaches the top)
                     R.dpath[1] = cell * p.yz_len; R.dpath[2] = cell * p.xz_len;
-                    rc_class = u_is_k ? RC_THREE_U : RC_THREE_V;
-                    third_first = 1; // mean adds xy, xz, yz: the chain's third piece before its second
+                    rc_class = u_is_k ? RC_THREE_U_SWAP : RC_THREE_V_SWAP; // mean adds xy, xz, yz: 3rd piece before 2nd
                 } else {             // xy -> xz -> yz
                     R.dpath[1] = cell * p.xz_len; R.dpath[2] = cell * p.yz_len;
                     rc_class = u_is_k ? RC_THREE_V : RC_THREE_U;
@@ -202,7 +202,7 @@ int build_plan(ftte_ctx *c, int ndir, const double *phi, const double *theta, co
                 R.dpath[1] = cell * p.xz_len;
                 rc_class = u_is_k ? RC_TWO_V : RC_TWO_U;
             }
-            R.info = rc_class | (third_first << 3);
+            R.info = rc_class;
             R.drift = (du & 0xffff) | (dv << 16);
             du_cum[i] = du; dv_cum[i] = dv;
             du += u_is_k ? step_k : step_j;
@@ -472,6 +472,10 @@ int ftte_set_option(ftte_ctx *c, const char *key, int value)
     } else if (!std::strcmp(key, "slots")) {
         if (value < 1 || value > kMaxSlots) return fail(c, FTTE_ERR_ARG, "slots must be 1..16");
         c->slots = value;
+    } else if (!std::strcmp(key, "waves")) {
+        if (value != 2 && value != 3 && value != 4 && value != 5 && value != 6 && value != 8)
+            return fail(c, FTTE_ERR_ARG, "waves must be 2, 3, 4, 5, 6 or 8");
+        c->waves = value;
     } else return fail(c, FTTE_ERR_ARG, std::string("unknown option: ") + key);
     c->plan.valid = false;
     return FTTE_OK;
@@ -561,10 +565,11 @@ int ftte_diffuse_sweep_device(ftte_ctx *c, int ndir, const double *phi, const do
         L.group_stride = c->ncell;
         L.n = n;
         L.nitems = LP.nitems;
+        L.nnu = nnu;
         LaunchTiming &T = c->timing[li];
         T.updates = LP.updates * nnu;
         FTTE_HIP(c, hipEventRecord(T.start, stream));
-        if (launch_sweep(L, c->rows, nnu, stream)) return fail(c, FTTE_ERR_NO_DEVICE, "sweep kernel launch failed");
+        if (launch_sweep(L, c->rows, c->waves, nnu, stream)) return fail(c, FTTE_ERR_NO_DEVICE, "sweep kernel launch failed");
         FTTE_HIP(c, hipEventRecord(T.stop, stream));
         c->timing_used = (int)li + 1;
     }

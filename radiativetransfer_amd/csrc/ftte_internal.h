@@ -17,14 +17,17 @@ enum RayClass : int {
     RC_TWO_U = 1,   // 2nd segment in cell (v, u+1)
     RC_TWO_V = 2,   // 2nd segment in cell (v+1, u)
     RC_THREE_U = 3, // 2nd in (v, u+1), 3rd in (v+1, u+1)
-    RC_THREE_V = 4  // 2nd in (v+1, u), 3rd in (v+1, u+1)
+    RC_THREE_V = 4, // 2nd in (v+1, u), 3rd in (v+1, u+1)
+    // same shapes, but the cell's mean adds the chain's 3rd piece before its 2nd: the reference sums
+    // xy, xz, yz whatever the chain order (transportRoutinesModule.f90:695-941)
+    RC_THREE_U_SWAP = 5,
+    RC_THREE_V_SWAP = 6
 };
 
 // One layer of one direction, 32 bytes, read with a single scalar load.
 struct LayerRec {
     double dpath[3];  // cell size * segment length, chain order (transportRoutinesModule.f90:651)
-    int32_t info;     // bits 0-2 RayClass; bit 3: the cell's mean adds the 3rd segment before the 2nd
-                      // (reference order is xy, xz, yz whatever the chain order)
+    int32_t info;     // bits 0-2 RayClass
     int32_t drift;    // cumulative drift of the rays up to this layer: low 16 bits along u, high 16 along v
 };
 static_assert(sizeof(LayerRec) == 32, "LayerRec must be 32 bytes");
@@ -34,8 +37,9 @@ struct DirRec {
     const LayerRec *layers; // [n], device memory
     const double *kappa;    // opacity in the layout of this direction's march axis, group 0
     double *J;              // accumulator of this direction's slot, same layout, group 0
-    int64_t org;            // element offset of the virtual cell (i,v,u) = (0,0,0)
-    int32_t si, sv, su;     // element strides along march, v, u (signed: reflections)
+    int64_t org;            // element offset of the virtual cell (i, v, column position) = (0,0,0)
+    int32_t si, sv, su;     // element strides along march and v (signed: reflections); su = +1, or -1 when the
+                            // u axis is mirrored: the column position of cell u is then n+1-u (stride +1 either way)
     int32_t u_lo, v_lo;     // label of the first owned ray along u / v
     int32_t first;          // 1: J receives a plain store (first direction into this accumulator)
     double w;               // quadrature weight
@@ -60,6 +64,7 @@ struct LaunchRec {
     int64_t group_stride; // elements between consecutive frequency groups (= ncell)
     int32_t n;          // grid size
     int32_t nitems;
+    int32_t nnu;        // frequency groups; workgroup b handles group b % nnu of work item b / nnu
 };
 
 } // namespace ftte

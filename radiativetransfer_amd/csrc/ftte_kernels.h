@@ -7,7 +7,7 @@
 
 namespace ftte {
 
-int launch_sweep(const LaunchRec &L, int rows, int nnu, hipStream_t stream);
+int launch_sweep(const LaunchRec &L, int rows, int waves, int nnu, hipStream_t stream);
 // cell-array order -> layout 1 ([jc][ic][kc]) or 2 ([kc][ic][jc]); nnu groups, group_stride apart
 int launch_to_layout(int layout, const double *src, double *dst, int n, int nnu, long group_stride, hipStream_t stream);
 // J (cell-array order) = acc[0] + acc[1] + ... in list order; layout[a] in {0,1,2}

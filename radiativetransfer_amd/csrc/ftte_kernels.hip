@@ -46,6 +46,19 @@ __device__ __forceinline__ double from_lane_below(double x)
 
 __device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
+// Values that are the same in every lane but reach the wave through vector loads (the compiler cannot prove the
+// tables are not written by the kernel, so it will not use scalar loads for them): pin them into SGPRs, so that
+// everything derived from them -- plane and row addresses, segment lengths, branch conditions -- is scalar.
+__device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ long uniform(long x)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(x & 0xffffffffl));
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long)x >> 32));
+    return (long)(((unsigned long)hi << 32) | lo);
+}
+__device__ __forceinline__ double uniform(double x) { return __longlong_as_double(uniform((long)__double_as_longlong(x))); }
+template <typename T> __device__ __forceinline__ T *uniform(T *p) { return reinterpret_cast<T *>(uniform(reinterpret_cast<long>(p))); }
+
 // One segment of one ray.  EDGE: the cell may lie outside the domain, where the ray is
 // re-initialised with the inflow (transportRoutinesModule.f90:594-597) and adds nothing.
 template <bool EDGE>
@@ -62,42 +75,50 @@ __device__ __forceinline__ double segment(double &I, double kap, double dpath, b
 
 // One layer of one tile.  RC: chain class (ftte_internal.h).  I[r]: intensity of ray r of this
 // lane on entry to the layer / on exit.
-//   krow0 / jrow0 : pointers to the virtual element (row cv0 = row of ray 0, column 0) of this
-//                   layer's kappa / J plane; rows are sv elements apart, columns su.
+//   kplane / jplane : byte pointers to the virtual element (row 0, column position 0) of this layer's
+//                     kappa / J plane; rows are sv elements apart; a lane's column enters as a
+//                     non-negative position (mirrored columns are folded into the position by the
+//                     caller) so that every access is  uniform 64-bit base + 32-bit lane offset.
 template <int ROWS, int RC, bool EDGE>
-__device__ __forceinline__ void layer_step(double (&I)[ROWS], const double *__restrict__ kplane,
-                                           double *__restrict__ jplane, int cv0, int cu, int n, int sv, int su,
-                                           double d0, double d1, double d2, bool third_first, double w, double uvb,
-                                           bool first, bool lane_owned)
+__device__ __forceinline__ void layer_step(double (&I)[ROWS], const char *__restrict__ kplane, char *__restrict__ jplane,
+                                           int cv0, int cu, int n, int sv, bool mirror_u, double d0, double d1, double d2,
+                                           double w, double uvb, bool first, bool lane_owned)
 {
-    constexpr bool HAS_U = (RC == RC_TWO_U || RC == RC_THREE_U || RC == RC_THREE_V); // touches column u+1
-    constexpr bool HAS_V = (RC == RC_TWO_V || RC == RC_THREE_U || RC == RC_THREE_V); // touches row v+1
-    constexpr int NSEG = (RC == RC_ONE) ? 1 : (RC <= RC_TWO_V ? 2 : 3);
+    constexpr int SHAPE = (RC == RC_THREE_U_SWAP) ? RC_THREE_U : (RC == RC_THREE_V_SWAP) ? RC_THREE_V : RC;
+    constexpr bool THIRD_FIRST = (RC == RC_THREE_U_SWAP || RC == RC_THREE_V_SWAP);
+    constexpr bool HAS_U = (SHAPE == RC_TWO_U || SHAPE == RC_THREE_U || SHAPE == RC_THREE_V); // touches column u+1
+    constexpr bool HAS_V = (SHAPE == RC_TWO_V || SHAPE == RC_THREE_U || SHAPE == RC_THREE_V); // touches row v+1
+    constexpr int NSEG = (SHAPE == RC_ONE) ? 1 : (SHAPE <= RC_TWO_V ? 2 : 3);
 
-    // lane-varying column offsets (elements), clamped into the domain for EDGE tiles
+    // lane-varying column positions, clamped into the domain for EDGE tiles
     const int c0 = EDGE ? clampi(cu, 1, n) : cu;
     const int c1 = EDGE ? clampi(cu + 1, 1, n) : cu + 1;
-    const int off0 = c0 * su, off1 = c1 * su;
+    const unsigned off0 = 8u * (unsigned)(mirror_u ? n + 1 - c0 : c0);
+    const unsigned off1 = 8u * (unsigned)(mirror_u ? n + 1 - c1 : c1);
     const bool in_u0 = !EDGE || (cu >= 1 && cu <= n);
     const bool in_u1 = !EDGE || (cu + 1 >= 1 && cu + 1 <= n);
+    const long row_bytes = 8l * sv;
 
     // ---- issue every load of the layer up front ------------------------------------------------
-    double K0[ROWS + 1], K1[ROWS + 1], Jold[ROWS];
+    double K0[ROWS + 1], K1[ROWS + 1], Jacc[ROWS];
 #pragma unroll
     for (int r = 0; r <= ROWS; ++r) {
         const int row = EDGE ? clampi(cv0 + r, 1, n) : cv0 + r;
-        const double *rp = kplane + (long)row * sv;
-        const bool need0 = (r < ROWS) || (RC == RC_TWO_V || RC == RC_THREE_V);
-        const bool need1 = HAS_U && ((RC == RC_TWO_U) ? (r < ROWS) : (RC == RC_THREE_U) ? true : (r >= 1));
-        if (need0) K0[r] = rp[off0];
-        if (need1) K1[r] = rp[off1];
+        const char *rp = kplane + row * row_bytes;
+        const bool need0 = (r < ROWS) || (SHAPE == RC_TWO_V || SHAPE == RC_THREE_V);
+        const bool need1 = HAS_U && ((SHAPE == RC_TWO_U) ? (r < ROWS) : (SHAPE == RC_THREE_U) ? true : (r >= 1));
+        if (need0) K0[r] = *reinterpret_cast<const double *>(rp + off0);
+        if (need1) K1[r] = *reinterpret_cast<const double *>(rp + off1);
     }
+    const bool own_lane = lane_owned && in_u0;
 #pragma unroll
-    for (int r = 1; r < ROWS; ++r) {
-        const int row = cv0 + r;
-        const bool own = lane_owned && in_u0 && (!EDGE || (row >= 1 && row <= n));
-        Jold[r] = 0.0;
-        if (!first && own) Jold[r] = jplane[(long)row * sv + off0];
+    for (int r = 1; r < ROWS; ++r) Jacc[r] = 0.0;
+    if (!first && own_lane) {
+#pragma unroll
+        for (int r = 1; r < ROWS; ++r) {
+            const int row = cv0 + r;
+            if (!EDGE || (row >= 1 && row <= n)) Jacc[r] = *reinterpret_cast<const double *>(jplane + row * row_bytes + off0);
+        }
     }
 
     // ---- march the rays of this lane through the layer, row by row -----------------------------
@@ -110,13 +131,13 @@ __device__ __forceinline__ void layer_step(double (&I)[ROWS], const double *__re
 
         double m0, m1 = 0.0, m2 = 0.0;
         m0 = segment<EDGE>(I[r], K0[r], d0, in_v0 && in_u0, uvb);
-        if (RC == RC_TWO_U) m1 = segment<EDGE>(I[r], K1[r], d1, in_v0 && in_u1, uvb);
-        if (RC == RC_TWO_V) m1 = segment<EDGE>(I[r], K0[r + 1], d1, in_v1 && in_u0, uvb);
-        if (RC == RC_THREE_U) {
+        if (SHAPE == RC_TWO_U) m1 = segment<EDGE>(I[r], K1[r], d1, in_v0 && in_u1, uvb);
+        if (SHAPE == RC_TWO_V) m1 = segment<EDGE>(I[r], K0[r + 1], d1, in_v1 && in_u0, uvb);
+        if (SHAPE == RC_THREE_U) {
             m1 = segment<EDGE>(I[r], K1[r], d1, in_v0 && in_u1, uvb);
             m2 = segment<EDGE>(I[r], K1[r + 1], d2, in_v1 && in_u1, uvb);
         }
-        if (RC == RC_THREE_V) {
+        if (SHAPE == RC_THREE_V) {
             m1 = segment<EDGE>(I[r], K0[r + 1], d1, in_v1 && in_u0, uvb);
             m2 = segment<EDGE>(I[r], K1[r + 1], d2, in_v1 && in_u1, uvb);
         }
@@ -125,110 +146,146 @@ __device__ __forceinline__ void layer_step(double (&I)[ROWS], const double *__re
         // up in it, which belong to the rays one step lower in u and/or v
         if (r >= 1) {
             double g1 = 0.0, g2 = 0.0;
-            if (RC == RC_TWO_U) g1 = from_lane_below(m1);
-            if (RC == RC_TWO_V) g1 = prev1;
-            if (RC == RC_THREE_U) { g1 = from_lane_below(m1); g2 = from_lane_below(prev2); }
-            if (RC == RC_THREE_V) { g1 = prev1; g2 = from_lane_below(prev2); }
+            if (SHAPE == RC_TWO_U) g1 = from_lane_below(m1);
+            if (SHAPE == RC_TWO_V) g1 = prev1;
+            if (SHAPE == RC_THREE_U) { g1 = from_lane_below(m1); g2 = from_lane_below(prev2); }
+            if (SHAPE == RC_THREE_V) { g1 = prev1; g2 = from_lane_below(prev2); }
             double acc = m0;
             if (NSEG == 2) acc += g1;
             if (NSEG == 3) {
                 // reference order: xy + xz + yz (transportRoutinesModule.f90:695-941)
-                const double a = third_first ? g2 : g1, b = third_first ? g1 : g2;
-                acc += a;
-                acc += b;
+                acc += THIRD_FIRST ? g2 : g1;
+                acc += THIRD_FIRST ? g1 : g2;
             }
-            const bool own = lane_owned && in_u0 && in_v0;
-            if (own) jplane[(long)row * sv + off0] = Jold[r] + ftte_cell_mean(acc, NSEG, w);
+            Jacc[r] += ftte_cell_mean(acc, NSEG, w);
+            // computed here, for every lane: otherwise the whole mean (selects, products) is sunk into the
+            // lane-predicated store block after the last row, with every row's operands kept alive until then
+            asm volatile("" : "+v"(Jacc[r]));
         }
         if (HAS_V) { prev1 = m1; prev2 = m2; }
-        if (RC == RC_THREE_U) prev2 = m2;
+        // keep the rows in program order: their arithmetic is independent, and left alone the scheduler
+        // interleaves all of them, which multiplies the live registers by the row count
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    if (own_lane) {
+#pragma unroll
+        for (int r = 1; r < ROWS; ++r) {
+            const int row = cv0 + r;
+            if (!EDGE || (row >= 1 && row <= n)) *reinterpret_cast<double *>(jplane + row * row_bytes + off0) = Jacc[r];
+        }
     }
 }
 
 template <int ROWS, bool EDGE>
-__device__ __forceinline__ void layer_dispatch(double (&I)[ROWS], int rc, const double *kplane, double *jplane, int cv0,
-                                               int cu, int n, int sv, int su, double d0, double d1, double d2,
-                                               bool third_first, double w, double uvb, bool first, bool lane_owned)
+__device__ __forceinline__ void layer_dispatch(double (&I)[ROWS], int rc, const char *kplane, char *jplane, int cv0, int cu,
+                                               int n, int sv, bool mirror_u, double d0, double d1, double d2, double w,
+                                               double uvb, bool first, bool lane_owned)
 {
+#define FTTE_CASE(C)                                                                                                   \
+    case C:                                                                                                            \
+        layer_step<ROWS, C, EDGE>(I, kplane, jplane, cv0, cu, n, sv, mirror_u, d0, d1, d2, w, uvb, first, lane_owned); \
+        break;
     switch (rc) {
-    case RC_ONE:
-        layer_step<ROWS, RC_ONE, EDGE>(I, kplane, jplane, cv0, cu, n, sv, su, d0, d1, d2, third_first, w, uvb, first, lane_owned);
-        break;
-    case RC_TWO_U:
-        layer_step<ROWS, RC_TWO_U, EDGE>(I, kplane, jplane, cv0, cu, n, sv, su, d0, d1, d2, third_first, w, uvb, first, lane_owned);
-        break;
-    case RC_TWO_V:
-        layer_step<ROWS, RC_TWO_V, EDGE>(I, kplane, jplane, cv0, cu, n, sv, su, d0, d1, d2, third_first, w, uvb, first, lane_owned);
-        break;
-    case RC_THREE_U:
-        layer_step<ROWS, RC_THREE_U, EDGE>(I, kplane, jplane, cv0, cu, n, sv, su, d0, d1, d2, third_first, w, uvb, first, lane_owned);
-        break;
+        FTTE_CASE(RC_ONE)
+        FTTE_CASE(RC_TWO_U)
+        FTTE_CASE(RC_TWO_V)
+        FTTE_CASE(RC_THREE_U)
+        FTTE_CASE(RC_THREE_V)
+        FTTE_CASE(RC_THREE_U_SWAP)
     default:
-        layer_step<ROWS, RC_THREE_V, EDGE>(I, kplane, jplane, cv0, cu, n, sv, su, d0, d1, d2, third_first, w, uvb, first, lane_owned);
+        layer_step<ROWS, RC_THREE_V_SWAP, EDGE>(I, kplane, jplane, cv0, cu, n, sv, mirror_u, d0, d1, d2, w, uvb, first,
+                                                lane_owned);
         break;
     }
+#undef FTTE_CASE
 }
 
-// grid: (nitems, nnu), block: one wavefront
-template <int ROWS>
-__global__ void __launch_bounds__(64) sweep_kernel(const LaunchRec L)
+// grid: nitems * nnu workgroups of one wavefront; the frequency group is the fastest index, so that
+// (for nnu = 8) all tiles of one group run on one XCD and share its L2: neighbouring tiles re-read each
+// other's halo rows and the partial 128-byte lines at their edges.
+template <int ROWS, int WAVES>
+__global__ void __launch_bounds__(64, WAVES) sweep_kernel(const LaunchRec L)
 {
-    const WorkItem item = L.items[blockIdx.x];
-    const int nu = blockIdx.y;
-    const DirRec &D = L.dir[item.slot];
+    const int nnu = L.nnu;
+    const int nu = blockIdx.x % nnu;
+    const WorkItem *ip = L.items + blockIdx.x / nnu;
+    const int slot = uniform((int)ip->slot), tu = uniform((int)ip->tu), tv = uniform((int)ip->tv);
+    const int i_first = uniform((int)ip->i_first), i_last = uniform((int)ip->i_last);
+    const DirRec &D = L.dir[slot];
     const int lane = threadIdx.x;
     const int n = L.n;
 
-    const double uvb = L.uvb[nu];
-    const double w = D.w;
-    const int sv = D.sv, su = D.su, si = D.si;
-    const bool first = D.first != 0;
-    const double *kbase = D.kappa + (long)nu * L.group_stride + D.org;
-    double *jbase = D.J + (long)nu * L.group_stride + D.org;
+    const double uvb = uniform(L.uvb[nu]);
+    const double w = uniform(D.w);
+    const int sv = uniform(D.sv), si = uniform(D.si);
+    const bool mirror_u = uniform(D.su) < 0;
+    const bool first = uniform(D.first) != 0;
+    const long org = uniform((long)D.org);
+    const char *kbase = reinterpret_cast<const char *>(uniform(D.kappa) + (long)nu * L.group_stride + org);
+    char *jbase = reinterpret_cast<char *>(uniform(D.J) + (long)nu * L.group_stride + org);
+    const int u_lo = uniform(D.u_lo), v_lo = uniform(D.v_lo);
 
     // labels of this lane's rays: u label of the lane, v label of its row 0 (both halo for index 0)
-    const int ul = D.u_lo + 63 * (int)item.tu + lane - 1;
-    const int vl0 = D.v_lo + (ROWS - 1) * (int)item.tv - 1;
+    const int ul = u_lo + 63 * tu + lane - 1;
+    const int vl0 = v_lo + (ROWS - 1) * tv - 1;
     const bool lane_owned = lane != 0;
 
     double I[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) I[r] = uvb;
 
-    const LayerRec *__restrict__ layers = D.layers;
-    for (int i = item.i_first; i <= item.i_last; ++i) {
-        const LayerRec rec = layers[i - 1];
-        const int du = (int)(short)(rec.drift & 0xffff), dv = rec.drift >> 16;
+    const LayerRec *layers = uniform(D.layers);
+    for (int i = i_first; i <= i_last; ++i) {
+        const LayerRec *rp = layers + (i - 1);
+        const double d0 = uniform(rp->dpath[0]), d1 = uniform(rp->dpath[1]), d2 = uniform(rp->dpath[2]);
+        const int rc = uniform(rp->info) & 7;
+        const int drift = uniform(rp->drift);
+        const int du = (int)(short)(drift & 0xffff), dv = drift >> 16;
         const int cu = ul + du;
         const int cv0 = vl0 + dv;
-        const int rc = rec.info & 7;
-        const bool third_first = (rec.info & 8) != 0;
-        const double *kplane = kbase + (long)i * si;
-        double *jplane = jbase + (long)i * si;
+        const char *kplane = kbase + 8l * i * si;
+        char *jplane = jbase + 8l * i * si;
 
         // interior test (wave-uniform): every cell any lane of the tile may touch, halo and +1
         // offsets included, lies inside the domain
-        const int u_min = D.u_lo + 63 * (int)item.tu - 1 + du, v_min = cv0;
+        const int u_min = u_lo + 63 * tu - 1 + du, v_min = cv0;
         const bool interior = u_min >= 1 && u_min + 64 <= n && v_min >= 1 && v_min + ROWS <= n;
         if (interior)
-            layer_dispatch<ROWS, false>(I, rc, kplane, jplane, cv0, cu, n, sv, su, rec.dpath[0], rec.dpath[1], rec.dpath[2],
-                                        third_first, w, uvb, first, lane_owned);
+            layer_dispatch<ROWS, false>(I, rc, kplane, jplane, cv0, cu, n, sv, mirror_u, d0, d1, d2, w, uvb, first, lane_owned);
         else
-            layer_dispatch<ROWS, true>(I, rc, kplane, jplane, cv0, cu, n, sv, su, rec.dpath[0], rec.dpath[1], rec.dpath[2],
-                                       third_first, w, uvb, first, lane_owned);
+            layer_dispatch<ROWS, true>(I, rc, kplane, jplane, cv0, cu, n, sv, mirror_u, d0, d1, d2, w, uvb, first, lane_owned);
     }
 }
 
-int launch_sweep(const LaunchRec &L, int rows, int nnu, hipStream_t stream)
+// WAVES = waves per SIMD the register allocation is held to (512 / WAVES VGPRs per lane)
+template <int ROWS>
+static int launch_rows(const LaunchRec &L, int waves, dim3 grid, dim3 block, hipStream_t stream)
 {
-    const dim3 grid(L.nitems, nnu), block(64);
-    if (L.nitems <= 0) return 0;
-    switch (rows) {
-    case 4: hipLaunchKernelGGL(sweep_kernel<4>, grid, block, 0, stream, L); break;
-    case 8: hipLaunchKernelGGL(sweep_kernel<8>, grid, block, 0, stream, L); break;
-    case 16: hipLaunchKernelGGL(sweep_kernel<16>, grid, block, 0, stream, L); break;
+    switch (waves) {
+    case 2: hipLaunchKernelGGL((sweep_kernel<ROWS, 2>), grid, block, 0, stream, L); break;
+    case 3: hipLaunchKernelGGL((sweep_kernel<ROWS, 3>), grid, block, 0, stream, L); break;
+    case 4: hipLaunchKernelGGL((sweep_kernel<ROWS, 4>), grid, block, 0, stream, L); break;
+    case 5: hipLaunchKernelGGL((sweep_kernel<ROWS, 5>), grid, block, 0, stream, L); break;
+    case 6: hipLaunchKernelGGL((sweep_kernel<ROWS, 6>), grid, block, 0, stream, L); break;
+    case 8: hipLaunchKernelGGL((sweep_kernel<ROWS, 8>), grid, block, 0, stream, L); break;
     default: return -1;
     }
+    return 0;
+}
+
+int launch_sweep(const LaunchRec &L, int rows, int waves, int nnu, hipStream_t stream)
+{
+    if (L.nitems <= 0 || nnu != L.nnu) return L.nitems <= 0 ? 0 : -1;
+    const dim3 grid((unsigned)L.nitems * (unsigned)nnu), block(64);
+    int rc;
+    switch (rows) {
+    case 4: rc = launch_rows<4>(L, waves, grid, block, stream); break;
+    case 8: rc = launch_rows<8>(L, waves, grid, block, stream); break;
+    case 16: rc = launch_rows<16>(L, waves, grid, block, stream); break;
+    default: return -1;
+    }
+    if (rc) return rc;
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -30,6 +30,34 @@
 #define FTTE_RINT(a) __builtin_rint(a)
 #define FTTE_LDEXP(a, n) __builtin_ldexp((a), (n))
 #define FTTE_FMAX(a, b) __builtin_fmax((a), (b))
+#if defined(__HIP_DEVICE_COMPILE__)
+/* a/b correctly rounded, for normal-range operands: v_rcp_f64 seed, two Newton steps, quotient, one residual
+ * correction -- the instruction sequence hipcc itself emits for an IEEE fp64 division, minus the
+ * v_div_scale / v_div_fixup range handling that 0.29 <= a <= 1, 0.34 <= b < 1e300 never needs (lanes outside
+ * that range discard the result).  Same bits as the host's `/`: checked by the bitwise parity tests. */
+__device__ __forceinline__ double ftte_div(double a, double b)
+{
+    double y = __builtin_amdgcn_rcp(b);
+    double t = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, t, y);
+    t = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, t, y);
+    const double q = a * y;
+    const double r = __builtin_fma(-b, q, a);
+    return __builtin_fma(r, y, q);
+}
+#define FTTE_DIV(a, b) ftte_div((a), (b))
+/* evaluate x here, in every lane: without this hipcc turns the select between the two forms of g into a
+ * divergent branch around the division and keeps every row's operands alive across it (2x the registers) */
+#define FTTE_KEEP(x) asm volatile("" : "+v"(x))
+/* true if the condition holds in any lane of the wavefront: lets a whole wave skip work none of its lanes needs
+ * (the result of every lane is the same as if each had evaluated the condition for itself) */
+#define FTTE_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0ul)
+#else
+#define FTTE_DIV(a, b) ((a) / (b))
+#define FTTE_KEEP(x) ((void)0)
+#define FTTE_ANY(c) (c)
+#endif
 #else
 #include <math.h>
 #define FTTE_HD static inline
@@ -37,6 +65,9 @@
 #define FTTE_RINT(a) rint(a)
 #define FTTE_LDEXP(a, n) ldexp((a), (n))
 #define FTTE_FMAX(a, b) fmax((a), (b))
+#define FTTE_DIV(a, b) ((a) / (b))
+#define FTTE_KEEP(x) ((void)0)
+#define FTTE_ANY(c) (c)
 #endif
 
 #define FTTE_LOG2E 0x1.71547652b82fep+0   /* 1/ln2 */
@@ -79,9 +110,13 @@ FTTE_HD void ftte_attenuation(double tau, double *e_out, double *g_out)
     const double e0 = FTTE_FMA(r, g0, 1.0); /* exp(r)     */
     const int n = (int)nf;
     const double e = FTTE_LDEXP(e0, n);
-    const double gd = (1.0 - e) / tau; /* n != 0: tau >= ln2/2, 1-e >= 0.29, no cancellation */
     *e_out = e;
-    *g_out = (n == 0) ? g0 : gd;
+    *g_out = g0;
+    if (FTTE_ANY(n != 0)) { /* optically thin wavefronts (tau < ln2/2 in every lane) never divide */
+        double gd = FTTE_DIV(1.0 - e, tau); /* n != 0: tau >= ln2/2, 1-e >= 0.29, no cancellation */
+        FTTE_KEEP(gd);
+        *g_out = (n == 0) ? g0 : gd;
+    }
 }
 
 /* One segment: advances the ray intensity and returns the path-mean intensity
@@ -94,7 +129,9 @@ FTTE_HD double ftte_segment(double *I, double tau)
     const double Iin = *I;
     const double Iout = Iin * e;
     *I = Iout;
-    return (Iout == 0.0) ? 0.0 : Iin * g;
+    double mean = Iin * g;
+    if (FTTE_ANY(Iout == 0.0)) mean = (Iout == 0.0) ? 0.0 : mean; /* underflow: rare enough to branch on per wave */
+    return mean;
 }
 
 /* (acc/nseg)*w with acc/nseg correctly rounded for nseg in {1,2,3} without a
