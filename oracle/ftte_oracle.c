@@ -12,6 +12,7 @@
 
 /* the device arithmetic, for FO_ARITH_DEVICE only */
 #include "../radiativetransfer_amd/csrc/ftte_math.h"
+static const ftte_consts fo_device_consts = FTTE_CONSTS_INIT;
 
 /* ------------------------------------------------------------------ constants
  * definitionsModule.f90:8-10: `pi = 3.141592654` is a default-real literal, so
@@ -282,7 +283,7 @@ static double fo_segment(double *I, double kappa, double eta, double dpath, int 
      * Iin/Iout perturbs the logarithm by up to eps/2 absolute, i.e. the mean by Iin*(eps/2)/tau
      * (ftte_oracle.h, fo_diffuse_sweep_uniform: `noise`) */
     if (noise && tau > 0.0) *noise += Iin * (0x1p-53 / tau);
-    if (arith == FO_ARITH_DEVICE && eta == 0.0) return ftte_segment(I, tau);
+    if (arith == FO_ARITH_DEVICE && eta == 0.0) return ftte_segment(&fo_device_consts, I, tau);
     const double absorb = exp(-tau);
     /* (float)1.e-10: the threshold is a default-real literal, :658 */
     const double emit = (tau > (double)1.e-10f) ? (1.0 - absorb) / kappa : dpath;
@@ -683,7 +684,7 @@ void fo_compute_opacities(int64_t ncell, int nnu, const double *HI, const double
 /* ----------------------------------------------------- device arithmetic, exposed for tests */
 void fo_device_attenuation(int64_t count, const double *tau, double *e, double *g)
 {
-    for (int64_t i = 0; i < count; ++i) ftte_attenuation(tau[i], &e[i], &g[i]);
+    for (int64_t i = 0; i < count; ++i) ftte_attenuation(&fo_device_consts, tau[i], &e[i], &g[i]);
 }
 
 void fo_device_cell_mean(int64_t count, const double *acc, int nseg, double w, double *out)

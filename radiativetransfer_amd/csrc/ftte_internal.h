@@ -3,6 +3,8 @@
 #pragma once
 #include <cstdint>
 
+#include "ftte_math.h"
+
 namespace ftte {
 
 // ---- kernel-frame ray classes --------------------------------------------------------------
@@ -65,6 +67,7 @@ struct LaunchRec {
     int32_t n;          // grid size
     int32_t nitems;
     int32_t nnu;        // frequency groups; workgroup b handles group b % nnu of work item b / nnu
+    ftte_consts math;   // constants of ftte_math.h, delivered through scalar registers
 };
 
 } // namespace ftte

@@ -62,15 +62,15 @@ template <typename T> __device__ __forceinline__ T *uniform(T *p) { return reint
 // One segment of one ray.  EDGE: the cell may lie outside the domain, where the ray is
 // re-initialised with the inflow (transportRoutinesModule.f90:594-597) and adds nothing.
 template <bool EDGE>
-__device__ __forceinline__ double segment(double &I, double kap, double dpath, bool inside, double uvb)
+__device__ __forceinline__ double segment(const ftte_consts &K, double &I, double kap, double dpath, bool inside, double uvb)
 {
     if (EDGE) {
         double It = I;
-        const double m = ftte_segment(&It, kap * dpath);
+        const double m = ftte_segment(&K, &It, kap * dpath);
         I = inside ? It : uvb;
         return inside ? m : 0.0;
     }
-    return ftte_segment(&I, kap * dpath);
+    return ftte_segment(&K, &I, kap * dpath);
 }
 
 // One layer of one tile.  RC: chain class (ftte_internal.h).  I[r]: intensity of ray r of this
@@ -80,7 +80,8 @@ __device__ __forceinline__ double segment(double &I, double kap, double dpath, b
 //                     non-negative position (mirrored columns are folded into the position by the
 //                     caller) so that every access is  uniform 64-bit base + 32-bit lane offset.
 template <int ROWS, int RC, bool EDGE>
-__device__ __forceinline__ void layer_step(double (&I)[ROWS], const char *__restrict__ kplane, char *__restrict__ jplane,
+__device__ __forceinline__ void layer_step(const ftte_consts &K, double (&I)[ROWS], const char *__restrict__ kplane,
+                                           char *__restrict__ jplane,
                                            int cv0, int cu, int n, int sv, bool mirror_u, double d0, double d1, double d2,
                                            double w, double uvb, bool first, bool lane_owned)
 {
@@ -130,16 +131,16 @@ __device__ __forceinline__ void layer_step(double (&I)[ROWS], const char *__rest
         const bool in_v1 = !EDGE || (row + 1 >= 1 && row + 1 <= n);
 
         double m0, m1 = 0.0, m2 = 0.0;
-        m0 = segment<EDGE>(I[r], K0[r], d0, in_v0 && in_u0, uvb);
-        if (SHAPE == RC_TWO_U) m1 = segment<EDGE>(I[r], K1[r], d1, in_v0 && in_u1, uvb);
-        if (SHAPE == RC_TWO_V) m1 = segment<EDGE>(I[r], K0[r + 1], d1, in_v1 && in_u0, uvb);
+        m0 = segment<EDGE>(K, I[r], K0[r], d0, in_v0 && in_u0, uvb);
+        if (SHAPE == RC_TWO_U) m1 = segment<EDGE>(K, I[r], K1[r], d1, in_v0 && in_u1, uvb);
+        if (SHAPE == RC_TWO_V) m1 = segment<EDGE>(K, I[r], K0[r + 1], d1, in_v1 && in_u0, uvb);
         if (SHAPE == RC_THREE_U) {
-            m1 = segment<EDGE>(I[r], K1[r], d1, in_v0 && in_u1, uvb);
-            m2 = segment<EDGE>(I[r], K1[r + 1], d2, in_v1 && in_u1, uvb);
+            m1 = segment<EDGE>(K, I[r], K1[r], d1, in_v0 && in_u1, uvb);
+            m2 = segment<EDGE>(K, I[r], K1[r + 1], d2, in_v1 && in_u1, uvb);
         }
         if (SHAPE == RC_THREE_V) {
-            m1 = segment<EDGE>(I[r], K0[r + 1], d1, in_v1 && in_u0, uvb);
-            m2 = segment<EDGE>(I[r], K1[r + 1], d2, in_v1 && in_u1, uvb);
+            m1 = segment<EDGE>(K, I[r], K0[r + 1], d1, in_v1 && in_u0, uvb);
+            m2 = segment<EDGE>(K, I[r], K1[r + 1], d2, in_v1 && in_u1, uvb);
         }
 
         // the cell (row, cu) collects: its own xy segment, and the 2nd / 3rd segments that end
@@ -178,13 +179,14 @@ __device__ __forceinline__ void layer_step(double (&I)[ROWS], const char *__rest
 }
 
 template <int ROWS, bool EDGE>
-__device__ __forceinline__ void layer_dispatch(double (&I)[ROWS], int rc, const char *kplane, char *jplane, int cv0, int cu,
+__device__ __forceinline__ void layer_dispatch(const ftte_consts &K, double (&I)[ROWS], int rc, const char *kplane,
+                                               char *jplane, int cv0, int cu,
                                                int n, int sv, bool mirror_u, double d0, double d1, double d2, double w,
                                                double uvb, bool first, bool lane_owned)
 {
 #define FTTE_CASE(C)                                                                                                   \
     case C:                                                                                                            \
-        layer_step<ROWS, C, EDGE>(I, kplane, jplane, cv0, cu, n, sv, mirror_u, d0, d1, d2, w, uvb, first, lane_owned); \
+        layer_step<ROWS, C, EDGE>(K, I, kplane, jplane, cv0, cu, n, sv, mirror_u, d0, d1, d2, w, uvb, first, lane_owned); \
         break;
     switch (rc) {
         FTTE_CASE(RC_ONE)
@@ -194,7 +196,7 @@ __device__ __forceinline__ void layer_dispatch(double (&I)[ROWS], int rc, const 
         FTTE_CASE(RC_THREE_V)
         FTTE_CASE(RC_THREE_U_SWAP)
     default:
-        layer_step<ROWS, RC_THREE_V_SWAP, EDGE>(I, kplane, jplane, cv0, cu, n, sv, mirror_u, d0, d1, d2, w, uvb, first,
+        layer_step<ROWS, RC_THREE_V_SWAP, EDGE>(K, I, kplane, jplane, cv0, cu, n, sv, mirror_u, d0, d1, d2, w, uvb, first,
                                                 lane_owned);
         break;
     }
@@ -252,9 +254,9 @@ __global__ void __launch_bounds__(64, WAVES) sweep_kernel(const LaunchRec L)
         const int u_min = u_lo + 63 * tu - 1 + du, v_min = cv0;
         const bool interior = u_min >= 1 && u_min + 64 <= n && v_min >= 1 && v_min + ROWS <= n;
         if (interior)
-            layer_dispatch<ROWS, false>(I, rc, kplane, jplane, cv0, cu, n, sv, mirror_u, d0, d1, d2, w, uvb, first, lane_owned);
+            layer_dispatch<ROWS, false>(L.math, I, rc, kplane, jplane, cv0, cu, n, sv, mirror_u, d0, d1, d2, w, uvb, first, lane_owned);
         else
-            layer_dispatch<ROWS, true>(I, rc, kplane, jplane, cv0, cu, n, sv, mirror_u, d0, d1, d2, w, uvb, first, lane_owned);
+            layer_dispatch<ROWS, true>(L.math, I, rc, kplane, jplane, cv0, cu, n, sv, mirror_u, d0, d1, d2, w, uvb, first, lane_owned);
     }
 }
 

@@ -19,7 +19,7 @@
  * tests compare the GPU against a CPU evaluation bit for bit.
  *
  * Coefficients: tools/fit_exp_poly.py (degree 9, |r| <= ln2/2: approximation
- * error 4.1e-17 in g, 1.6e-17 in exp, before rounding).
+ * error 4.1e-17 in g, 1.6e-17 in exp, before rounding); see ftte_consts below.
  */
 #ifndef FTTE_MATH_H
 #define FTTE_MATH_H
@@ -70,41 +70,46 @@ __device__ __forceinline__ double ftte_div(double a, double b)
 #define FTTE_ANY(c) (c)
 #endif
 
-#define FTTE_LOG2E 0x1.71547652b82fep+0   /* 1/ln2 */
-#define FTTE_LN2_HI 0x1.62e42fee00000p-1  /* ln2, low 21 bits clear: n*LN2_HI exact for |n| < 2^21 */
-#define FTTE_LN2_LO 0x1.a39ef35793c76p-33 /* ln2 - LN2_HI */
-#define FTTE_X_FLOOR (-1000.0)            /* exp(-1000) == 0 in binary64; keeps n inside int range */
+/* The constants of the attenuation pair, passed as a table: on the device the table arrives through the kernel
+ * argument segment, so the coefficients sit in scalar registers and every Horner step is one v_fma_f64 with a scalar
+ * addend (as literals hipcc parks them in vector registers and pays a v_mov_b64 per step). */
+typedef struct {
+    double log2e;   /* 1/ln2 */
+    double ln2_hi;  /* ln2, low 21 bits clear: n*ln2_hi exact for |n| < 2^21 */
+    double ln2_lo;  /* ln2 - ln2_hi */
+    double x_floor; /* exp(x_floor) == 0 in binary64; keeps n inside int range */
+    double c[10];   /* (exp(r)-1-r)/r^2 ~ c0 + c1 r + ... + c9 r^9, tools/fit_exp_poly.py */
+} ftte_consts;
 
-#define FTTE_EXPQ_C0 0x1.0000000000001p-1
-#define FTTE_EXPQ_C1 0x1.5555555555556p-3
-#define FTTE_EXPQ_C2 0x1.5555555553d63p-5
-#define FTTE_EXPQ_C3 0x1.11111111109b3p-7
-#define FTTE_EXPQ_C4 0x1.6c16c1788bd90p-10
-#define FTTE_EXPQ_C5 0x1.a01a01a7c41d5p-13
-#define FTTE_EXPQ_C6 0x1.a019b90d2ae7ap-16
-#define FTTE_EXPQ_C7 0x1.71de0dae63bb3p-19
-#define FTTE_EXPQ_C8 0x1.289185613a3d6p-22
-#define FTTE_EXPQ_C9 0x1.af38a9b0ec855p-26
+#define FTTE_CONSTS_INIT                                                                                              \
+    {                                                                                                                 \
+        0x1.71547652b82fep+0, 0x1.62e42fee00000p-1, 0x1.a39ef35793c76p-33, -1000.0,                                   \
+        {                                                                                                             \
+            0x1.0000000000001p-1, 0x1.5555555555556p-3, 0x1.5555555553d63p-5, 0x1.11111111109b3p-7,                   \
+                0x1.6c16c1788bd90p-10, 0x1.a01a01a7c41d5p-13, 0x1.a019b90d2ae7ap-16, 0x1.71de0dae63bb3p-19,           \
+                0x1.289185613a3d6p-22, 0x1.af38a9b0ec855p-26                                                          \
+        }                                                                                                             \
+    }
 
 /* e = exp(-tau), g = (1-exp(-tau))/tau  (g(0) = 1).  tau >= 0 expected; a
  * negative tau (unphysical opacity) still evaluates, up to overflow. */
-FTTE_HD void ftte_attenuation(double tau, double *e_out, double *g_out)
+FTTE_HD void ftte_attenuation(const ftte_consts *K, double tau, double *e_out, double *g_out)
 {
-    const double x = FTTE_FMAX(-tau, FTTE_X_FLOOR);
-    const double nf = FTTE_RINT(x * FTTE_LOG2E);
-    double r = FTTE_FMA(nf, -FTTE_LN2_HI, x);
-    r = FTTE_FMA(nf, -FTTE_LN2_LO, r);
+    const double x = FTTE_FMAX(-tau, K->x_floor);
+    const double nf = FTTE_RINT(x * K->log2e);
+    double r = FTTE_FMA(nf, -K->ln2_hi, x);
+    r = FTTE_FMA(nf, -K->ln2_lo, r);
 
-    double q = FTTE_EXPQ_C9;
-    q = FTTE_FMA(q, r, FTTE_EXPQ_C8);
-    q = FTTE_FMA(q, r, FTTE_EXPQ_C7);
-    q = FTTE_FMA(q, r, FTTE_EXPQ_C6);
-    q = FTTE_FMA(q, r, FTTE_EXPQ_C5);
-    q = FTTE_FMA(q, r, FTTE_EXPQ_C4);
-    q = FTTE_FMA(q, r, FTTE_EXPQ_C3);
-    q = FTTE_FMA(q, r, FTTE_EXPQ_C2);
-    q = FTTE_FMA(q, r, FTTE_EXPQ_C1);
-    q = FTTE_FMA(q, r, FTTE_EXPQ_C0);
+    double q = K->c[9];
+    q = FTTE_FMA(q, r, K->c[8]);
+    q = FTTE_FMA(q, r, K->c[7]);
+    q = FTTE_FMA(q, r, K->c[6]);
+    q = FTTE_FMA(q, r, K->c[5]);
+    q = FTTE_FMA(q, r, K->c[4]);
+    q = FTTE_FMA(q, r, K->c[3]);
+    q = FTTE_FMA(q, r, K->c[2]);
+    q = FTTE_FMA(q, r, K->c[1]);
+    q = FTTE_FMA(q, r, K->c[0]);
 
     const double g0 = FTTE_FMA(r, q, 1.0);  /* expm1(r)/r */
     const double e0 = FTTE_FMA(r, g0, 1.0); /* exp(r)     */
@@ -122,10 +127,10 @@ FTTE_HD void ftte_attenuation(double tau, double *e_out, double *g_out)
 /* One segment: advances the ray intensity and returns the path-mean intensity
  * the cell receives from it.  Iout == 0 (underflow) yields a zero mean, as the
  * reference's (Iin-0)/log(Iin/0) does. */
-FTTE_HD double ftte_segment(double *I, double tau)
+FTTE_HD double ftte_segment(const ftte_consts *K, double *I, double tau)
 {
     double e, g;
-    ftte_attenuation(tau, &e, &g);
+    ftte_attenuation(K, tau, &e, &g);
     const double Iin = *I;
     const double Iout = Iin * e;
     *I = Iout;

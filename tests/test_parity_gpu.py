@@ -55,7 +55,7 @@ def test_every_izone_bitwise(engine, rows, n):
 GOLDEN_UNIFORM = ["uniform8_transparent", "uniform16_constant", "uniform16_lognormal_24zones", "uniform24_lognormal_48dir"]
 
 
-@pytest.mark.parametrize("slots", [1, 4])
+@pytest.mark.parametrize("slots", [1, 4, 6])
 @pytest.mark.parametrize("name", GOLDEN_UNIFORM)
 def test_reference_goldens(engine, golden, name, slots):
     """The reference's own outputs (3 frequency groups, tests/golden/) within the tau-aware tolerance."""
@@ -66,7 +66,7 @@ def test_reference_goldens(engine, golden, name, slots):
     engine.set_grid(n, g["level"], float(g["box"]))
     engine.set_opacity(g["kappa"])
     J = engine.transport(g["phi"], g["theta"], g["w"], g["uvb"])
-    engine.set_option("slots", 4)
+    engine.set_option("slots", 6)
     _, noise = O.sweep_uniform(n, *args, with_noise=True)
     assert np.all(np.abs(J - g["J"]) <= reference_bound(n, g["J"], noise))
     # and against the same arithmetic on the host: only the summation order differs
@@ -142,6 +142,57 @@ def test_species_opacities(engine):
     kappa = O.compute_opacities(HI, HeI, HeII, beta)
     ref = O.sweep_uniform(n, kappa, 1.0, phi, theta, w, uvb, arith=O.ARITH_DEVICE)
     assert np.allclose(J, ref, rtol=SUM_RTOL, atol=0)
+
+
+def test_caches_follow_their_inputs(engine):
+    """The library caches the three opacity layouts and the direction plan; changing any input must invalidate them:
+    new opacities (all layouts), a new direction list, a new grid size, new tuning."""
+    rng = np.random.default_rng(11)
+    dirs24 = np.array(one_per_izone())
+    uvb = np.array([1e-21, 3e-22])
+    for n in (12, 9):
+        engine.set_uniform_grid(n, 1.5)
+        for trial in range(2):
+            kappa = rng.lognormal(0, 1, (2, n ** 3)) * n * 0.3
+            engine.set_opacity(kappa)
+            for sel in (slice(0, 24), slice(5, 17)):
+                phi, theta = dirs24[sel, 0].copy(), dirs24[sel, 1].copy()
+                w = np.full(len(phi), 1.0 / len(phi))
+                J = engine.transport(phi, theta, w, uvb)
+                ref = O.sweep_uniform(n, kappa, 1.5, phi, theta, w, uvb, arith=O.ARITH_DEVICE)
+                assert np.allclose(J, ref, rtol=SUM_RTOL, atol=0)
+    engine.set_option("rows", 4)
+    engine.set_option("waves", 6)
+    J2 = engine.transport(phi, theta, w, uvb)
+    engine.set_option("rows", 8)
+    engine.set_option("waves", 4)
+    assert np.allclose(J2, ref, rtol=SUM_RTOL, atol=0)
+
+
+def test_arbitrary_directions_and_weights(engine):
+    """Directions need not come from HEALPix: random angles, unequal weights, one frequency group."""
+    rng = np.random.default_rng(21)
+    n = 31
+    pi = O.lib().fo_pi()
+    phi = rng.uniform(0.01, 2 * pi - 0.01, 40)
+    theta = rng.uniform(0.02, 0.5 * pi - 0.02, 40) * rng.choice([-1, 1], 40)
+    keep = [i for i in range(40) if _foldable(phi[i], theta[i])]
+    phi, theta = phi[keep], theta[keep]
+    w = rng.random(len(phi))
+    kappa, uvb, box = synthetic.uniform_workload(n, 1, seed=8, tau_median=0.5)
+    engine.set_uniform_grid(n, box)
+    engine.set_opacity(kappa)
+    J = engine.transport(phi, theta, w, uvb)
+    ref, noise = O.sweep_uniform(n, kappa, box, phi, theta, w, uvb, with_noise=True)
+    assert np.all(np.abs(J - ref) <= reference_bound(n, ref, noise))
+
+
+def _foldable(p, t):
+    try:
+        O.fold_direction(p, t)
+        return True
+    except ValueError:
+        return False
 
 
 def test_call_order_and_refusals(engine):
