@@ -67,8 +67,8 @@ const char *ftte_last_error(const ftte_ctx *ctx);
  * (readCellArray.f90:154-187 createFullyThreadedStructure) and for physicalBoxSize
  * (definitionsModule.f90:256).  nx == ny == nz is required, as in the reference.
  * level[ncell]: depth-first leaf list, 0 = base cell.  A list of all zeros (ncell = nx^3) is a
- * uniform grid; refined cell arrays are validated and then refused with FTTE_ERR_UNSUPPORTED
- * by this build (scope). */
+ * uniform grid and takes the tiled sweep kernel; a refined cell array takes the general
+ * segment-forest path (setRaysRefined / findNeighbours / transport of the reference). */
 int ftte_set_grid(ftte_ctx *ctx, int nx, int ny, int nz, int64_t ncell, const int32_t *level, double box_cm);
 
 /* Opacities kappa[nnu][ncell] in cell-array order (host memory), cm^-1.  Stands in for the
@@ -106,10 +106,13 @@ int ftte_diffuse_sweep_device(ftte_ctx *ctx, int ndir, const double *phi, const 
 
 /* ---- tuning and instrumentation ------------------------------------------------------------- */
 
-/* Tuning knobs: "rows" (rays per lane: 4, 8 or 16), "slots" (directions in flight per
- * launch, 1..16), "waves" (waves per SIMD the sweep kernel's register allocation is held to:
- * 2, 3, 4, 5, 6 or 8).  Results do not depend on any of them except through the order in
- * which "slots" sums directions.  Unknown keys return FTTE_ERR_ARG. */
+/* Tuning knobs: "rows" (rays per lane: 4, 8 or 16), "stack" (wavefronts per workgroup, stacked
+ * along the row axis and exchanging their boundary row through LDS: 1, 2, 4 or 8), "slots"
+ * (directions in flight per launch, 1..16), "waves" (waves per SIMD the sweep kernel's register
+ * allocation is held to: 2, 3, 4 or 6), "forest" (1: use the refined-grid path on a uniform grid
+ * too, for cross-checks).  Built variants: rows x stack = 4x{1,4,8}, 8x{1,2,4}, 16x1.
+ * Results do not depend on any of them except through the order in which "slots" sums
+ * directions.  Unknown keys return FTTE_ERR_ARG. */
 int ftte_set_option(ftte_ctx *ctx, const char *key, int value);
 /* Launch records of the last sweep (valid after the sweep's stream has been synchronised).
  * Each sweep-kernel launch is bracketed by HIP events on the stream it runs on. */

@@ -1,0 +1,281 @@
+// ftte_amr.cpp -- see ftte_amr.h.  Host-side only; O(leaves) per direction, done once per (tree, direction
+// list) and cached by the context: the reference's tree is static over a whole run, while it re-links every
+// leaf for every direction in every iteration (equiSources.f90:1557-1566).
+#include "ftte_amr.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <functional>
+
+#include "ftte_geometry.h"
+
+namespace ftte {
+
+std::string AmrTree::build(int n_, int64_t ncell_, const int32_t *lv)
+{
+    n = n_;
+    ncell = ncell_;
+    max_level = 0;
+    const int64_t nbase = (int64_t)n * n * n;
+    parent.assign(nbase, -1);
+    child0.assign(nbase, -1);
+    leaf.assign(nbase, -1);
+    level.assign(nbase, 0);
+    int64_t cur = 0;
+    std::string err;
+    // createFullyThreadedStructure, readCellArray.f90:154-187: a cell whose list entry is deeper than itself is
+    // refined and its eight children consume the following entries
+    std::function<void(int32_t, int)> grow = [&](int32_t node, int depth) {
+        if (!err.empty()) return;
+        if (cur >= ncell) { err = "error in levels: level list ends inside a refined cell"; return; }
+        const int l = lv[cur];
+        if (l == depth) {
+            leaf[node] = (int32_t)cur++;
+        } else if (l > depth) {
+            if (depth + 1 > 60) { err = "error in levels: more than 60 levels"; return; }
+            const int32_t c0 = (int32_t)parent.size();
+            child0[node] = c0;
+            for (int c = 0; c < 8; ++c) {
+                parent.push_back(node);
+                child0.push_back(-1);
+                leaf.push_back(-1);
+                level.push_back((int8_t)(depth + 1));
+            }
+            max_level = std::max(max_level, depth + 1);
+            for (int c = 0; c < 8; ++c) grow(c0 + c, depth + 1);
+        } else {
+            err = "error in levels: level list is not a depth-first leaf list";
+        }
+    };
+    for (int64_t b = 0; b < nbase && err.empty(); ++b) grow((int32_t)b, 0);
+    if (err.empty() && cur != ncell) err = "error in levels: level list longer than the tree it describes";
+    return err;
+}
+
+namespace {
+
+struct PatNode {
+    ftte_pattern p;
+    int32_t sub[2]; // patterns of the lower / upper sub-layer of a refined cell carrying this pattern
+};
+
+struct Builder {
+    const AmrTree &T;
+    AmrForest &F;
+    int izone;
+    double phi, theta;
+    int cs[2][2][2]; // storage child index of the sweep child (i,j,k)
+    std::vector<PatNode> pats;
+    std::vector<int32_t> node_pat;
+    std::vector<int32_t> depth;
+    int32_t anc[64];
+    int seq[64][3];
+    int status = 0;
+    std::string err;
+
+    Builder(const AmrTree &t, AmrForest &f) : T(t), F(f) {}
+
+    static int slot_of(int top) { return top == 1 ? 0 : (top == 3 ? 1 : 2); } // xyEnd, xzEnd, yzEnd -> 0, 1, 2
+
+    // setRaysRefined, transportRoutinesModule.f90:150-187: the lower sub-layer starts at the parent's entry point
+    // doubled (mod 1), the upper one where the lower one's top-ending segment leaves
+    int32_t sub_pattern(int32_t parent, int which)
+    {
+        if (pats[parent].sub[0] < 0) {
+            PatNode lo, hi;
+            std::memset(&lo, 0, sizeof lo);
+            std::memset(&hi, 0, sizeof hi);
+            lo.sub[0] = lo.sub[1] = hi.sub[0] = hi.sub[1] = -1;
+            const ftte_pattern &pp = pats[parent].p;
+            lo.p.xy_x0 = pp.xy_x0 < 0.5 ? 2.0 * pp.xy_x0 : 2.0 * pp.xy_x0 - 1.0;
+            lo.p.xy_y0 = pp.xy_y0 < 0.5 ? 2.0 * pp.xy_y0 : 2.0 * pp.xy_y0 - 1.0;
+            if (set_pattern(&lo.p, phi, theta)) { status = FTTE_ERR_PATTERN; err = "ray pattern left the unit cell"; }
+            if (advance_entry(lo.p, &hi.p.xy_x0, &hi.p.xy_y0) || set_pattern(&hi.p, phi, theta)) {
+                status = FTTE_ERR_PATTERN;
+                err = "ray pattern left the unit cell";
+            }
+            const int32_t a = (int32_t)pats.size();
+            pats.push_back(lo);
+            pats.push_back(hi);
+            pats[parent].sub[0] = a;
+            pats[parent].sub[1] = a + 1;
+        }
+        return pats[parent].sub[which];
+    }
+
+    // where the top-ending segment of `b` leaves the cell = entry point of the (sub-)layer above
+    // (equiSources.f90:1507-1522, transportRoutinesModule.f90:167-182)
+    int advance_entry(const ftte_pattern &b, double *x0, double *y0) const
+    {
+        if (b.xy_top == 1) {
+            *x0 = b.xy_x0 + std::cos(phi) / std::tan(theta);
+            *y0 = b.xy_y0 + std::sin(phi) / std::tan(theta);
+        } else if (b.xy_top == 3) {
+            *x0 = b.xz_x0 + b.xz_len * std::cos(theta) * std::cos(phi);
+            *y0 = b.xz_len * std::cos(theta) * std::sin(phi);
+        } else if (b.xy_top == 2) {
+            *x0 = b.yz_len * std::cos(theta) * std::cos(phi);
+            *y0 = b.yz_y0 + b.yz_len * std::cos(theta) * std::sin(phi);
+        } else return 1;
+        return (*x0 > 1.0 || *y0 > 1.0) ? 1 : 0;
+    }
+
+    // get??Neighbour, transportRoutinesModule.f90:455-558: go down into `c`, at every level into the child that
+    // holds the entry point (a, b) on the shared face; `.le. 0.5` picks the lower half.
+    // face 0: (x, y) on the bottom face, children of the upper sub-layer;  face 1: (x, z), children of the far-y half;
+    // face 2: (y, z), children of the far-x half.  Sweep frame: i <-> z, j <-> y, k <-> x.
+    int32_t descend(int32_t c, int face, double a, double b) const
+    {
+        while (T.child0[c] >= 0) {
+            const int ha = a <= 0.5 ? 0 : 1, hb = b <= 0.5 ? 0 : 1;
+            int i, j, k;
+            if (face == 0) { i = 1; k = ha; j = hb; }
+            else if (face == 1) { j = 1; k = ha; i = hb; }
+            else { k = 1; j = ha; i = hb; }
+            c = T.child0[c] + cs[i][j][k];
+            a = 2.0 * a - ha;
+            b = 2.0 * b - hb;
+        }
+        return c;
+    }
+
+    // findNeighbours for one face, transportRoutinesModule.f90:264-418
+    int32_t upstream_leaf(int lvl, int face, double a, double b) const
+    {
+        for (int lv = lvl; lv >= 0; --lv) {
+            const int i = seq[lv][0], j = seq[lv][1], k = seq[lv][2];
+            const int along = face == 0 ? i : (face == 1 ? j : k);
+            if (along > 1) {
+                const int si = i - (face == 0), sj = j - (face == 1), sk = k - (face == 2);
+                int32_t sib;
+                if (lv == 0) {
+                    int ic, jc, kc;
+                    rotate_indices(si, sj, sk, T.n, T.n, T.n, izone, &ic, &jc, &kc);
+                    sib = (int32_t)(((int64_t)(ic - 1) * T.n + (jc - 1)) * T.n + (kc - 1));
+                } else sib = T.child0[anc[lv - 1]] + cs[si - 1][sj - 1][sk - 1];
+                return descend(sib, face, a, b);
+            }
+            // no sibling on the upstream side at this level: express the entry point in the parent's units
+            if (face == 0) { b = b / 2.0 + (j == 1 ? 0.0 : 0.5); a = a / 2.0 + (k == 1 ? 0.0 : 0.5); }
+            else if (face == 1) { b = b / 2.0 + (i == 1 ? 0.0 : 0.5); a = a / 2.0 + (k == 1 ? 0.0 : 0.5); }
+            else { b = b / 2.0 + (i == 1 ? 0.0 : 0.5); a = a / 2.0 + (j == 1 ? 0.0 : 0.5); }
+        }
+        return -1;
+    }
+
+    void leaf_segments(int32_t node, int lvl, double cell)
+    {
+        const ftte_pattern &P = pats[node_pat[node]].p;
+        const int64_t base = 3 * (int64_t)T.leaf[node];
+        for (int face = 0; face < 3; ++face) {
+            const int64_t seg = base + face;
+            const bool active = face == 0 || (face == 1 ? P.xz_active : P.yz_active) != 0;
+            if (!active) { F.up[seg] = AmrForest::kInactive; continue; }
+            double a, b, len;
+            if (face == 0) { a = P.xy_x0; b = P.xy_y0; len = P.xy_len; }
+            else if (face == 1) { a = P.xz_x0; b = P.xz_z0; len = P.xz_len; }
+            else { a = P.yz_y0; b = P.yz_z0; len = P.yz_len; }
+            F.dpath[seg] = cell * len;
+            const int32_t U = upstream_leaf(lvl, face, a, b);
+            int32_t d = 0;
+            if (U < 0) {
+                F.up[seg] = AmrForest::kInflow;
+            } else {
+                const ftte_pattern &Q = pats[node_pat[U]].p;
+                const int top = face == 0 ? Q.xy_top : (face == 1 ? Q.xz_top : Q.yz_top);
+                const int32_t ub = 3 * T.leaf[U];
+                if (top != 0) {
+                    F.up[seg] = ub + slot_of(top);
+                } else {
+                    // the upstream leaf has no segment ending on the shared face: legal only behind a coarser leaf,
+                    // which then hands over the mean of its xy and xz (else yz) segments (:612-634)
+                    if (lvl <= T.level[U]) {
+                        status = FTTE_ERR_PATTERN;
+                        err = "upstream cell of the same or a finer level has no segment ending on the shared face "
+                              "(the reference stops here: 'error in xzTop')";
+                        return;
+                    }
+                    if (Q.xz_active) { F.up[seg] = ub + 1; F.up2[seg] = ub; }
+                    else if (Q.yz_active) { F.up[seg] = ub + 2; F.up2[seg] = ub; }
+                    else F.up[seg] = ub;
+                }
+                d = 1 + depth[F.up[seg]];
+                if (F.up2[seg] >= 0) d = std::max(d, 1 + depth[F.up2[seg]]);
+            }
+            depth[seg] = d;
+        }
+    }
+
+    // transport's recursion order, transportRoutinesModule.f90:577-586: children in sweep order
+    void visit(int32_t node, int32_t pat, int lvl, double cell)
+    {
+        if (status) return;
+        node_pat[node] = pat;
+        anc[lvl] = node;
+        if (T.child0[node] < 0) { leaf_segments(node, lvl, cell); return; }
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j)
+                for (int k = 0; k < 2; ++k) {
+                    seq[lvl + 1][0] = i + 1; seq[lvl + 1][1] = j + 1; seq[lvl + 1][2] = k + 1;
+                    visit(T.child0[node] + cs[i][j][k], sub_pattern(pat, i), lvl + 1, cell / 2.0);
+                }
+    }
+};
+
+} // namespace
+
+int build_forest(const AmrTree &tree, double phi, double theta, int izone, double box, AmrForest *out, std::string *err)
+{
+    AmrForest &F = *out;
+    const int n = tree.n;
+    const int64_t nseg = 3 * tree.ncell;
+    F.izone = izone; F.phi = phi; F.theta = theta;
+    F.up.assign(nseg, AmrForest::kInactive);
+    F.up2.assign(nseg, -1);
+    F.dpath.assign(nseg, 0.0);
+
+    Builder B(tree, F);
+    B.izone = izone; B.phi = phi; B.theta = theta;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            for (int k = 0; k < 2; ++k) {
+                int a, b, c;
+                rotate_indices(i + 1, j + 1, k + 1, 2, 2, 2, izone, &a, &b, &c); // equiSources.f90:1485-1491
+                B.cs[i][j][k] = 4 * (a - 1) + 2 * (b - 1) + (c - 1);
+            }
+    std::vector<ftte_pattern> layers(n);
+    if (layer_patterns(n, phi, theta, layers.data())) {
+        *err = "ray pattern left the unit cell (setPattern consistency check)";
+        return FTTE_ERR_PATTERN;
+    }
+    B.pats.resize(n);
+    for (int i = 0; i < n; ++i) { B.pats[i].p = layers[i]; B.pats[i].sub[0] = B.pats[i].sub[1] = -1; }
+    B.node_pat.assign(tree.parent.size(), -1);
+    B.depth.assign(nseg, 0);
+
+    const double cell = box / (double)n; // equiSources.f90:1570
+    for (int i = 1; i <= n && !B.status; ++i)
+        for (int j = 1; j <= n && !B.status; ++j)
+            for (int k = 1; k <= n && !B.status; ++k) {
+                int ic, jc, kc;
+                rotate_indices(i, j, k, n, n, n, izone, &ic, &jc, &kc);
+                B.seq[0][0] = i; B.seq[0][1] = j; B.seq[0][2] = k;
+                B.visit((int32_t)(((int64_t)(ic - 1) * n + (jc - 1)) * n + (kc - 1)), i - 1, 0, cell);
+            }
+    if (B.status) { *err = B.err; return B.status; }
+
+    // counting sort of the active segments by depth
+    int32_t maxd = 0;
+    for (int64_t s = 0; s < nseg; ++s) if (F.up[s] != AmrForest::kInactive) maxd = std::max(maxd, B.depth[s]);
+    F.depth_off.assign((size_t)maxd + 2, 0);
+    for (int64_t s = 0; s < nseg; ++s) if (F.up[s] != AmrForest::kInactive) ++F.depth_off[B.depth[s] + 1];
+    for (size_t d = 1; d < F.depth_off.size(); ++d) F.depth_off[d] += F.depth_off[d - 1];
+    F.order.resize((size_t)F.depth_off.back());
+    std::vector<int64_t> cursor(F.depth_off.begin(), F.depth_off.end() - 1);
+    for (int64_t s = 0; s < nseg; ++s)
+        if (F.up[s] != AmrForest::kInactive) F.order[(size_t)cursor[B.depth[s]]++] = (int32_t)s;
+    return 0;
+}
+
+} // namespace ftte

@@ -1,0 +1,56 @@
+// ftte_amr.h -- host planner of the sweep on refined cell arrays (the fully threaded tree of the reference).
+//
+// On an AMR tree the per-direction dependency structure of the reference (setRaysRefined, findNeighbours,
+// get??Neighbour, transport: transportRoutinesModule.f90:121-218, 264-558, 560-963) is a forest over ray
+// *segments*: every segment (leaf, xy|xz|yz) takes its incoming intensity from exactly one upstream segment --
+// the one of the upstream leaf that ends on the shared face -- or from the inflow, or (a fine cell behind a
+// coarser one that has no segment ending on that face, :612-634) from the mean of two segments of that leaf.
+// The planner walks the tree once per direction in the reference's sweep order, resolves those links with
+// the reference's rules, and orders the segments by their depth in the forest.  The device then processes one
+// depth after the other (ftte_kernels.hip: amr_level_kernel), every segment of a depth in parallel.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/ftte.h"
+
+namespace ftte {
+
+// The tree rebuilt from the depth-first leaf list (readCellArray.f90:154-187).  Nodes 0 .. n^3-1 are the base
+// cells in storage order; the 8 children of a refined node are contiguous, indexed 4(a-1)+2(b-1)+(c-1) by their
+// storage position (a,b,c), which is also their order in the cell array (equiSources.f90:4044-4079).
+struct AmrTree {
+    int n = 0;
+    int64_t ncell = 0;
+    int max_level = 0;
+    std::vector<int32_t> parent; // node -> parent node (-1 for base cells)
+    std::vector<int32_t> child0; // node -> first child node, -1 for a leaf
+    std::vector<int32_t> leaf;   // node -> cell-array index, -1 for a refined node
+    std::vector<int8_t> level;
+
+    // returns "" or the reference's complaint ('error in levels', readCellArray.f90:182)
+    std::string build(int n, int64_t ncell, const int32_t *levels);
+    bool refined() const { return max_level > 0; }
+};
+
+// One direction's segment forest.  Segment id = 3 * leaf + slot, slot 0 xy, 1 xz, 2 yz (the order in which the
+// reference adds them into the cell's mean).
+struct AmrForest {
+    static constexpr int32_t kInflow = -1;   // upstream is the domain boundary
+    static constexpr int32_t kInactive = -2; // the leaf's pattern has no such segment
+    std::vector<int32_t> up;     // [3 ncell] upstream segment, kInflow, or kInactive
+    std::vector<int32_t> up2;    // [3 ncell] second upstream segment of the mean-of-two rule, else -1
+    std::vector<double> dpath;   // [3 ncell] cell size * segment length (transportRoutinesModule.f90:651)
+    std::vector<int32_t> order;  // active segments sorted by depth
+    std::vector<int64_t> depth_off; // [ndepth + 1] ranges of `order`
+    int izone = 0;
+    double phi = 0, theta = 0;
+};
+
+// Returns 0, or an ftte_status (FTTE_ERR_PATTERN where the reference stops: a pattern leaving the unit cell,
+// or a same-level upstream leaf without a segment on the shared face, transportRoutinesModule.f90:613-616).
+int build_forest(const AmrTree &tree, double phi_folded, double theta_folded, int izone, double box, AmrForest *out,
+                 std::string *err);
+
+} // namespace ftte

@@ -12,7 +12,10 @@
 #include <string>
 #include <vector>
 
+#include <thread>
+
 #include "../../include/ftte.h"
+#include "ftte_amr.h"
 #include "ftte_geometry.h"
 #include "ftte_internal.h"
 #include "ftte_kernels.h"
@@ -46,7 +49,7 @@ struct LaunchPlan {
 struct Plan {
     bool valid = false;
     // key
-    int n = 0, rows = 0, slots = 0;
+    int n = 0, rows = 0, slots = 0, stack = 0;
     double box = 0;
     std::vector<double> phi, theta, w;
     // content
@@ -82,7 +85,7 @@ struct ftte_ctx {
     double *acc[3][kMaxSlots] = {};
     size_t acc_cap = 0; // elements per accumulator
 
-    int rows = 8, slots = 6, waves = 4;
+    int rows = 8, slots = 6, waves = 4, stack = 1;
 
     Plan plan;
     LayerRec *d_layers = nullptr; size_t d_layers_cap = 0;
@@ -92,6 +95,21 @@ struct ftte_ctx {
 
     std::vector<LaunchTiming> timing;
     int timing_used = 0;
+
+    // refined cell arrays: the tree, and the per-direction segment forests resident on the device
+    AmrTree tree;
+    bool use_forest = false;  // refined grid (or option "forest" = 1 on a uniform one, for cross-checks)
+    int force_forest = 0;
+    struct ForestDev {
+        int32_t *up = nullptr, *up2 = nullptr, *order = nullptr;
+        double *dpath = nullptr;
+        std::vector<int64_t> depth_off;
+        double w = 0;
+    };
+    std::vector<ForestDev> forests;
+    std::vector<double> forest_key; // phi, theta, w of the cached forests (+ box)
+    double *amr_Iout = nullptr, *amr_mean = nullptr;
+    size_t amr_scratch_cap = 0; // elements per array
 };
 
 namespace {
@@ -121,15 +139,16 @@ int fold_status(int rc)
 int build_plan(ftte_ctx *c, int ndir, const double *phi, const double *theta, const double *w)
 {
     Plan &P = c->plan;
-    const int n = c->n, rows = c->rows, slots = c->slots;
-    if (P.valid && P.n == n && P.rows == rows && P.slots == slots && P.box == c->box && (int)P.phi.size() == ndir &&
+    const int n = c->n, rows = c->rows, slots = c->slots, stack = c->stack;
+    const int tile_rows = stack * rows - 1; // owned rows of one work item
+    if (P.valid && P.n == n && P.rows == rows && P.slots == slots && P.stack == stack && P.box == c->box && (int)P.phi.size() == ndir &&
         (ndir == 0 || (!std::memcmp(P.phi.data(), phi, sizeof(double) * ndir) &&
                        !std::memcmp(P.theta.data(), theta, sizeof(double) * ndir) &&
                        !std::memcmp(P.w.data(), w, sizeof(double) * ndir))))
         return FTTE_OK;
 
     P = Plan();
-    P.n = n; P.rows = rows; P.slots = slots; P.box = c->box;
+    P.n = n; P.rows = rows; P.slots = slots; P.stack = stack; P.box = c->box;
     P.phi.assign(phi, phi + ndir); P.theta.assign(theta, theta + ndir); P.w.assign(w, w + ndir);
     P.dirs.resize(ndir);
     P.layers.resize((size_t)ndir * n);
@@ -212,7 +231,7 @@ int build_plan(ftte_ctx *c, int ndir, const double *phi, const double *theta, co
         D.u_lo = 1 - du_cum[n - 1];
         D.v_lo = 1 - dv_cum[n - 1];
         D.ntu = (n - D.u_lo + 1 + 62) / 63;
-        D.ntv = (n - D.v_lo + 1 + rows - 2) / (rows - 1);
+        D.ntv = (n - D.v_lo + 1 + tile_rows - 1) / tile_rows;
         D.slot = in_layout[D.layout]++ % slots;
     }
 
@@ -237,7 +256,7 @@ int build_plan(ftte_ctx *c, int ndir, const double *phi, const double *theta, co
                         // owned labels of this tile; a layer is active when any owned ray, or the cell one
                         // step beyond it, is inside the domain
                         const int ul_min = D.u_lo + 63 * tu, ul_max = ul_min + 62;
-                        const int vl_min = D.v_lo + (rows - 1) * tv, vl_max = vl_min + rows - 2;
+                        const int vl_min = D.v_lo + tile_rows * tv, vl_max = vl_min + tile_rows - 1;
                         int i_first = 0, i_last = -1;
                         for (int i = 1; i <= n; ++i) {
                             const int cu_d = (int)(short)(Ls[i - 1].drift & 0xffff), cv_d = Ls[i - 1].drift >> 16;
@@ -296,6 +315,141 @@ int check_ready(ftte_ctx *c, bool need_kappa)
     return FTTE_OK;
 }
 
+void free_forests(ftte_ctx *c)
+{
+    for (auto &f : c->forests) {
+        if (f.up) (void)hipFree(f.up);
+        if (f.up2) (void)hipFree(f.up2);
+        if (f.order) (void)hipFree(f.order);
+        if (f.dpath) (void)hipFree(f.dpath);
+    }
+    c->forests.clear();
+    c->forest_key.clear();
+}
+
+// The sweep on a refined cell array: per-direction segment forests (ftte_amr.h), processed depth by depth.
+int forest_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, const double *w, const double *uvb,
+                 double *J_dev, hipStream_t stream)
+{
+    const int nnu = c->nnu;
+    const int64_t ncell = c->ncell, nseg = 3 * ncell;
+    int rc;
+
+    // ---- plan: fold, link, order; cached while the direction list, the tree and the box stay the same
+    std::vector<double> key;
+    key.reserve(3 * (size_t)ndir + 1);
+    key.push_back(c->box);
+    key.insert(key.end(), phi, phi + ndir);
+    key.insert(key.end(), theta, theta + ndir);
+    key.insert(key.end(), w, w + ndir);
+    if (key != c->forest_key || (int)c->forests.size() != ndir) {
+        FTTE_HIP(c, hipStreamSynchronize(stream));
+        free_forests(c);
+        std::vector<double> fphi(ndir), ftheta(ndir);
+        std::vector<int> fzone(ndir);
+        for (int d = 0; d < ndir; ++d) {
+            const int frc = fold_direction(phi[d], theta[d], &fphi[d], &ftheta[d], &fzone[d]);
+            if (frc) {
+                char buf[160];
+                std::snprintf(buf, sizeof buf, "direction %d (phi=%.17g, theta=%.17g) cannot be folded", d, phi[d], theta[d]);
+                return fail(c, fold_status(frc), buf);
+            }
+        }
+        c->forests.resize(ndir);
+        // link on the host, a few directions at a time on separate threads, upload, drop the host copy
+        const int nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        for (int d0 = 0; d0 < ndir; d0 += nthreads) {
+            const int nb = std::min(nthreads, ndir - d0);
+            std::vector<AmrForest> F(nb);
+            std::vector<int> st(nb, 0);
+            std::vector<std::string> msg(nb);
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nb; ++t)
+                pool.emplace_back([&, t] { st[t] = build_forest(c->tree, fphi[d0 + t], ftheta[d0 + t], fzone[d0 + t], c->box, &F[t], &msg[t]); });
+            for (auto &th : pool) th.join();
+            for (int t = 0; t < nb; ++t) {
+                if (st[t]) { free_forests(c); return fail(c, st[t], "direction " + std::to_string(d0 + t) + ": " + msg[t]); }
+                ftte_ctx::ForestDev &D = c->forests[d0 + t];
+                D.w = w[d0 + t];
+                D.depth_off = F[t].depth_off;
+                FTTE_HIP(c, hipMalloc((void **)&D.up, sizeof(int32_t) * nseg));
+                FTTE_HIP(c, hipMalloc((void **)&D.up2, sizeof(int32_t) * nseg));
+                FTTE_HIP(c, hipMalloc((void **)&D.order, sizeof(int32_t) * std::max<size_t>(F[t].order.size(), 1)));
+                FTTE_HIP(c, hipMalloc((void **)&D.dpath, sizeof(double) * nseg));
+                FTTE_HIP(c, hipMemcpy(D.up, F[t].up.data(), sizeof(int32_t) * nseg, hipMemcpyHostToDevice));
+                FTTE_HIP(c, hipMemcpy(D.up2, F[t].up2.data(), sizeof(int32_t) * nseg, hipMemcpyHostToDevice));
+                FTTE_HIP(c, hipMemcpy(D.order, F[t].order.data(), sizeof(int32_t) * F[t].order.size(), hipMemcpyHostToDevice));
+                FTTE_HIP(c, hipMemcpy(D.dpath, F[t].dpath.data(), sizeof(double) * nseg, hipMemcpyHostToDevice));
+            }
+        }
+        c->forest_key = key;
+    }
+
+    const size_t per_dir = (size_t)nseg * nnu;
+    if (c->amr_scratch_cap < per_dir * kAmrBatch) {
+        FTTE_HIP(c, hipStreamSynchronize(stream));
+        if (c->amr_Iout) { FTTE_HIP(c, hipFree(c->amr_Iout)); c->amr_Iout = nullptr; }
+        if (c->amr_mean) { FTTE_HIP(c, hipFree(c->amr_mean)); c->amr_mean = nullptr; }
+        FTTE_HIP(c, hipMalloc((void **)&c->amr_Iout, sizeof(double) * per_dir * kAmrBatch));
+        FTTE_HIP(c, hipMalloc((void **)&c->amr_mean, sizeof(double) * per_dir * kAmrBatch));
+        c->amr_scratch_cap = per_dir * kAmrBatch;
+    }
+    FTTE_HIP(c, hipStreamSynchronize(stream)); // d_uvb below may still be read by the previous sweep
+    if ((rc = ensure(c, &c->d_uvb, &c->d_uvb_cap, (size_t)nnu))) return rc;
+    FTTE_HIP(c, hipMemcpy(c->d_uvb, uvb, sizeof(double) * nnu, hipMemcpyHostToDevice));
+
+    const int nbatch = (ndir + kAmrBatch - 1) / kAmrBatch;
+    while ((int)c->timing.size() < nbatch) {
+        LaunchTiming t;
+        FTTE_HIP(c, hipEventCreate(&t.start));
+        FTTE_HIP(c, hipEventCreate(&t.stop));
+        c->timing.push_back(t);
+    }
+    c->timing_used = 0;
+    if (ndir == 0) FTTE_HIP(c, hipMemsetAsync(J_dev, 0, sizeof(double) * (size_t)nnu * ncell, stream));
+
+    static const ftte_consts kMath = FTTE_CONSTS_INIT;
+    for (int b = 0; b < nbatch; ++b) {
+        const int d0 = b * kAmrBatch, nb = std::min(kAmrBatch, ndir - d0);
+        AmrLevelRec A;
+        std::memset(&A, 0, sizeof A);
+        A.kappa = c->kappa[0];
+        A.uvb = c->d_uvb;
+        A.ncell = ncell;
+        A.ndir = nb;
+        A.nnu = nnu;
+        A.math = kMath;
+        size_t maxdepth = 0;
+        for (int t = 0; t < nb; ++t) {
+            const ftte_ctx::ForestDev &D = c->forests[d0 + t];
+            A.dir[t].up = D.up; A.dir[t].up2 = D.up2; A.dir[t].order = D.order; A.dir[t].dpath = D.dpath;
+            A.dir[t].Iout = c->amr_Iout + per_dir * t;
+            A.dir[t].mean = c->amr_mean + per_dir * t;
+            A.dir[t].w = D.w;
+            maxdepth = std::max(maxdepth, D.depth_off.size() - 1);
+        }
+        LaunchTiming &T = c->timing[b];
+        T.updates = (int64_t)nb * ncell * nnu;
+        FTTE_HIP(c, hipEventRecord(T.start, stream));
+        for (size_t depth = 0; depth < maxdepth; ++depth) {
+            int64_t total = 0;
+            for (int t = 0; t < nb; ++t) {
+                const std::vector<int64_t> &off = c->forests[d0 + t].depth_off;
+                A.first[t] = total;
+                if (depth + 1 < off.size()) { A.begin[t] = off[depth]; total += off[depth + 1] - off[depth]; }
+                else A.begin[t] = 0;
+            }
+            for (int t = nb; t <= kAmrBatch; ++t) A.first[t] = total;
+            A.total = total;
+            if (launch_amr_level(A, stream)) return fail(c, FTTE_ERR_NO_DEVICE, "forest level kernel launch failed");
+        }
+        if (launch_amr_combine(A, J_dev, b == 0, stream)) return fail(c, FTTE_ERR_NO_DEVICE, "forest combine kernel launch failed");
+        FTTE_HIP(c, hipEventRecord(T.stop, stream));
+        c->timing_used = b + 1;
+    }
+    return FTTE_OK;
+}
+
 } // namespace
 
 // =================================================================================================
@@ -344,6 +498,9 @@ int ftte_destroy(ftte_ctx *c)
     if (c->d_layers) (void)hipFree(c->d_layers);
     if (c->d_items) (void)hipFree(c->d_items);
     if (c->d_uvb) (void)hipFree(c->d_uvb);
+    free_forests(c);
+    if (c->amr_Iout) (void)hipFree(c->amr_Iout);
+    if (c->amr_mean) (void)hipFree(c->amr_mean);
     for (auto &t : c->timing) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -358,32 +515,12 @@ int ftte_set_grid(ftte_ctx *c, int nx, int ny, int nz, int64_t ncell, const int3
     if (nx < 1 || !level || ncell < 1 || !(box_cm > 0.0)) return fail(c, FTTE_ERR_ARG, "ftte_set_grid: bad argument");
     if (nx != ny || nx != nz) return fail(c, FTTE_ERR_NOT_CUBIC, "base grid needs to be of size n^3");
     if (nx > 32000) return fail(c, FTTE_ERR_UNSUPPORTED, "ftte_set_grid: n > 32000");
-    // walk the depth-first leaf list exactly as createFullyThreadedStructure does
-    // (readCellArray.f90:154-187): each base cell consumes one subtree
-    const int64_t nbase = (int64_t)nx * nx * nx;
-    int64_t cur = 0;
-    bool refined = false;
-    for (int64_t b = 0; b < nbase; ++b) {
-        // iterative subtree walk: `open[l]` children still expected at level l
-        int open[64];
-        int depth = 0;
-        open[0] = 1;
-        while (depth >= 0) {
-            if (open[depth] == 0) { --depth; continue; }
-            if (cur >= ncell) return fail(c, FTTE_ERR_LEVELS, "error in levels: level list ends inside a refined cell");
-            const int lv = level[cur];
-            if (lv == depth) { ++cur; --open[depth]; }
-            else if (lv > depth) {
-                if (depth + 1 >= 63) return fail(c, FTTE_ERR_LEVELS, "error in levels: more than 62 levels");
-                --open[depth]; open[++depth] = 8; refined = true;
-            } else return fail(c, FTTE_ERR_LEVELS, "error in levels: level list is not a depth-first leaf list");
-        }
-    }
-    if (cur != ncell) return fail(c, FTTE_ERR_LEVELS, "error in levels: level list longer than the tree it describes");
-    if (refined)
-        return fail(c, FTTE_ERR_UNSUPPORTED,
-                    "ftte_set_grid: refined cell arrays (AMR) are valid input but the device sweep of this build handles "
-                    "uniform grids only");
+    // rebuild the tree exactly as createFullyThreadedStructure does (readCellArray.f90:154-187); this also
+    // validates the list
+    AmrTree tree;
+    const std::string terr = tree.build(nx, ncell, level);
+    if (!terr.empty()) return fail(c, FTTE_ERR_LEVELS, terr);
+    if (tree.refined() && 3 * ncell >= (int64_t)1 << 31) return fail(c, FTTE_ERR_UNSUPPORTED, "refined cell array with more than 7.1e8 leaves");
     if (c->grid_set && (c->n != nx || c->ncell != ncell)) {
         // a different grid: drop everything sized by the old one
         (void)hipSetDevice(c->device);
@@ -392,12 +529,19 @@ int ftte_set_grid(ftte_ctx *c, int nx, int ny, int nz, int64_t ncell, const int3
             if (c->kappa[l]) { (void)hipFree(c->kappa[l]); c->kappa[l] = nullptr; }
             for (int s = 0; s < kMaxSlots; ++s) if (c->acc[l][s]) { (void)hipFree(c->acc[l][s]); c->acc[l][s] = nullptr; }
         }
-        c->kappa_cap = c->acc_cap = 0;
+        if (c->amr_Iout) { (void)hipFree(c->amr_Iout); c->amr_Iout = nullptr; }
+        if (c->amr_mean) { (void)hipFree(c->amr_mean); c->amr_mean = nullptr; }
+        c->kappa_cap = c->acc_cap = c->amr_scratch_cap = 0;
         c->nnu = 0;
     }
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_forests(c);
     c->n = nx; c->ncell = ncell; c->box = box_cm; c->grid_set = true;
     c->kappa_ready[0] = c->kappa_ready[1] = c->kappa_ready[2] = false;
     c->plan.valid = false;
+    c->tree = std::move(tree);
+    c->use_forest = c->tree.refined() || c->force_forest;
     return FTTE_OK;
 }
 
@@ -475,9 +619,18 @@ int ftte_set_option(ftte_ctx *c, const char *key, int value)
         if (value < 1 || value > kMaxSlots) return fail(c, FTTE_ERR_ARG, "slots must be 1..16");
         c->slots = value;
     } else if (!std::strcmp(key, "waves")) {
-        if (value != 2 && value != 3 && value != 4 && value != 5 && value != 6 && value != 8)
-            return fail(c, FTTE_ERR_ARG, "waves must be 2, 3, 4, 5, 6 or 8");
+        if (value != 2 && value != 3 && value != 4 && value != 6) return fail(c, FTTE_ERR_ARG, "waves must be 2, 3, 4 or 6");
         c->waves = value;
+    } else if (!std::strcmp(key, "forest")) {
+        if (value != 0 && value != 1) return fail(c, FTTE_ERR_ARG, "forest must be 0 or 1");
+        c->force_forest = value;
+        c->use_forest = (c->grid_set && c->tree.refined()) || value;
+    } else if (!std::strcmp(key, "ldspad")) {
+        if (value < 0 || value > 160 * 1024) return fail(c, FTTE_ERR_ARG, "ldspad must be 0..163840 bytes");
+        set_lds_pad(value);
+    } else if (!std::strcmp(key, "stack")) {
+        if (value != 1 && value != 2 && value != 4 && value != 8) return fail(c, FTTE_ERR_ARG, "stack must be 1, 2, 4 or 8");
+        c->stack = value;
     } else return fail(c, FTTE_ERR_ARG, std::string("unknown option: ") + key);
     c->plan.valid = false;
     return FTTE_OK;
@@ -495,6 +648,7 @@ int ftte_diffuse_sweep_device(ftte_ctx *c, int ndir, const double *phi, const do
     const int n = c->n, nnu = c->nnu;
     const size_t per_acc = (size_t)nnu * c->ncell;
 
+    if (c->use_forest) return forest_sweep(c, ndir, phi, theta, w, uvb, J_dev, stream);
     if ((rc = build_plan(c, ndir, phi, theta, w))) return rc;
     Plan &P = c->plan;
 
@@ -573,7 +727,11 @@ int ftte_diffuse_sweep_device(ftte_ctx *c, int ndir, const double *phi, const do
         LaunchTiming &T = c->timing[li];
         T.updates = LP.updates * nnu;
         FTTE_HIP(c, hipEventRecord(T.start, stream));
-        if (launch_sweep(L, c->rows, c->waves, nnu, stream)) return fail(c, FTTE_ERR_NO_DEVICE, "sweep kernel launch failed");
+        const int lrc = launch_sweep(L, c->rows, c->waves, c->stack, nnu, stream);
+        if (lrc == -1)
+            return fail(c, FTTE_ERR_ARG, "no sweep kernel variant for this rows/stack/waves combination (rows x stack: 4x{1,4,8}, "
+                                         "8x{1,2,4}, 16x1; waves 2, 3, 4, 6)");
+        if (lrc) return fail(c, FTTE_ERR_NO_DEVICE, "sweep kernel launch failed");
         FTTE_HIP(c, hipEventRecord(T.stop, stream));
         c->timing_used = (int)li + 1;
     }

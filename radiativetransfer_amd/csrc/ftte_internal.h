@@ -70,4 +70,25 @@ struct LaunchRec {
     ftte_consts math;   // constants of ftte_math.h, delivered through scalar registers
 };
 
+// ---- refined cell arrays (ftte_amr.h) ------------------------------------------------------------------
+constexpr int kAmrBatch = 8; // directions in flight in the forest path
+
+struct AmrDirRec {
+    const int32_t *up, *up2, *order; // device copies of AmrForest::up / up2 / order
+    const double *dpath;
+    double *Iout, *mean;             // [3 ncell][nnu] scratch of this direction's slot
+    double w;
+};
+
+struct AmrLevelRec {
+    AmrDirRec dir[kAmrBatch];
+    int64_t first[kAmrBatch + 1]; // prefix of the per-direction element counts of this depth
+    int64_t begin[kAmrBatch];     // where this depth starts in each direction's `order`
+    int64_t total;                // first[ndir]
+    const double *kappa, *uvb;
+    int64_t ncell;
+    int32_t ndir, nnu;
+    ftte_consts math;
+};
+
 } // namespace ftte

@@ -7,7 +7,9 @@
 
 namespace ftte {
 
-int launch_sweep(const LaunchRec &L, int rows, int waves, int nnu, hipStream_t stream);
+// rows x stack: 4x{1,4,8}, 8x{1,2,4}, 16x1; waves: 2, 3, 4, 6
+void set_lds_pad(int bytes); // diagnostic: dynamic LDS per workgroup, to cap residency
+int launch_sweep(const LaunchRec &L, int rows, int waves, int stack, int nnu, hipStream_t stream);
 // cell-array order -> layout 1 ([jc][ic][kc]) or 2 ([kc][ic][jc]); nnu groups, group_stride apart
 int launch_to_layout(int layout, const double *src, double *dst, int n, int nnu, long group_stride, hipStream_t stream);
 // J (cell-array order) = acc[0] + acc[1] + ... in list order; layout[a] in {0,1,2}
@@ -15,5 +17,9 @@ int launch_merge(const double *const *acc, const int *layout, int count, double 
                  hipStream_t stream);
 int launch_opacity(const double *HI, const double *HeI, const double *HeII, const double *beta, double *kappa, long ncell,
                    int nnu, hipStream_t stream);
+
+// refined cell arrays: one depth of the segment forest of up to kAmrBatch directions; then the per-leaf means into J
+int launch_amr_level(const AmrLevelRec &A, hipStream_t stream);
+int launch_amr_combine(const AmrLevelRec &A, double *J, bool zero_first, hipStream_t stream);
 
 } // namespace ftte

@@ -79,17 +79,24 @@ __device__ __forceinline__ double segment(const ftte_consts &K, double &I, doubl
 //                     kappa / J plane; rows are sv elements apart; a lane's column enters as a
 //                     non-negative position (mirrored columns are folded into the position by the
 //                     caller) so that every access is  uniform 64-bit base + 32-bit lane offset.
-template <int ROWS, int RC, bool EDGE>
+//   STACK           : wavefronts of the workgroup stacked along v.  The cell of row 0 needs the 2nd/3rd
+//                     segments of the row below, which belongs to the wavefront below: with STACK = 1 row 0
+//                     is a read-only halo (the tile below recomputes it); with STACK > 1 only the lowest
+//                     wavefront has a halo row, the others receive the two numbers per lane they need
+//                     through LDS (`xchg`, one s_barrier per layer that has such segments) and own row 0.
+template <int ROWS, int RC, bool EDGE, int STACK>
 __device__ __forceinline__ void layer_step(const ftte_consts &K, double (&I)[ROWS], const char *__restrict__ kplane,
-                                           char *__restrict__ jplane,
-                                           int cv0, int cu, int n, int sv, bool mirror_u, double d0, double d1, double d2,
-                                           double w, double uvb, bool first, bool lane_owned)
+                                           char *__restrict__ jplane, int cv0, int cu, int n, int sv, bool mirror_u,
+                                           double d0, double d1, double d2, double w, double uvb, bool first,
+                                           bool lane_owned, int lane, int wid, double *xchg)
 {
     constexpr int SHAPE = (RC == RC_THREE_U_SWAP) ? RC_THREE_U : (RC == RC_THREE_V_SWAP) ? RC_THREE_V : RC;
     constexpr bool THIRD_FIRST = (RC == RC_THREE_U_SWAP || RC == RC_THREE_V_SWAP);
     constexpr bool HAS_U = (SHAPE == RC_TWO_U || SHAPE == RC_THREE_U || SHAPE == RC_THREE_V); // touches column u+1
     constexpr bool HAS_V = (SHAPE == RC_TWO_V || SHAPE == RC_THREE_U || SHAPE == RC_THREE_V); // touches row v+1
     constexpr int NSEG = (SHAPE == RC_ONE) ? 1 : (SHAPE <= RC_TWO_V ? 2 : 3);
+    const bool row0_owned = STACK > 1 && wid > 0; // wave-uniform
+    constexpr int R0 = (STACK > 1) ? 0 : 1;       // first row that may be owned
 
     // lane-varying column positions, clamped into the domain for EDGE tiles
     const int c0 = EDGE ? clampi(cu, 1, n) : cu;
@@ -113,17 +120,19 @@ __device__ __forceinline__ void layer_step(const ftte_consts &K, double (&I)[ROW
     }
     const bool own_lane = lane_owned && in_u0;
 #pragma unroll
-    for (int r = 1; r < ROWS; ++r) Jacc[r] = 0.0;
+    for (int r = R0; r < ROWS; ++r) Jacc[r] = 0.0;
     if (!first && own_lane) {
 #pragma unroll
-        for (int r = 1; r < ROWS; ++r) {
+        for (int r = R0; r < ROWS; ++r) {
             const int row = cv0 + r;
-            if (!EDGE || (row >= 1 && row <= n)) Jacc[r] = *reinterpret_cast<const double *>(jplane + row * row_bytes + off0);
+            if ((r > 0 || row0_owned) && (!EDGE || (row >= 1 && row <= n)))
+                Jacc[r] = *reinterpret_cast<const double *>(jplane + row * row_bytes + off0);
         }
     }
 
     // ---- march the rays of this lane through the layer, row by row -----------------------------
     double prev1 = 0.0, prev2 = 0.0; // 2nd / 3rd segment means of the previous row (for HAS_V gathers)
+    double own0 = 0.0, side0 = 0.0;  // row 0: its own xy mean, and what lane-1 of the same row gives it
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         const int row = cv0 + r;
@@ -162,6 +171,9 @@ __device__ __forceinline__ void layer_step(const ftte_consts &K, double (&I)[ROW
             // computed here, for every lane: otherwise the whole mean (selects, products) is sunk into the
             // lane-predicated store block after the last row, with every row's operands kept alive until then
             asm volatile("" : "+v"(Jacc[r]));
+        } else if (STACK > 1) {
+            own0 = m0;
+            if (SHAPE == RC_TWO_U || SHAPE == RC_THREE_U) side0 = from_lane_below(m1);
         }
         if (HAS_V) { prev1 = m1; prev2 = m2; }
         // keep the rows in program order: their arithmetic is independent, and left alone the scheduler
@@ -169,24 +181,54 @@ __device__ __forceinline__ void layer_step(const ftte_consts &K, double (&I)[ROW
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    if (STACK > 1) {
+        // row 0 of every wavefront but the lowest: the row below lives in the wavefront below
+        double below1 = 0.0, below2 = 0.0;
+        if (HAS_V) {
+            double *mine = xchg + (wid * 2) * 64;
+            mine[lane] = prev1;      // my top row's 2nd-segment mean
+            mine[64 + lane] = prev2; // and 3rd
+            __syncthreads();
+            if (row0_owned) {
+                const double *theirs = xchg + ((wid - 1) * 2) * 64;
+                below1 = theirs[lane];
+                below2 = theirs[64 + (lane > 0 ? lane - 1 : 0)]; // the 3rd segment comes from one lane lower as well
+            }
+        }
+        double g1 = 0.0, g2 = 0.0;
+        if (SHAPE == RC_TWO_U) g1 = side0;
+        if (SHAPE == RC_TWO_V) g1 = below1;
+        if (SHAPE == RC_THREE_U) { g1 = side0; g2 = below2; }
+        if (SHAPE == RC_THREE_V) { g1 = below1; g2 = below2; }
+        double acc = own0;
+        if (NSEG == 2) acc += g1;
+        if (NSEG == 3) {
+            acc += THIRD_FIRST ? g2 : g1;
+            acc += THIRD_FIRST ? g1 : g2;
+        }
+        Jacc[0] += ftte_cell_mean(acc, NSEG, w);
+    }
+
     if (own_lane) {
 #pragma unroll
-        for (int r = 1; r < ROWS; ++r) {
+        for (int r = R0; r < ROWS; ++r) {
             const int row = cv0 + r;
-            if (!EDGE || (row >= 1 && row <= n)) *reinterpret_cast<double *>(jplane + row * row_bytes + off0) = Jacc[r];
+            if ((r > 0 || row0_owned) && (!EDGE || (row >= 1 && row <= n)))
+                *reinterpret_cast<double *>(jplane + row * row_bytes + off0) = Jacc[r];
         }
     }
 }
 
-template <int ROWS, bool EDGE>
+template <int ROWS, bool EDGE, int STACK>
 __device__ __forceinline__ void layer_dispatch(const ftte_consts &K, double (&I)[ROWS], int rc, const char *kplane,
-                                               char *jplane, int cv0, int cu,
-                                               int n, int sv, bool mirror_u, double d0, double d1, double d2, double w,
-                                               double uvb, bool first, bool lane_owned)
+                                               char *jplane, int cv0, int cu, int n, int sv, bool mirror_u, double d0,
+                                               double d1, double d2, double w, double uvb, bool first, bool lane_owned,
+                                               int lane, int wid, double *xchg)
 {
-#define FTTE_CASE(C)                                                                                                   \
-    case C:                                                                                                            \
-        layer_step<ROWS, C, EDGE>(K, I, kplane, jplane, cv0, cu, n, sv, mirror_u, d0, d1, d2, w, uvb, first, lane_owned); \
+#define FTTE_CASE(C)                                                                                                     \
+    case C:                                                                                                              \
+        layer_step<ROWS, C, EDGE, STACK>(K, I, kplane, jplane, cv0, cu, n, sv, mirror_u, d0, d1, d2, w, uvb, first,     \
+                                         lane_owned, lane, wid, xchg);                                                   \
         break;
     switch (rc) {
         FTTE_CASE(RC_ONE)
@@ -196,26 +238,28 @@ __device__ __forceinline__ void layer_dispatch(const ftte_consts &K, double (&I)
         FTTE_CASE(RC_THREE_V)
         FTTE_CASE(RC_THREE_U_SWAP)
     default:
-        layer_step<ROWS, RC_THREE_V_SWAP, EDGE>(K, I, kplane, jplane, cv0, cu, n, sv, mirror_u, d0, d1, d2, w, uvb, first,
-                                                lane_owned);
+        layer_step<ROWS, RC_THREE_V_SWAP, EDGE, STACK>(K, I, kplane, jplane, cv0, cu, n, sv, mirror_u, d0, d1, d2, w, uvb,
+                                                       first, lane_owned, lane, wid, xchg);
         break;
     }
 #undef FTTE_CASE
 }
 
-// grid: nitems * nnu workgroups of one wavefront; the frequency group is the fastest index, so that
-// (for nnu = 8) all tiles of one group run on one XCD and share its L2: neighbouring tiles re-read each
-// other's halo rows and the partial 128-byte lines at their edges.
-template <int ROWS, int WAVES>
-__global__ void __launch_bounds__(64, WAVES) sweep_kernel(const LaunchRec L)
+// grid: nitems * nnu workgroups of STACK wavefronts; the frequency group is the fastest index, so that
+// (for nnu = 8) all tiles of one group run on one XCD.
+template <int ROWS, int WAVES, int STACK>
+__global__ void __launch_bounds__(64 * STACK, WAVES) sweep_kernel(const LaunchRec L)
 {
+    __shared__ double xchg_lds[STACK > 1 ? 2 * STACK * 2 * 64 : 1]; // [parity][wavefront][2nd|3rd][lane]
+    extern __shared__ double occupancy_pad[];                        // diagnostic: dynamic LDS only limits residency
     const int nnu = L.nnu;
     const int nu = blockIdx.x % nnu;
     const WorkItem *ip = L.items + blockIdx.x / nnu;
     const int slot = uniform((int)ip->slot), tu = uniform((int)ip->tu), tv = uniform((int)ip->tv);
     const int i_first = uniform((int)ip->i_first), i_last = uniform((int)ip->i_last);
     const DirRec &D = L.dir[slot];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wid = STACK > 1 ? uniform((int)(threadIdx.x >> 6)) : 0;
     const int n = L.n;
 
     const double uvb = uniform(L.uvb[nu]);
@@ -228,9 +272,10 @@ __global__ void __launch_bounds__(64, WAVES) sweep_kernel(const LaunchRec L)
     char *jbase = reinterpret_cast<char *>(uniform(D.J) + (long)nu * L.group_stride + org);
     const int u_lo = uniform(D.u_lo), v_lo = uniform(D.v_lo);
 
-    // labels of this lane's rays: u label of the lane, v label of its row 0 (both halo for index 0)
+    // labels of this lane's rays: u label of the lane (lane 0: halo), v label of this wavefront's row 0
+    // (row 0 of wavefront 0: halo)
     const int ul = u_lo + 63 * tu + lane - 1;
-    const int vl0 = v_lo + (ROWS - 1) * tv - 1;
+    const int vl0 = v_lo + (STACK * ROWS - 1) * tv - 1 + wid * ROWS;
     const bool lane_owned = lane != 0;
 
     double I[ROWS];
@@ -238,6 +283,7 @@ __global__ void __launch_bounds__(64, WAVES) sweep_kernel(const LaunchRec L)
     for (int r = 0; r < ROWS; ++r) I[r] = uvb;
 
     const LayerRec *layers = uniform(D.layers);
+    int parity = 0;
     for (int i = i_first; i <= i_last; ++i) {
         const LayerRec *rp = layers + (i - 1);
         const double d0 = uniform(rp->dpath[0]), d1 = uniform(rp->dpath[1]), d2 = uniform(rp->dpath[2]);
@@ -248,45 +294,61 @@ __global__ void __launch_bounds__(64, WAVES) sweep_kernel(const LaunchRec L)
         const int cv0 = vl0 + dv;
         const char *kplane = kbase + 8l * i * si;
         char *jplane = jbase + 8l * i * si;
+        double *xchg = xchg_lds + parity * (STACK * 2 * 64);
+        const bool has_v = rc != RC_ONE && rc != RC_TWO_U; // this layer passes segments from row to row
 
-        // interior test (wave-uniform): every cell any lane of the tile may touch, halo and +1
-        // offsets included, lies inside the domain
+        // wave-uniform position tests on every cell any lane of this wavefront may touch (halo and +1 offsets included)
         const int u_min = u_lo + 63 * tu - 1 + du, v_min = cv0;
         const bool interior = u_min >= 1 && u_min + 64 <= n && v_min >= 1 && v_min + ROWS <= n;
-        if (interior)
-            layer_dispatch<ROWS, false>(L.math, I, rc, kplane, jplane, cv0, cu, n, sv, mirror_u, d0, d1, d2, w, uvb, first, lane_owned);
+        const bool outside = STACK > 1 && (u_min > n || u_min + 64 < 1 || v_min > n || v_min + ROWS < 1);
+        if (outside) {
+            // nothing of this wavefront is in the domain at this layer: its rays keep (or, having left, no longer need)
+            // the inflow value; it only has to keep the workgroup's exchange protocol going
+            if (has_v) {
+                xchg[(wid * 2) * 64 + lane] = 0.0;
+                xchg[(wid * 2 + 1) * 64 + lane] = 0.0;
+                __syncthreads();
+            }
+        } else if (interior)
+            layer_dispatch<ROWS, false, STACK>(L.math, I, rc, kplane, jplane, cv0, cu, n, sv, mirror_u, d0, d1, d2, w, uvb,
+                                               first, lane_owned, lane, wid, xchg);
         else
-            layer_dispatch<ROWS, true>(L.math, I, rc, kplane, jplane, cv0, cu, n, sv, mirror_u, d0, d1, d2, w, uvb, first, lane_owned);
+            layer_dispatch<ROWS, true, STACK>(L.math, I, rc, kplane, jplane, cv0, cu, n, sv, mirror_u, d0, d1, d2, w, uvb,
+                                              first, lane_owned, lane, wid, xchg);
+        if (STACK > 1 && has_v) parity ^= 1;
     }
 }
 
 // WAVES = waves per SIMD the register allocation is held to (512 / WAVES VGPRs per lane)
-template <int ROWS>
-static int launch_rows(const LaunchRec &L, int waves, dim3 grid, dim3 block, hipStream_t stream)
+static int g_lds_pad = 0; // bytes of dynamic LDS per workgroup (diagnostic knob "ldspad")
+void set_lds_pad(int bytes) { g_lds_pad = bytes; }
+
+template <int ROWS, int STACK>
+static int launch_variant(const LaunchRec &L, int waves, dim3 grid, hipStream_t stream)
 {
+    const dim3 block(64 * STACK);
     switch (waves) {
-    case 2: hipLaunchKernelGGL((sweep_kernel<ROWS, 2>), grid, block, 0, stream, L); break;
-    case 3: hipLaunchKernelGGL((sweep_kernel<ROWS, 3>), grid, block, 0, stream, L); break;
-    case 4: hipLaunchKernelGGL((sweep_kernel<ROWS, 4>), grid, block, 0, stream, L); break;
-    case 5: hipLaunchKernelGGL((sweep_kernel<ROWS, 5>), grid, block, 0, stream, L); break;
-    case 6: hipLaunchKernelGGL((sweep_kernel<ROWS, 6>), grid, block, 0, stream, L); break;
-    case 8: hipLaunchKernelGGL((sweep_kernel<ROWS, 8>), grid, block, 0, stream, L); break;
+    case 2: hipLaunchKernelGGL((sweep_kernel<ROWS, 2, STACK>), grid, block, g_lds_pad, stream, L); break;
+    case 3: hipLaunchKernelGGL((sweep_kernel<ROWS, 3, STACK>), grid, block, g_lds_pad, stream, L); break;
+    case 4: hipLaunchKernelGGL((sweep_kernel<ROWS, 4, STACK>), grid, block, g_lds_pad, stream, L); break;
+    case 6: hipLaunchKernelGGL((sweep_kernel<ROWS, 6, STACK>), grid, block, g_lds_pad, stream, L); break;
     default: return -1;
     }
     return 0;
 }
 
-int launch_sweep(const LaunchRec &L, int rows, int waves, int nnu, hipStream_t stream)
+int launch_sweep(const LaunchRec &L, int rows, int waves, int stack, int nnu, hipStream_t stream)
 {
     if (L.nitems <= 0 || nnu != L.nnu) return L.nitems <= 0 ? 0 : -1;
-    const dim3 grid((unsigned)L.nitems * (unsigned)nnu), block(64);
-    int rc;
-    switch (rows) {
-    case 4: rc = launch_rows<4>(L, waves, grid, block, stream); break;
-    case 8: rc = launch_rows<8>(L, waves, grid, block, stream); break;
-    case 16: rc = launch_rows<16>(L, waves, grid, block, stream); break;
-    default: return -1;
-    }
+    const dim3 grid((unsigned)L.nitems * (unsigned)nnu);
+    int rc = -1;
+    if (rows == 4 && stack == 1) rc = launch_variant<4, 1>(L, waves, grid, stream);
+    else if (rows == 4 && stack == 4) rc = launch_variant<4, 4>(L, waves, grid, stream);
+    else if (rows == 4 && stack == 8) rc = launch_variant<4, 8>(L, waves, grid, stream);
+    else if (rows == 8 && stack == 1) rc = launch_variant<8, 1>(L, waves, grid, stream);
+    else if (rows == 8 && stack == 2) rc = launch_variant<8, 2>(L, waves, grid, stream);
+    else if (rows == 8 && stack == 4) rc = launch_variant<8, 4>(L, waves, grid, stream);
+    else if (rows == 16 && stack == 1) rc = launch_variant<16, 1>(L, waves, grid, stream);
     if (rc) return rc;
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -393,6 +455,76 @@ int launch_merge(const double *const *acc, const int *layout, int count, double 
     for (int a = 0; a < count; ++a) { M.acc[a] = acc[a]; M.layout[a] = layout[a]; }
     const dim3 grid((n + 31) / 32, (n + 31) / 32, n * nnu);
     hipLaunchKernelGGL(merge_kernel, grid, dim3(256), 0, stream, M, J, n, group_stride);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Refined cell arrays.  The host planner (ftte_amr.cpp) has turned the reference's per-direction
+// neighbour links into a forest over segments, ordered by depth; one launch processes one depth of
+// up to kAmrBatch directions: a thread per (segment, frequency group) takes the intensity its upstream
+// segment left (or the inflow, or the mean of two segments: transportRoutinesModule.f90:594-649),
+// crosses its own segment (ftte_math.h), and stores the outgoing intensity and the segment's mean.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) amr_level_kernel(const AmrLevelRec A)
+{
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nnu = A.nnu;
+    const long e = tid / nnu;
+    const int nu = (int)(tid - e * nnu);
+    if (e >= A.total) return;
+    int d = 0;
+    while (d + 1 < A.ndir && e >= A.first[d + 1]) ++d;
+    const AmrDirRec &D = A.dir[d];
+    const int seg = D.order[A.begin[d] + (e - A.first[d])];
+    const int up = D.up[seg], up2 = D.up2[seg];
+    double *Io = D.Iout + (long)seg * nnu;
+    double I;
+    if (up < 0) I = A.uvb[nu];
+    else {
+        I = D.Iout[(long)up * nnu + nu];
+        if (up2 >= 0) I = 0.5 * (I + D.Iout[(long)up2 * nnu + nu]);
+    }
+    const int cell = seg / 3;
+    const double kap = A.kappa[(long)nu * A.ncell + cell];
+    const double m = ftte_segment(&A.math, &I, kap * D.dpath[seg]);
+    Io[nu] = I;
+    D.mean[(long)seg * nnu + nu] = m;
+}
+
+// J[g][leaf] += (w / nseg) * (mean_xy + mean_xz + mean_yz), one direction after the other in list order
+// (transportRoutinesModule.f90:953-955)
+__global__ void __launch_bounds__(256) amr_combine_kernel(const AmrLevelRec A, double *__restrict__ J, int zero_first)
+{
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nnu = A.nnu;
+    const long cell = tid / nnu;
+    const int nu = (int)(tid - cell * nnu);
+    if (cell >= A.ncell) return;
+    double acc_J = zero_first ? 0.0 : J[(long)nu * A.ncell + cell];
+    for (int d = 0; d < A.ndir; ++d) {
+        const AmrDirRec &D = A.dir[d];
+        double acc = D.mean[(3 * cell) * nnu + nu];
+        int nseg = 1;
+        if (D.up[3 * cell + 1] != -2) { acc += D.mean[(3 * cell + 1) * nnu + nu]; ++nseg; }
+        if (D.up[3 * cell + 2] != -2) { acc += D.mean[(3 * cell + 2) * nnu + nu]; ++nseg; }
+        acc_J += ftte_cell_mean(acc, nseg, D.w);
+    }
+    J[(long)nu * A.ncell + cell] = acc_J;
+}
+
+int launch_amr_level(const AmrLevelRec &A, hipStream_t stream)
+{
+    if (A.total <= 0) return 0;
+    const long threads = A.total * A.nnu;
+    hipLaunchKernelGGL(amr_level_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, A);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_amr_combine(const AmrLevelRec &A, double *J, bool zero_first, hipStream_t stream)
+{
+    const long threads = A.ncell * A.nnu;
+    hipLaunchKernelGGL(amr_combine_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, A, J,
+                       zero_first ? 1 : 0);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -1,0 +1,76 @@
+"""The product's refined-grid planner (csrc/ftte_amr.cpp: tree rebuild, sub-layer patterns, upstream links,
+depth order) on the CPU: tests/host/forest_check.cpp evaluates the forest it builds with the device arithmetic,
+serially, exactly as the two device kernels do, and must reproduce the oracle's tree sweep bit for bit."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from radiativetransfer_amd import synthetic
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "radiativetransfer_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def forest_check(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("host") / "forest_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-mfma", "-o", exe,
+                           os.path.join(ROOT, "tests", "host", "forest_check.cpp"),
+                           os.path.join(CSRC, "ftte_amr.cpp"), os.path.join(CSRC, "ftte_geometry.cpp")])
+
+    def run(n, level, kappa, box, uvb, phi, theta, w, tmp):
+        case, out = os.path.join(tmp, "case.bin"), os.path.join(tmp, "out.bin")
+        with open(case, "wb") as f:
+            f.write(struct.pack("<4i", n, len(level), len(phi), kappa.shape[0]))
+            f.write(struct.pack("<d", box))
+            f.write(np.asarray(uvb, "<f8").tobytes())
+            f.write(np.asarray(level, "<i4").tobytes())
+            f.write(np.ascontiguousarray(kappa, "<f8").tobytes())
+            for a in (phi, theta, w):
+                f.write(np.asarray(a, "<f8").tobytes())
+        r = subprocess.run([exe, case, out], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        return np.fromfile(out, "<f8").reshape(kappa.shape)
+    return run
+
+
+@pytest.mark.parametrize("name", ["amr8_block_level1", "amr6_scattered_level2", "uniform16_lognormal_24zones"])
+def test_planner_on_goldens(forest_check, golden, tmp_path, name):
+    g = golden(name)
+    n = int(g["n"])
+    args = (g["kappa"], float(g["box"]), g["phi"], g["theta"], g["w"], g["uvb"])
+    J = forest_check(n, g["level"], g["kappa"], float(g["box"]), g["uvb"], g["phi"], g["theta"], g["w"], str(tmp_path))
+    ref = O.sweep_tree(n, g["level"], *args, arith=O.ARITH_DEVICE)
+    assert np.array_equal(J, ref)
+    # and therefore within the reference tolerance of the reference's own output
+    _, noise = O.sweep_tree(n, g["level"], *args, with_noise=True)
+    assert np.all(np.abs(J - g["J"]) <= 8 * noise + 12 * n * 4 * np.finfo(float).eps * np.abs(g["J"]))
+
+
+def test_planner_on_a_deep_ragged_tree(forest_check, tmp_path):
+    """Three levels, refinement touching the domain boundary and neighbouring refined cells of different depth."""
+    n = 5
+    rng = np.random.default_rng(17)
+    # hand-built ragged tree: depth-first list with nested refinement
+    def cell(depth, p):
+        if depth < 3 and rng.random() < p:
+            out = []
+            for _ in range(8):
+                out += cell(depth + 1, p * 0.6)
+            return out
+        return [depth]
+    level = []
+    for b in range(n ** 3):
+        level += cell(0, 0.25 if b % 7 else 0.9)
+    level = np.array(level, np.int32)
+    assert level.max() == 3
+    kappa = rng.lognormal(0, 1, (2, len(level))) * n * 0.4 * (2.0 ** level)[None, :]
+    phi, theta, w = O.healpix_directions(2)
+    uvb = np.array([1e-21, 4e-22])
+    J = forest_check(n, level, kappa, 1.0, uvb, phi, theta, w, str(tmp_path))
+    ref = O.sweep_tree(n, level, kappa, 1.0, phi, theta, w, uvb, arith=O.ARITH_DEVICE)
+    assert np.array_equal(J, ref)

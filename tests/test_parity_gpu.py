@@ -207,9 +207,8 @@ def test_call_order_and_refusals(engine):
         with pytest.raises(rt.FtteError) as err:
             e.set_grid(2, np.array([0, 0, 0, 1, 0, 0, 0, 0], np.int32), 1.0)  # a lone level-1 leaf list that runs out
         assert err.value.status == "FTTE_ERR_LEVELS"
-        with pytest.raises(rt.FtteError) as err:
-            e.set_grid(2, synthetic.refine_levels(2, [(0, 0, 0)]), 1.0)  # valid AMR: refused, not mis-computed
-        assert err.value.status == "FTTE_ERR_UNSUPPORTED"
+        e.set_grid(2, synthetic.refine_levels(2, [(0, 0, 0)]), 1.0)  # a refined cell array is accepted
+        assert e.ncell == 15
         e.set_uniform_grid(4, 1.0)
         with pytest.raises(rt.FtteError) as err:
             e.transport([0.3], [0.4], [1.0], [1e-21])
@@ -221,6 +220,89 @@ def test_call_order_and_refusals(engine):
         with pytest.raises(rt.FtteError) as err:
             e.set_emissivity(np.ones((1, 64)))
         assert err.value.status == "FTTE_ERR_UNSUPPORTED"
+
+
+# ---- refined cell arrays (setRaysRefined / findNeighbours / transport with the coarse-neighbour rule) -----------------
+
+@pytest.mark.parametrize("name", ["amr8_block_level1", "amr6_scattered_level2"])
+def test_refined_goldens(engine, golden, name):
+    """The reference's own outputs on refined cell arrays; and the oracle's tree sweep with the device arithmetic
+    bit for bit (the forest path adds directions in list order, like the reference)."""
+    g = golden(name)
+    n = int(g["n"])
+    args = (g["kappa"], float(g["box"]), g["phi"], g["theta"], g["w"], g["uvb"])
+    engine.set_grid(n, g["level"], float(g["box"]))
+    engine.set_opacity(g["kappa"])
+    J = engine.transport(g["phi"], g["theta"], g["w"], g["uvb"])
+    assert np.array_equal(J, O.sweep_tree(n, g["level"], *args, arith=O.ARITH_DEVICE))
+    _, noise = O.sweep_tree(n, g["level"], *args, with_noise=True)
+    assert np.all(np.abs(J - g["J"]) <= reference_bound(4 * n, g["J"], noise))
+
+
+def test_refined_ragged_tree(engine):
+    n = 5
+    rng = np.random.default_rng(17)
+
+    def cell(depth, p):
+        if depth < 3 and rng.random() < p:
+            out = []
+            for _ in range(8):
+                out += cell(depth + 1, p * 0.6)
+            return out
+        return [depth]
+    level = []
+    for b in range(n ** 3):
+        level += cell(0, 0.25 if b % 7 else 0.9)
+    level = np.array(level, np.int32)
+    kappa = rng.lognormal(0, 1, (3, len(level))) * n * 0.4 * (2.0 ** level)[None, :]
+    phi, theta, w = O.healpix_directions(2)
+    uvb = np.array([1e-21, 4e-22, 1e-22])
+    engine.set_grid(n, level, 1.0)
+    engine.set_opacity(kappa)
+    J = engine.transport(phi, theta, w, uvb)
+    assert np.array_equal(J, O.sweep_tree(n, level, kappa, 1.0, phi, theta, w, uvb, arith=O.ARITH_DEVICE))
+    assert J.shape == (3, len(level))
+    J0 = engine.transport(phi[:0], theta[:0], w[:0], uvb)
+    assert not J0.any()
+
+
+def test_forest_path_on_a_uniform_grid_equals_the_tiled_kernel(engine):
+    n = 18
+    kappa, uvb, box = synthetic.uniform_workload(n, 2, seed=3, tau_median=0.4)
+    phi, theta, w = O.healpix_directions(2)
+    engine.set_uniform_grid(n, box)
+    engine.set_opacity(kappa)
+    J_tiled = engine.transport(phi, theta, w, uvb)
+    engine.set_option("forest", 1)
+    engine.set_uniform_grid(n, box)
+    engine.set_opacity(kappa)
+    J_forest = engine.transport(phi, theta, w, uvb)
+    engine.set_option("forest", 0)
+    engine.set_uniform_grid(n, box)
+    assert np.array_equal(J_forest, O.sweep_uniform(n, kappa, box, phi, theta, w, uvb, arith=O.ARITH_DEVICE))
+    assert np.allclose(J_tiled, J_forest, rtol=SUM_RTOL, atol=0)
+
+
+def test_nested_patch_like_config4(engine):
+    """BASELINE configs[3] in small: a cubic base grid whose central block is refined once (here 24^3 with the central
+    8^3 block), 8 frequency groups; two directions against the oracle bit for bit, the whole 48-direction set for
+    sanity (0 < J <= inflow)."""
+    n = 24
+    blocks = [(8 + a, 8 + b, 8 + c) for a in range(8) for b in range(8) for c in range(8)]
+    level = synthetic.refine_levels(n, blocks, depth=1)
+    assert len(level) == n ** 3 - 512 + 4096
+    rho = synthetic.lognormal_density(len(level), seed=40)
+    _, s_nu, uvb = synthetic.frequency_groups(8)
+    kappa = (0.2 * n) * s_nu[:, None] * rho[None, :]
+    phi, theta, w = O.healpix_directions(2)
+    engine.set_grid(n, level, 1.0)
+    engine.set_opacity(kappa)
+    J = engine.transport(phi, theta, w, uvb)
+    assert np.all(J > 0) and np.all(J <= uvb[:, None] * (1 + 1e-12))
+    sel = [0, 7]
+    J2 = engine.transport(phi[[5, 29]], theta[[5, 29]], w[[5, 29]], uvb)
+    ref = O.sweep_tree(n, level, kappa[sel], 1.0, phi[[5, 29]], theta[[5, 29]], w[[5, 29]], uvb[sel], arith=O.ARITH_DEVICE)
+    assert np.array_equal(J2[sel], ref)
 
 
 # ---- BASELINE size: properties that need no oracle run ------------------------------------------------------------

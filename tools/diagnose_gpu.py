@@ -32,8 +32,9 @@ def main():
         kappa, uvb, box = synthetic.uniform_workload(n, 2, seed=n, tau_median=0.3)
         eng.set_uniform_grid(n, box)
         eng.set_opacity(kappa)
-        for rows in (4, 8, 16):
+        for rows, stack in ((4, 1), (8, 1), (16, 1), (8, 4), (8, 2), (4, 8), (4, 4)):
             eng.set_option("rows", rows)
+            eng.set_option("stack", stack)
             for z in range(1, 25):
                 p, t = pick[z]
                 phi, theta, w = np.array([p]), np.array([t]), np.array([0.37])
@@ -46,12 +47,13 @@ def main():
                     bad = np.argwhere(J != ref)
                     cells = bad[:4].tolist()
                     idx = [np.unravel_index(c[1], (n, n, n)) for c in cells]
-                    print(f"n={n} rows={rows} izone={z:2d} MISMATCH count={len(bad)}/{J.size} maxrel={diff.max():.3e} "
+                    print(f"n={n} rows={rows} stack={stack} izone={z:2d} MISMATCH count={len(bad)}/{J.size} maxrel={diff.max():.3e} "
                           f"first={[(int(a), int(b), int(c)) for a, b, c in idx]} nan={np.isnan(J).sum()}")
                 else:
-                    print(f"n={n} rows={rows} izone={z:2d} bitwise ok")
+                    print(f"n={n} rows={rows} stack={stack} izone={z:2d} bitwise ok")
         # all 24 at once (three layouts, slots, merge)
         eng.set_option("rows", 8)
+        eng.set_option("stack", 4)
         for slots in (1, 4):
             eng.set_option("slots", slots)
             ps = np.array([pick[z][0] for z in range(1, 25)]); ts = np.array([pick[z][1] for z in range(1, 25)])

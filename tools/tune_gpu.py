@@ -18,10 +18,10 @@ def main():
     n, nnu, ndir = 256, 8, 96
     combos = []
     for arg in sys.argv[1:]:
-        r, w, s = (int(x) for x in arg.split(","))
-        combos.append((r, w, s))
+        f = [int(x) for x in arg.split(",")]
+        combos.append(tuple(f + [1] * (4 - len(f))) if len(f) < 5 else tuple(f))
     if not combos:
-        combos = [(8, 4, 4), (8, 5, 4), (8, 3, 4), (4, 6, 4), (4, 8, 4), (16, 3, 4), (16, 2, 4), (8, 4, 8)]
+        combos = [(8, 4, 6, 1), (8, 4, 6, 4), (8, 4, 6, 2), (4, 6, 6, 8), (4, 6, 6, 4), (4, 4, 6, 8)]
     kappa_host, uvb, box = synthetic.uniform_workload(n, nnu, seed=12345, tau_median=0.1)
     dev = torch.device("cuda", 0)
     kappa = torch.from_numpy(kappa_host).to(dev)
@@ -32,8 +32,11 @@ def main():
     eng.set_uniform_grid(n, box)
     stream = torch.cuda.current_stream().cuda_stream
     ref = None
-    for rows, waves, slots in combos:
+    for combo in combos:
+        rows, waves, slots, stack = combo[:4]
+        eng.set_option("ldspad", combo[4] if len(combo) > 4 else 0)
         eng.set_option("rows", rows); eng.set_option("waves", waves); eng.set_option("slots", slots)
+        eng.set_option("stack", stack)
         def step():
             eng.set_opacity_device(nnu, kappa.data_ptr())
             eng.transport_device(phi, theta, w, uvb, J.data_ptr(), stream)
@@ -49,7 +52,7 @@ def main():
         chk = float(J.sum().item())
         if ref is None:
             ref = chk
-        print(f"rows={rows:2d} waves={waves} slots={slots}: {dt * 1e3:7.2f} ms/step  {upd / dt:.3e} upd/s  "
+        print(f"rows={rows:2d} stack={stack} waves={waves} slots={slots} ldspad={combo[4] if len(combo) > 4 else 0}: {dt * 1e3:7.2f} ms/step  {upd / dt:.3e} upd/s  "
               f"sweep kernels {kms / reps:7.2f} ms -> {upd * 24 / (kms / reps * 1e-3) / 1e9:6.0f} GB/s algorithmic "
               f"({upd * 24 / (kms / reps * 1e-3) / 8e12:.3f} of 8 TB/s)  checksum rel {abs(chk / ref - 1):.1e}", flush=True)
 
