@@ -71,7 +71,7 @@ struct LaunchRec {
 };
 
 // ---- refined cell arrays (ftte_amr.h) ------------------------------------------------------------------
-constexpr int kAmrBatch = 8; // directions in flight in the forest path
+constexpr int kAmrBatch = 32; // directions in flight in the forest path
 
 struct AmrDirRec {
     const int32_t *up, *up2, *order; // device copies of AmrForest::up / up2 / order
