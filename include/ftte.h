@@ -83,10 +83,17 @@ int ftte_set_opacity_device(ftte_ctx *ctx, int nnu, const double *kappa_dev);
  * HeI = beta26, HeII = beta25 of the reference's group tables). */
 int ftte_set_species(ftte_ctx *ctx, int nnu, const double *HI, const double *HeI, const double *HeII,
                      const double *beta);
-/* Emissivity eta[nnu][ncell]; NULL selects the reference's hard-wired zero emissivity
- * (transportRoutinesModule.f90:673-675).  A non-NULL eta is refused with
- * FTTE_ERR_UNSUPPORTED by this build. */
+/* Emissivity eta[nnu][ncell] (call after the opacities are set; sized by their nnu).  NULL selects the reference's
+ * hard-wired zero emissivity (transportRoutinesModule.f90:673-675).  Non-NULL switches the sweep to the reference's
+ * emission term as written at :676,   Iout = Iin*tmpabs + nemi*tmpemi/dpath   with tmpemi = (1-tmpabs)/kappa
+ * (dpath below tau = 1e-10), and to its log-mean (:1044-1048) for the cell intensity.  Replaces any source function. */
 int ftte_set_emissivity(ftte_ctx *ctx, const double *eta);
+int ftte_set_emissivity_device(ftte_ctx *ctx, const double *eta_dev);
+/* Source function S[nnu][ncell]: NOT in the reference (whose emission term is never enabled and is not an emissivity
+ * per unit length): Iout = Iin*exp(-tau) + S*(1 - exp(-tau)), the form a source iteration S = (1-eps) J + eps B needs
+ * (BASELINE configs[4]).  NULL switches emission off.  Replaces any emissivity. */
+int ftte_set_source_function(ftte_ctx *ctx, const double *S);
+int ftte_set_source_function_device(ftte_ctx *ctx, const double *S_dev);
 
 /* ---- the sweep ----------------------------------------------------------------------------- */
 

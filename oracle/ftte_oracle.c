@@ -275,22 +275,45 @@ int fo_layer_patterns(int n, double phi, double theta, fo_pattern *L)
 /* -------------------------------------------------------- segment arithmetic */
 /* transportRoutinesModule.f90:651-678 and 1036-1054.  Advances *I through one
  * segment and returns the term added to the cell's running mean. */
-static double fo_segment(double *I, double kappa, double eta, double dpath, int arith, double *noise)
+/* emitting != 0: an emissivity and/or source-function array was given, so the device takes its emission path for
+ * every segment (ftte_segment_emit), whatever the local values */
+static double fo_segment(double *I, double kappa, double eta, double src, int emitting, double dpath, int arith,
+                         double *noise, double *Inoise)
 {
     const double Iin = *I;
     const double tau = kappa * dpath;
-    /* rounding noise of the reference's own quotient (Iin-Iout)/log(Iin/Iout): the division
-     * Iin/Iout perturbs the logarithm by up to eps/2 absolute, i.e. the mean by Iin*(eps/2)/tau
-     * (ftte_oracle.h, fo_diffuse_sweep_uniform: `noise`) */
-    if (noise && tau > 0.0) *noise += Iin * (0x1p-53 / tau);
-    if (arith == FO_ARITH_DEVICE && eta == 0.0) return ftte_segment(&fo_device_consts, I, tau);
-    const double absorb = exp(-tau);
-    /* (float)1.e-10: the threshold is a default-real literal, :658 */
-    const double emit = (tau > (double)1.e-10f) ? (1.0 - absorb) / kappa : dpath;
-    const double Iout = Iin * absorb + eta * emit / dpath;
-    *I = Iout;
-    if (Iout < Iin) return (Iin - Iout) / log(Iin / Iout);
-    return 0.5 * (Iin + Iout);
+    double mean;
+    if (arith == FO_ARITH_DEVICE) {
+        mean = emitting ? ftte_segment_emit(&fo_device_consts, I, tau, eta, src) : ftte_segment(&fo_device_consts, I, tau);
+    } else {
+        const double absorb = exp(-tau);
+        /* (float)1.e-10: the threshold is a default-real literal, :658 */
+        const double emit = (tau > (double)1.e-10f) ? (1.0 - absorb) / kappa : dpath;
+        double Iout = Iin * absorb + eta * emit / dpath;
+        if (src != 0.0) Iout += src * (1.0 - absorb); /* source function S: the build's extension, not in the reference */
+        *I = Iout;
+        mean = (Iout < Iin) ? (Iin - Iout) / log(Iin / Iout) : 0.5 * (Iin + Iout);
+    }
+    /* rounding noise of the quotient (Iin-Iout)/log(Iin/Iout): the division Iin/Iout perturbs the logarithm by up to
+     * eps/2 absolute, i.e. the mean by a relative (eps/2)/|log(Iin/Iout)| (= (eps/2)/tau without emission);
+     * see ftte_oracle.h, fo_diffuse_sweep_uniform: `noise` */
+    if (noise) {
+        const double Iout = *I;
+        if (!emitting) { if (tau > 0.0) *noise += Iin * (0x1p-53 / tau); }
+        else {
+            /* with emission the reference formula also loses 1-exp(-tau) to cancellation (absolute eps/2 in
+             * 1-tmpabs, i.e. |eta|*(eps/2)/tau in Iout), and that error travels down the ray: carry a bound on the
+             * error of the intensity itself (Inoise, attenuated like the intensity) and charge it to the means */
+            const double a = exp(-tau);
+            const double in_n = Inoise ? *Inoise : 0.0;
+            double out_n = in_n * a + 4 * 0x1p-52 * fabs(Iout);
+            if (tau > 0.0) out_n += (fabs(eta) / tau + fabs(src)) * 0x1p-53;
+            if (Inoise) *Inoise = out_n;
+            if (Iout < Iin && Iout > 0.0) *noise += fmin(mean, mean * (0x1p-53 / log(Iin / Iout)));
+            *noise += in_n + out_n;
+        }
+    }
+    return mean;
 }
 
 static double fo_cell_mean(double acc, int nseg, double w, int arith)
@@ -317,10 +340,11 @@ static int fo_seg_slot(int end_code) /* storage slot of a segment type: xy 0, xz
 }
 
 /* --------------------------------------------------------------- uniform grid */
-int fo_diffuse_sweep_uniform(int n, int nnu, const double *kappa, const double *eta, double box, int ndir,
-                             const double *phiL, const double *thetaL, const double *w, const double *uvb,
+int fo_diffuse_sweep_uniform(int n, int nnu, const double *kappa, const double *eta, const double *src, double box,
+                             int ndir, const double *phiL, const double *thetaL, const double *w, const double *uvb,
                              double *J, int arith, int order, double *noise)
 {
+    const int emitting = eta != NULL || src != NULL;
     const size_t ncell = (size_t)n * n * n;
     if (noise) memset(noise, 0, (size_t)nnu * ncell * sizeof *noise);
     const size_t plane = (size_t)n * n;
@@ -329,6 +353,9 @@ int fo_diffuse_sweep_uniform(int n, int nnu, const double *kappa, const double *
     /* segment outputs of the layer below and of the current layer: [slot][j][k][nu] */
     double *below = malloc(3 * plane * nnu * sizeof *below);
     double *here = malloc(3 * plane * nnu * sizeof *here);
+    /* error bounds of those intensities, carried only for the emitting noise estimate */
+    double *below_n = calloc(3 * plane * nnu, sizeof *below_n);
+    double *here_n = calloc(3 * plane * nnu, sizeof *here_n);
     fo_pattern *L = malloc((size_t)n * sizeof *L);
     int status = 0;
     const double delta = box / (double)n; /* equiSources.f90:1570 */
@@ -354,24 +381,32 @@ int fo_diffuse_sweep_uniform(int n, int nnu, const double *kappa, const double *
                     for (int g = 0; g < nnu; ++g) {
                         const double kap = kappa[(size_t)g * ncell + cell];
                         const double em = eta ? eta[(size_t)g * ncell + cell] : 0.0;
+                        const double sf = src ? src[(size_t)g * ncell + cell] : 0.0;
                         double sum = 0.0, I, nz = 0.0;
                         double *nzp = noise ? &nz : NULL;
                         int nseg = 0;
                         /* xy segment <- cell (i-1,j,k), transportRoutinesModule.f90:594-611 */
+                        double In;
                         I = Pb ? below[fo_seg_slot(Pb->xy_top) * plane * nnu + at + g] : uvb[g];
-                        sum += fo_segment(&I, kap, em, delta * P->xy_len, arith, nzp);
+                        In = Pb ? below_n[fo_seg_slot(Pb->xy_top) * plane * nnu + at + g] : 0.0;
+                        sum += fo_segment(&I, kap, em, sf, emitting, delta * P->xy_len, arith, nzp, &In);
                         here[0 * plane * nnu + at + g] = I;
+                        here_n[0 * plane * nnu + at + g] = In;
                         ++nseg;
                         if (P->xz_active) { /* <- cell (i,j-1,k), :708-772 */
                             I = (j > 1) ? here[fo_seg_slot(P->xz_top) * plane * nnu + at - (size_t)n * nnu + g] : uvb[g];
-                            sum += fo_segment(&I, kap, em, delta * P->xz_len, arith, nzp);
+                            In = (j > 1) ? here_n[fo_seg_slot(P->xz_top) * plane * nnu + at - (size_t)n * nnu + g] : 0.0;
+                            sum += fo_segment(&I, kap, em, sf, emitting, delta * P->xz_len, arith, nzp, &In);
                             here[1 * plane * nnu + at + g] = I;
+                            here_n[1 * plane * nnu + at + g] = In;
                             ++nseg;
                         }
                         if (P->yz_active) { /* <- cell (i,j,k-1), :830-894 */
                             I = (k > 1) ? here[fo_seg_slot(P->yz_top) * plane * nnu + at - (size_t)nnu + g] : uvb[g];
-                            sum += fo_segment(&I, kap, em, delta * P->yz_len, arith, nzp);
+                            In = (k > 1) ? here_n[fo_seg_slot(P->yz_top) * plane * nnu + at - (size_t)nnu + g] : 0.0;
+                            sum += fo_segment(&I, kap, em, sf, emitting, delta * P->yz_len, arith, nzp, &In);
                             here[2 * plane * nnu + at + g] = I;
+                            here_n[2 * plane * nnu + at + g] = In;
                             ++nseg;
                         }
                         Jd[(size_t)g * ncell + cell] += fo_cell_mean(sum, nseg, w[d], arith);
@@ -380,6 +415,7 @@ int fo_diffuse_sweep_uniform(int n, int nnu, const double *kappa, const double *
                 }
             }
             double *t = below; below = here; here = t;
+            t = below_n; below_n = here_n; here_n = t;
         }
     }
 
@@ -388,7 +424,7 @@ int fo_diffuse_sweep_uniform(int n, int nnu, const double *kappa, const double *
         if (nacc == 1) memcpy(J, acc, tot * sizeof *J);
         else for (size_t x = 0; x < tot; ++x) J[x] = (acc[x] + acc[tot + x]) + acc[2 * tot + x];
     }
-    free(acc); free(below); free(here); free(L);
+    free(acc); free(below); free(here); free(below_n); free(here_n); free(L);
     return status;
 }
 
@@ -417,7 +453,7 @@ typedef struct {
     int n, izone, nnu, arith;
     int cs[2][2][2]; /* storage child index of sweep child (i,j,k) */
     double phi, theta;
-    const double *kappa, *uvb;
+    const double *kappa, *uvb, *eta, *src;
     double *Iout;    /* [nnode][3][nnu] */
     double *Jd, *noise;
     double w;
@@ -588,20 +624,23 @@ static void fo_transport(fo_tree *T, int me, double cell_size) /* :560-963 */
     double *Io = T->Iout + ((size_t)me * 3) * T->nnu;
     for (int g = 0; g < T->nnu; ++g) {
         const double kap = T->kappa[(size_t)g * T->ncell + cell];
+        const double em = T->eta ? T->eta[(size_t)g * T->ncell + cell] : 0.0;
+        const double sf = T->src ? T->src[(size_t)g * T->ncell + cell] : 0.0;
+        const int emitting = T->eta != NULL || T->src != NULL;
         double sum = 0.0, I, nz = 0.0;
         double *nzp = T->noise ? &nz : NULL;
         int nseg = 0;
         I = fo_incoming(T, me, 0, g);
-        sum += fo_segment(&I, kap, 0.0, cell_size * P->xy_len, T->arith, nzp);
+        sum += fo_segment(&I, kap, em, sf, emitting, cell_size * P->xy_len, T->arith, nzp, NULL);
         Io[g] = I; ++nseg;
         if (P->xz_active) {
             I = fo_incoming(T, me, 1, g);
-            sum += fo_segment(&I, kap, 0.0, cell_size * P->xz_len, T->arith, nzp);
+            sum += fo_segment(&I, kap, em, sf, emitting, cell_size * P->xz_len, T->arith, nzp, NULL);
             Io[(size_t)1 * T->nnu + g] = I; ++nseg;
         }
         if (P->yz_active) {
             I = fo_incoming(T, me, 2, g);
-            sum += fo_segment(&I, kap, 0.0, cell_size * P->yz_len, T->arith, nzp);
+            sum += fo_segment(&I, kap, em, sf, emitting, cell_size * P->yz_len, T->arith, nzp, NULL);
             Io[(size_t)2 * T->nnu + g] = I; ++nseg;
         }
         T->Jd[(size_t)g * T->ncell + cell] += fo_cell_mean(sum, nseg, T->w, T->arith);
@@ -609,12 +648,13 @@ static void fo_transport(fo_tree *T, int me, double cell_size) /* :560-963 */
     }
 }
 
-int fo_diffuse_sweep_tree(int n, int64_t ncell, const int32_t *level, int nnu, const double *kappa, double box,
-                          int ndir, const double *phiL, const double *thetaL, const double *w, const double *uvb,
-                          double *J, int arith, int order, double *noise)
+int fo_diffuse_sweep_tree(int n, int64_t ncell, const int32_t *level, int nnu, const double *kappa, const double *eta,
+                          const double *src, double box, int ndir, const double *phiL, const double *thetaL,
+                          const double *w, const double *uvb, double *J, int arith, int order, double *noise)
 {
     fo_tree T;
     memset(&T, 0, sizeof T);
+    T.eta = eta; T.src = src;
     T.noise = noise;
     if (noise) memset(noise, 0, (size_t)nnu * ncell * sizeof *noise);
     T.level = level; T.ncell = ncell; T.n = n; T.nnu = nnu; T.arith = arith; T.kappa = kappa; T.uvb = uvb;
@@ -685,6 +725,11 @@ void fo_compute_opacities(int64_t ncell, int nnu, const double *HI, const double
 void fo_device_attenuation(int64_t count, const double *tau, double *e, double *g)
 {
     for (int64_t i = 0; i < count; ++i) ftte_attenuation(&fo_device_consts, tau[i], &e[i], &g[i]);
+}
+
+void fo_device_log(int64_t count, const double *x, double *out)
+{
+    for (int64_t i = 0; i < count; ++i) out[i] = ftte_log1p(&fo_device_consts, x[i] - 1.0);
 }
 
 void fo_device_cell_mean(int64_t count, const double *acc, int nseg, double w, double *out)

@@ -71,24 +71,26 @@ int fo_layer_patterns(int n, double phi, double theta, fo_pattern *layers);
  * (flat = ((i-1)*n + (j-1))*n + (k-1), definitionsModule.f90:323-326).
  * J is overwritten (the reference zeroes it in computeOpacities,
  * equiSources.f90:4964-4966).  eta may be NULL (the reference's hard-wired
- * zero emissivity, transportRoutinesModule.f90:673-675).
+ * zero emissivity, transportRoutinesModule.f90:673-675); non-NULL: the reference's emission term
+ * Iout = Iin*tmpabs + nemi*tmpemi/dpath (:676).  src (may be NULL) is NOT in the reference: a source
+ * function S per cell adding S*(1-exp(-tau)), the form source iterations need.
  * noise (may be NULL): [nnu][n^3], receives a per-cell bound on the rounding noise the
  * REFERENCE formula (Iin-Iout)/log(Iin/Iout) carries: sum over directions and segments of
  * (w/nseg) * Iin * (eps/2)/tau_seg, eps/2 = 2^-53.  The quotient Iin/Iout is rounded before the
  * logarithm is taken, which perturbs log by eps/2 absolute and the mean by a relative eps/(2 tau);
  * the parity tests use it as the tau-aware part of their tolerance.
  * Returns 0 or the negative code of the first direction that cannot be folded. */
-int fo_diffuse_sweep_uniform(int n, int nnu, const double *kappa, const double *eta, double box, int ndir,
-                             const double *phi, const double *theta, const double *w, const double *uvb,
+int fo_diffuse_sweep_uniform(int n, int nnu, const double *kappa, const double *eta, const double *src, double box,
+                             int ndir, const double *phi, const double *theta, const double *w, const double *uvb,
                              double *J, int arith, int order, double *noise);
 
 /* Same on an AMR cell array: level[ncell] is the depth-first leaf list
  * (readCellArray.f90:154-187); kappa, J: [nnu][ncell].  Restates
  * setRaysRefined / findNeighbours / get??Neighbour / transport
  * (transportRoutinesModule.f90:121-218, 264-558, 560-963). */
-int fo_diffuse_sweep_tree(int n, int64_t ncell, const int32_t *level, int nnu, const double *kappa, double box,
-                          int ndir, const double *phi, const double *theta, const double *w, const double *uvb,
-                          double *J, int arith, int order, double *noise);
+int fo_diffuse_sweep_tree(int n, int64_t ncell, const int32_t *level, int nnu, const double *kappa, const double *eta,
+                          const double *src, double box, int ndir, const double *phi, const double *theta,
+                          const double *w, const double *uvb, double *J, int arith, int order, double *noise);
 
 /* equiSources.f90:4956-4983 generalised to nnu groups: kappa[g][c] = sum_s n_s[c]*beta[s][g],
  * summed in species order HI, HeI, HeII. beta: [3][nnu]. */
@@ -98,6 +100,7 @@ void fo_compute_opacities(int64_t ncell, int nnu, const double *HI, const double
 /* radiativetransfer_amd/csrc/ftte_math.h evaluated on the host, element-wise (for tests of the
  * device arithmetic itself): e = exp(-tau), g = (1-exp(-tau))/tau; out = (acc/nseg)*w. */
 void fo_device_attenuation(int64_t count, const double *tau, double *e, double *g);
+void fo_device_log(int64_t count, const double *x, double *out);
 void fo_device_cell_mean(int64_t count, const double *acc, int nseg, double w, double *out);
 
 #ifdef __cplusplus

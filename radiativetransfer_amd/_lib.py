@@ -42,6 +42,9 @@ SIGNATURES = {
     "ftte_set_opacity_device": (C.c_int, [_vp, C.c_int, _vp]),
     "ftte_set_species": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp]),
     "ftte_set_emissivity": (C.c_int, [_vp, _dp]),
+    "ftte_set_emissivity_device": (C.c_int, [_vp, _vp]),
+    "ftte_set_source_function": (C.c_int, [_vp, _dp]),
+    "ftte_set_source_function_device": (C.c_int, [_vp, _vp]),
     "ftte_diffuse_sweep": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     "ftte_diffuse_sweep_device": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, _vp, _vp]),
     "ftte_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),

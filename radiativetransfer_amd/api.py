@@ -165,7 +165,20 @@ class DiffuseTransfer:
         self.nnu = beta.shape[1]
 
     def set_emissivity(self, eta=None):
-        self._ok(self._lib.ftte_set_emissivity(self._ctx, None if eta is None else _dp(_f64(eta))))
+        """The reference's emission term (transportRoutinesModule.f90:676) with eta[nnu][ncell]; None switches it off."""
+        eta = None if eta is None else _f64(eta)
+        self._ok(self._lib.ftte_set_emissivity(self._ctx, None if eta is None else _dp(eta)))
+
+    def set_source_function(self, S=None):
+        """Source function S[nnu][ncell]: Iout = Iin exp(-tau) + S (1 - exp(-tau)) (not in the reference); None: off."""
+        S = None if S is None else _f64(S)
+        self._ok(self._lib.ftte_set_source_function(self._ctx, None if S is None else _dp(S)))
+
+    def set_emissivity_device(self, device_ptr: int):
+        self._ok(self._lib.ftte_set_emissivity_device(self._ctx, C.c_void_p(device_ptr)))
+
+    def set_source_function_device(self, device_ptr: int):
+        self._ok(self._lib.ftte_set_source_function_device(self._ctx, C.c_void_p(device_ptr)))
 
     def set_option(self, key: str, value: int):
         self._ok(self._lib.ftte_set_option(self._ctx, key.encode(), int(value)))

@@ -82,6 +82,11 @@ struct ftte_ctx {
     bool kappa_ready[3] = {false, false, false};
     size_t kappa_cap = 0; // elements per layout buffer
 
+    // emissivity (mode 1: the reference's eta) or source function (mode 2), same three layouts as kappa
+    int emit_mode = 0;
+    double *emis[3] = {nullptr, nullptr, nullptr};
+    bool emis_ready[3] = {false, false, false};
+
     double *acc[3][kMaxSlots] = {};
     size_t acc_cap = 0; // elements per accumulator
 
@@ -136,10 +141,10 @@ int fold_status(int rc)
 // ---- planner ------------------------------------------------------------------------------------
 // Turns the direction list into what the kernel consumes.  O(ndir * (n + tiles)) host work,
 // cached in the context for as long as the directions, the grid and the tuning stay the same.
-int build_plan(ftte_ctx *c, int ndir, const double *phi, const double *theta, const double *w)
+int build_plan(ftte_ctx *c, int rows, int stack, int ndir, const double *phi, const double *theta, const double *w)
 {
     Plan &P = c->plan;
-    const int n = c->n, rows = c->rows, slots = c->slots, stack = c->stack;
+    const int n = c->n, slots = c->slots;
     const int tile_rows = stack * rows - 1; // owned rows of one work item
     if (P.valid && P.n == n && P.rows == rows && P.slots == slots && P.stack == stack && P.box == c->box && (int)P.phi.size() == ndir &&
         (ndir == 0 || (!std::memcmp(P.phi.data(), phi, sizeof(double) * ndir) &&
@@ -301,7 +306,11 @@ int ensure_kappa(ftte_ctx *c, int nnu)
 {
     const size_t need = (size_t)nnu * c->ncell;
     if (c->kappa[0] && c->kappa_cap >= need) return FTTE_OK;
-    for (int l = 0; l < 3; ++l) if (c->kappa[l]) { FTTE_HIP(c, hipFree(c->kappa[l])); c->kappa[l] = nullptr; }
+    for (int l = 0; l < 3; ++l) {
+        if (c->kappa[l]) { FTTE_HIP(c, hipFree(c->kappa[l])); c->kappa[l] = nullptr; }
+        if (c->emis[l]) { FTTE_HIP(c, hipFree(c->emis[l])); c->emis[l] = nullptr; }
+    }
+    c->emit_mode = 0; // sized by the old number of groups: has to be set again
     FTTE_HIP(c, hipMalloc((void **)&c->kappa[0], need * sizeof(double)));
     c->kappa_cap = need;
     return FTTE_OK;
@@ -414,6 +423,8 @@ int forest_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
         AmrLevelRec A;
         std::memset(&A, 0, sizeof A);
         A.kappa = c->kappa[0];
+        A.emis = c->emit_mode ? c->emis[0] : nullptr;
+        A.emit = c->emit_mode;
         A.uvb = c->d_uvb;
         A.ncell = ncell;
         A.ndir = nb;
@@ -493,6 +504,7 @@ int ftte_destroy(ftte_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (int l = 0; l < 3; ++l) {
         if (c->kappa[l]) (void)hipFree(c->kappa[l]);
+        if (c->emis[l]) (void)hipFree(c->emis[l]);
         for (int s = 0; s < kMaxSlots; ++s) if (c->acc[l][s]) (void)hipFree(c->acc[l][s]);
     }
     if (c->d_layers) (void)hipFree(c->d_layers);
@@ -527,8 +539,10 @@ int ftte_set_grid(ftte_ctx *c, int nx, int ny, int nz, int64_t ncell, const int3
         (void)hipStreamSynchronize(c->stream);
         for (int l = 0; l < 3; ++l) {
             if (c->kappa[l]) { (void)hipFree(c->kappa[l]); c->kappa[l] = nullptr; }
+            if (c->emis[l]) { (void)hipFree(c->emis[l]); c->emis[l] = nullptr; }
             for (int s = 0; s < kMaxSlots; ++s) if (c->acc[l][s]) { (void)hipFree(c->acc[l][s]); c->acc[l][s] = nullptr; }
         }
+        c->emit_mode = 0;
         if (c->amr_Iout) { (void)hipFree(c->amr_Iout); c->amr_Iout = nullptr; }
         if (c->amr_mean) { (void)hipFree(c->amr_mean); c->amr_mean = nullptr; }
         c->kappa_cap = c->acc_cap = c->amr_scratch_cap = 0;
@@ -599,15 +613,28 @@ int ftte_set_species(ftte_ctx *c, int nnu, const double *HI, const double *HeI, 
     return FTTE_OK;
 }
 
-int ftte_set_emissivity(ftte_ctx *c, const double *eta)
+static int set_emission(ftte_ctx *c, int mode, const double *values, bool on_device, const char *who)
 {
     if (!c) return FTTE_ERR_ARG;
-    if (eta)
-        return fail(c, FTTE_ERR_UNSUPPORTED,
-                    "ftte_set_emissivity: only the reference's zero emissivity (eta = NULL, transportRoutinesModule.f90:673-675) "
-                    "is implemented in this build");
+    if (!values) { c->emit_mode = 0; return FTTE_OK; }
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    FTTE_HIP(c, hipSetDevice(c->device));
+    if (!on_device) FTTE_HIP(c, hipStreamSynchronize(c->stream));
+    if (!c->emis[0]) FTTE_HIP(c, hipMalloc((void **)&c->emis[0], sizeof(double) * c->kappa_cap));
+    const size_t bytes = sizeof(double) * (size_t)c->nnu * c->ncell;
+    FTTE_HIP(c, hipMemcpyAsync(c->emis[0], values, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    if (!on_device) FTTE_HIP(c, hipStreamSynchronize(c->stream));
+    c->emit_mode = mode;
+    c->emis_ready[0] = true; c->emis_ready[1] = c->emis_ready[2] = false;
+    (void)who;
     return FTTE_OK;
 }
+
+int ftte_set_emissivity(ftte_ctx *c, const double *eta) { return set_emission(c, 1, eta, false, "ftte_set_emissivity"); }
+int ftte_set_emissivity_device(ftte_ctx *c, const double *eta_dev) { return set_emission(c, 1, eta_dev, true, "ftte_set_emissivity_device"); }
+int ftte_set_source_function(ftte_ctx *c, const double *S) { return set_emission(c, 2, S, false, "ftte_set_source_function"); }
+int ftte_set_source_function_device(ftte_ctx *c, const double *S_dev) { return set_emission(c, 2, S_dev, true, "ftte_set_source_function_device"); }
 
 int ftte_set_option(ftte_ctx *c, const char *key, int value)
 {
@@ -649,7 +676,9 @@ int ftte_diffuse_sweep_device(ftte_ctx *c, int ndir, const double *phi, const do
     const size_t per_acc = (size_t)nnu * c->ncell;
 
     if (c->use_forest) return forest_sweep(c, ndir, phi, theta, w, uvb, J_dev, stream);
-    if ((rc = build_plan(c, ndir, phi, theta, w))) return rc;
+    // the emission variants of the tiled kernel are built for one shape
+    const int rows = c->emit_mode ? 8 : c->rows, stack = c->emit_mode ? 1 : c->stack;
+    if ((rc = build_plan(c, rows, stack, ndir, phi, theta, w))) return rc;
     Plan &P = c->plan;
 
     // everything below overwrites device tables the previous sweep may still be reading
@@ -689,6 +718,12 @@ int ftte_diffuse_sweep_device(ftte_ctx *c, int ndir, const double *phi, const do
                 return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
             c->kappa_ready[l] = true;
         }
+        if (any && c->emit_mode && !c->emis_ready[l]) {
+            if (!c->emis[l]) FTTE_HIP(c, hipMalloc((void **)&c->emis[l], sizeof(double) * c->kappa_cap));
+            if (launch_to_layout(l, c->emis[0], c->emis[l], n, nnu, (long)c->ncell, stream))
+                return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
+            c->emis_ready[l] = true;
+        }
     }
 
     // events for the launch records
@@ -710,6 +745,7 @@ int ftte_diffuse_sweep_device(ftte_ctx *c, int ndir, const double *phi, const do
             R.layers = c->d_layers + D.layer_off;
             R.kappa = c->kappa[LP.layout];
             R.J = c->acc[LP.layout][s];
+            R.emis = c->emit_mode ? c->emis[LP.layout] : nullptr;
             R.org = D.org;
             R.si = D.si; R.sv = D.sv; R.su = D.su;
             R.u_lo = D.u_lo; R.v_lo = D.v_lo;
@@ -722,12 +758,13 @@ int ftte_diffuse_sweep_device(ftte_ctx *c, int ndir, const double *phi, const do
         L.n = n;
         L.nitems = LP.nitems;
         L.nnu = nnu;
+        L.emit = c->emit_mode;
         static const ftte_consts kMath = FTTE_CONSTS_INIT;
         L.math = kMath;
         LaunchTiming &T = c->timing[li];
         T.updates = LP.updates * nnu;
         FTTE_HIP(c, hipEventRecord(T.start, stream));
-        const int lrc = launch_sweep(L, c->rows, c->waves, c->stack, nnu, stream);
+        const int lrc = launch_sweep(L, rows, c->waves, stack, nnu, stream);
         if (lrc == -1)
             return fail(c, FTTE_ERR_ARG, "no sweep kernel variant for this rows/stack/waves combination (rows x stack: 4x{1,4,8}, "
                                          "8x{1,2,4}, 16x1; waves 2, 3, 4, 6)");

@@ -39,6 +39,7 @@ struct DirRec {
     const LayerRec *layers; // [n], device memory
     const double *kappa;    // opacity in the layout of this direction's march axis, group 0
     double *J;              // accumulator of this direction's slot, same layout, group 0
+    const double *emis;     // emissivity or source function in the same layout (LaunchRec::emit), else null
     int64_t org;            // element offset of the virtual cell (i, v, column position) = (0,0,0)
     int32_t si, sv, su;     // element strides along march and v (signed: reflections); su = +1, or -1 when the
                             // u axis is mirrored: the column position of cell u is then n+1-u (stride +1 either way)
@@ -67,6 +68,7 @@ struct LaunchRec {
     int32_t n;          // grid size
     int32_t nitems;
     int32_t nnu;        // frequency groups; workgroup b handles group b % nnu of work item b / nnu
+    int32_t emit;       // 0 none, 1 DirRec::emis is the reference's eta, 2 a source function
     ftte_consts math;   // constants of ftte_math.h, delivered through scalar registers
 };
 
@@ -85,9 +87,9 @@ struct AmrLevelRec {
     int64_t first[kAmrBatch + 1]; // prefix of the per-direction element counts of this depth
     int64_t begin[kAmrBatch];     // where this depth starts in each direction's `order`
     int64_t total;                // first[ndir]
-    const double *kappa, *uvb;
+    const double *kappa, *uvb, *emis; // cell-array order
     int64_t ncell;
-    int32_t ndir, nnu;
+    int32_t ndir, nnu, emit;
     ftte_consts math;
 };
 

@@ -61,16 +61,21 @@ template <typename T> __device__ __forceinline__ T *uniform(T *p) { return reint
 
 // One segment of one ray.  EDGE: the cell may lie outside the domain, where the ray is
 // re-initialised with the inflow (transportRoutinesModule.f90:594-597) and adds nothing.
-template <bool EDGE>
-__device__ __forceinline__ double segment(const ftte_consts &K, double &I, double kap, double dpath, bool inside, double uvb)
+// EMIT: 0 no emission (the reference as shipped), 1 `x` is the reference's emissivity eta, 2 `x` is a source function S
+// (ftte_math.h: ftte_segment_emit).
+template <bool EDGE, int EMIT>
+__device__ __forceinline__ double segment(const ftte_consts &K, double &I, double kap, double x, double dpath, bool inside,
+                                          double uvb)
 {
+    double It = I, m;
+    if (EMIT == 0) m = ftte_segment(&K, &It, kap * dpath);
+    else m = ftte_segment_emit(&K, &It, kap * dpath, EMIT == 1 ? x : 0.0, EMIT == 2 ? x : 0.0);
     if (EDGE) {
-        double It = I;
-        const double m = ftte_segment(&K, &It, kap * dpath);
         I = inside ? It : uvb;
         return inside ? m : 0.0;
     }
-    return ftte_segment(&K, &I, kap * dpath);
+    I = It;
+    return m;
 }
 
 // One layer of one tile.  RC: chain class (ftte_internal.h).  I[r]: intensity of ray r of this
@@ -84,9 +89,10 @@ __device__ __forceinline__ double segment(const ftte_consts &K, double &I, doubl
 //                     is a read-only halo (the tile below recomputes it); with STACK > 1 only the lowest
 //                     wavefront has a halo row, the others receive the two numbers per lane they need
 //                     through LDS (`xchg`, one s_barrier per layer that has such segments) and own row 0.
-template <int ROWS, int RC, bool EDGE, int STACK>
+template <int ROWS, int RC, bool EDGE, int STACK, int EMIT>
 __device__ __forceinline__ void layer_step(const ftte_consts &K, double (&I)[ROWS], const char *__restrict__ kplane,
-                                           char *__restrict__ jplane, int cv0, int cu, int n, int sv, bool mirror_u,
+                                           const char *__restrict__ xplane, char *__restrict__ jplane, int cv0, int cu,
+                                           int n, int sv, bool mirror_u,
                                            double d0, double d1, double d2, double w, double uvb, bool first,
                                            bool lane_owned, int lane, int wid, double *xchg)
 {
@@ -108,7 +114,7 @@ __device__ __forceinline__ void layer_step(const ftte_consts &K, double (&I)[ROW
     const long row_bytes = 8l * sv;
 
     // ---- issue every load of the layer up front ------------------------------------------------
-    double K0[ROWS + 1], K1[ROWS + 1], Jacc[ROWS];
+    double K0[ROWS + 1], K1[ROWS + 1], X0[EMIT ? ROWS + 1 : 1], X1[EMIT ? ROWS + 1 : 1], Jacc[ROWS];
 #pragma unroll
     for (int r = 0; r <= ROWS; ++r) {
         const int row = EDGE ? clampi(cv0 + r, 1, n) : cv0 + r;
@@ -117,7 +123,13 @@ __device__ __forceinline__ void layer_step(const ftte_consts &K, double (&I)[ROW
         const bool need1 = HAS_U && ((SHAPE == RC_TWO_U) ? (r < ROWS) : (SHAPE == RC_THREE_U) ? true : (r >= 1));
         if (need0) K0[r] = *reinterpret_cast<const double *>(rp + off0);
         if (need1) K1[r] = *reinterpret_cast<const double *>(rp + off1);
+        if (EMIT) {
+            const char *xp = xplane + row * row_bytes;
+            if (need0) X0[r] = *reinterpret_cast<const double *>(xp + off0);
+            if (need1) X1[r] = *reinterpret_cast<const double *>(xp + off1);
+        }
     }
+    constexpr int XM = EMIT ? ~0 : 0; // index mask: without emission the X arrays have one (unused) element
     const bool own_lane = lane_owned && in_u0;
 #pragma unroll
     for (int r = R0; r < ROWS; ++r) Jacc[r] = 0.0;
@@ -140,16 +152,16 @@ __device__ __forceinline__ void layer_step(const ftte_consts &K, double (&I)[ROW
         const bool in_v1 = !EDGE || (row + 1 >= 1 && row + 1 <= n);
 
         double m0, m1 = 0.0, m2 = 0.0;
-        m0 = segment<EDGE>(K, I[r], K0[r], d0, in_v0 && in_u0, uvb);
-        if (SHAPE == RC_TWO_U) m1 = segment<EDGE>(K, I[r], K1[r], d1, in_v0 && in_u1, uvb);
-        if (SHAPE == RC_TWO_V) m1 = segment<EDGE>(K, I[r], K0[r + 1], d1, in_v1 && in_u0, uvb);
+        m0 = segment<EDGE, EMIT>(K, I[r], K0[r], X0[r & XM], d0, in_v0 && in_u0, uvb);
+        if (SHAPE == RC_TWO_U) m1 = segment<EDGE, EMIT>(K, I[r], K1[r], X1[r & XM], d1, in_v0 && in_u1, uvb);
+        if (SHAPE == RC_TWO_V) m1 = segment<EDGE, EMIT>(K, I[r], K0[r + 1], X0[(r + 1) & XM], d1, in_v1 && in_u0, uvb);
         if (SHAPE == RC_THREE_U) {
-            m1 = segment<EDGE>(K, I[r], K1[r], d1, in_v0 && in_u1, uvb);
-            m2 = segment<EDGE>(K, I[r], K1[r + 1], d2, in_v1 && in_u1, uvb);
+            m1 = segment<EDGE, EMIT>(K, I[r], K1[r], X1[r & XM], d1, in_v0 && in_u1, uvb);
+            m2 = segment<EDGE, EMIT>(K, I[r], K1[r + 1], X1[(r + 1) & XM], d2, in_v1 && in_u1, uvb);
         }
         if (SHAPE == RC_THREE_V) {
-            m1 = segment<EDGE>(K, I[r], K0[r + 1], d1, in_v1 && in_u0, uvb);
-            m2 = segment<EDGE>(K, I[r], K1[r + 1], d2, in_v1 && in_u1, uvb);
+            m1 = segment<EDGE, EMIT>(K, I[r], K0[r + 1], X0[(r + 1) & XM], d1, in_v1 && in_u0, uvb);
+            m2 = segment<EDGE, EMIT>(K, I[r], K1[r + 1], X1[(r + 1) & XM], d2, in_v1 && in_u1, uvb);
         }
 
         // the cell (row, cu) collects: its own xy segment, and the 2nd / 3rd segments that end
@@ -219,16 +231,17 @@ __device__ __forceinline__ void layer_step(const ftte_consts &K, double (&I)[ROW
     }
 }
 
-template <int ROWS, bool EDGE, int STACK>
+template <int ROWS, bool EDGE, int STACK, int EMIT>
 __device__ __forceinline__ void layer_dispatch(const ftte_consts &K, double (&I)[ROWS], int rc, const char *kplane,
-                                               char *jplane, int cv0, int cu, int n, int sv, bool mirror_u, double d0,
+                                               const char *xplane, char *jplane, int cv0, int cu, int n, int sv,
+                                               bool mirror_u, double d0,
                                                double d1, double d2, double w, double uvb, bool first, bool lane_owned,
                                                int lane, int wid, double *xchg)
 {
 #define FTTE_CASE(C)                                                                                                     \
     case C:                                                                                                              \
-        layer_step<ROWS, C, EDGE, STACK>(K, I, kplane, jplane, cv0, cu, n, sv, mirror_u, d0, d1, d2, w, uvb, first,     \
-                                         lane_owned, lane, wid, xchg);                                                   \
+        layer_step<ROWS, C, EDGE, STACK, EMIT>(K, I, kplane, xplane, jplane, cv0, cu, n, sv, mirror_u, d0, d1, d2, w,   \
+                                               uvb, first, lane_owned, lane, wid, xchg);                                 \
         break;
     switch (rc) {
         FTTE_CASE(RC_ONE)
@@ -238,8 +251,8 @@ __device__ __forceinline__ void layer_dispatch(const ftte_consts &K, double (&I)
         FTTE_CASE(RC_THREE_V)
         FTTE_CASE(RC_THREE_U_SWAP)
     default:
-        layer_step<ROWS, RC_THREE_V_SWAP, EDGE, STACK>(K, I, kplane, jplane, cv0, cu, n, sv, mirror_u, d0, d1, d2, w, uvb,
-                                                       first, lane_owned, lane, wid, xchg);
+        layer_step<ROWS, RC_THREE_V_SWAP, EDGE, STACK, EMIT>(K, I, kplane, xplane, jplane, cv0, cu, n, sv, mirror_u, d0, d1,
+                                                             d2, w, uvb, first, lane_owned, lane, wid, xchg);
         break;
     }
 #undef FTTE_CASE
@@ -247,7 +260,7 @@ __device__ __forceinline__ void layer_dispatch(const ftte_consts &K, double (&I)
 
 // grid: nitems * nnu workgroups of STACK wavefronts; the frequency group is the fastest index, so that
 // (for nnu = 8) all tiles of one group run on one XCD.
-template <int ROWS, int WAVES, int STACK>
+template <int ROWS, int WAVES, int STACK, int EMIT>
 __global__ void __launch_bounds__(64 * STACK, WAVES) sweep_kernel(const LaunchRec L)
 {
     __shared__ double xchg_lds[STACK > 1 ? 2 * STACK * 2 * 64 : 1]; // [parity][wavefront][2nd|3rd][lane]
@@ -270,6 +283,7 @@ __global__ void __launch_bounds__(64 * STACK, WAVES) sweep_kernel(const LaunchRe
     const long org = uniform((long)D.org);
     const char *kbase = reinterpret_cast<const char *>(uniform(D.kappa) + (long)nu * L.group_stride + org);
     char *jbase = reinterpret_cast<char *>(uniform(D.J) + (long)nu * L.group_stride + org);
+    const char *xbase = EMIT ? reinterpret_cast<const char *>(uniform(D.emis) + (long)nu * L.group_stride + org) : nullptr;
     const int u_lo = uniform(D.u_lo), v_lo = uniform(D.v_lo);
 
     // labels of this lane's rays: u label of the lane (lane 0: halo), v label of this wavefront's row 0
@@ -294,6 +308,7 @@ __global__ void __launch_bounds__(64 * STACK, WAVES) sweep_kernel(const LaunchRe
         const int cv0 = vl0 + dv;
         const char *kplane = kbase + 8l * i * si;
         char *jplane = jbase + 8l * i * si;
+        const char *xplane = EMIT ? xbase + 8l * i * si : nullptr;
         double *xchg = xchg_lds + parity * (STACK * 2 * 64);
         const bool has_v = rc != RC_ONE && rc != RC_TWO_U; // this layer passes segments from row to row
 
@@ -310,11 +325,11 @@ __global__ void __launch_bounds__(64 * STACK, WAVES) sweep_kernel(const LaunchRe
                 __syncthreads();
             }
         } else if (interior)
-            layer_dispatch<ROWS, false, STACK>(L.math, I, rc, kplane, jplane, cv0, cu, n, sv, mirror_u, d0, d1, d2, w, uvb,
-                                               first, lane_owned, lane, wid, xchg);
+            layer_dispatch<ROWS, false, STACK, EMIT>(L.math, I, rc, kplane, xplane, jplane, cv0, cu, n, sv, mirror_u, d0, d1,
+                                                     d2, w, uvb, first, lane_owned, lane, wid, xchg);
         else
-            layer_dispatch<ROWS, true, STACK>(L.math, I, rc, kplane, jplane, cv0, cu, n, sv, mirror_u, d0, d1, d2, w, uvb,
-                                              first, lane_owned, lane, wid, xchg);
+            layer_dispatch<ROWS, true, STACK, EMIT>(L.math, I, rc, kplane, xplane, jplane, cv0, cu, n, sv, mirror_u, d0, d1,
+                                                    d2, w, uvb, first, lane_owned, lane, wid, xchg);
         if (STACK > 1 && has_v) parity ^= 1;
     }
 }
@@ -328,10 +343,10 @@ static int launch_variant(const LaunchRec &L, int waves, dim3 grid, hipStream_t 
 {
     const dim3 block(64 * STACK);
     switch (waves) {
-    case 2: hipLaunchKernelGGL((sweep_kernel<ROWS, 2, STACK>), grid, block, g_lds_pad, stream, L); break;
-    case 3: hipLaunchKernelGGL((sweep_kernel<ROWS, 3, STACK>), grid, block, g_lds_pad, stream, L); break;
-    case 4: hipLaunchKernelGGL((sweep_kernel<ROWS, 4, STACK>), grid, block, g_lds_pad, stream, L); break;
-    case 6: hipLaunchKernelGGL((sweep_kernel<ROWS, 6, STACK>), grid, block, g_lds_pad, stream, L); break;
+    case 2: hipLaunchKernelGGL((sweep_kernel<ROWS, 2, STACK, 0>), grid, block, g_lds_pad, stream, L); break;
+    case 3: hipLaunchKernelGGL((sweep_kernel<ROWS, 3, STACK, 0>), grid, block, g_lds_pad, stream, L); break;
+    case 4: hipLaunchKernelGGL((sweep_kernel<ROWS, 4, STACK, 0>), grid, block, g_lds_pad, stream, L); break;
+    case 6: hipLaunchKernelGGL((sweep_kernel<ROWS, 6, STACK, 0>), grid, block, g_lds_pad, stream, L); break;
     default: return -1;
     }
     return 0;
@@ -342,6 +357,12 @@ int launch_sweep(const LaunchRec &L, int rows, int waves, int stack, int nnu, hi
     if (L.nitems <= 0 || nnu != L.nnu) return L.nitems <= 0 ? 0 : -1;
     const dim3 grid((unsigned)L.nitems * (unsigned)nnu);
     int rc = -1;
+    if (L.emit) { // emission: one built shape (8 rows, single wavefront, 3 waves per SIMD)
+        if (rows != 8 || stack != 1) return -1;
+        if (L.emit == 1) hipLaunchKernelGGL((sweep_kernel<8, 3, 1, 1>), grid, dim3(64), g_lds_pad, stream, L);
+        else hipLaunchKernelGGL((sweep_kernel<8, 3, 1, 2>), grid, dim3(64), g_lds_pad, stream, L);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     if (rows == 4 && stack == 1) rc = launch_variant<4, 1>(L, waves, grid, stream);
     else if (rows == 4 && stack == 4) rc = launch_variant<4, 4>(L, waves, grid, stream);
     else if (rows == 4 && stack == 8) rc = launch_variant<4, 8>(L, waves, grid, stream);
@@ -486,7 +507,12 @@ __global__ void __launch_bounds__(256) amr_level_kernel(const AmrLevelRec A)
     }
     const int cell = seg / 3;
     const double kap = A.kappa[(long)nu * A.ncell + cell];
-    const double m = ftte_segment(&A.math, &I, kap * D.dpath[seg]);
+    double m;
+    if (A.emit == 0) m = ftte_segment(&A.math, &I, kap * D.dpath[seg]);
+    else {
+        const double x = A.emis[(long)nu * A.ncell + cell];
+        m = ftte_segment_emit(&A.math, &I, kap * D.dpath[seg], A.emit == 1 ? x : 0.0, A.emit == 2 ? x : 0.0);
+    }
     Io[nu] = I;
     D.mean[(long)seg * nnu + nu] = m;
 }

@@ -30,6 +30,7 @@
 #define FTTE_RINT(a) __builtin_rint(a)
 #define FTTE_LDEXP(a, n) __builtin_ldexp((a), (n))
 #define FTTE_FMAX(a, b) __builtin_fmax((a), (b))
+#define FTTE_FREXP(a, pe) __builtin_frexp((a), (pe))
 #if defined(__HIP_DEVICE_COMPILE__)
 /* a/b correctly rounded, for normal-range operands: v_rcp_f64 seed, two Newton steps, quotient, one residual
  * correction -- the instruction sequence hipcc itself emits for an IEEE fp64 division, minus the
@@ -65,6 +66,7 @@ __device__ __forceinline__ double ftte_div(double a, double b)
 #define FTTE_RINT(a) rint(a)
 #define FTTE_LDEXP(a, n) ldexp((a), (n))
 #define FTTE_FMAX(a, b) fmax((a), (b))
+#define FTTE_FREXP(a, pe) frexp((a), (pe))
 #define FTTE_DIV(a, b) ((a) / (b))
 #define FTTE_KEEP(x) ((void)0)
 #define FTTE_ANY(c) (c)
@@ -79,6 +81,8 @@ typedef struct {
     double ln2_lo;  /* ln2 - ln2_hi */
     double x_floor; /* exp(x_floor) == 0 in binary64; keeps n inside int range */
     double c[10];   /* (exp(r)-1-r)/r^2 ~ c0 + c1 r + ... + c9 r^9, tools/fit_exp_poly.py */
+    double sqrt_half; /* sqrt(1/2) */
+    double lg[7];   /* (atanh(s)/s - 1)/s^2 ~ lg0 + lg1 z + ... + lg6 z^6, z = s^2, tools/fit_log_poly.py */
 } ftte_consts;
 
 #define FTTE_CONSTS_INIT                                                                                              \
@@ -88,6 +92,11 @@ typedef struct {
             0x1.0000000000001p-1, 0x1.5555555555556p-3, 0x1.5555555553d63p-5, 0x1.11111111109b3p-7,                   \
                 0x1.6c16c1788bd90p-10, 0x1.a01a01a7c41d5p-13, 0x1.a019b90d2ae7ap-16, 0x1.71de0dae63bb3p-19,           \
                 0x1.289185613a3d6p-22, 0x1.af38a9b0ec855p-26                                                          \
+        },                                                                                                            \
+            0x1.6a09e667f3bcdp-1,                                                                                     \
+        {                                                                                                             \
+            0x1.5555555555558p-2, 0x1.9999999995273p-3, 0x1.2492492dfd879p-3, 0x1.c71c62d5e43dfp-4,                   \
+                0x1.7462b91bd6c45p-4, 0x1.39fdcce1da1aep-4, 0x1.2b5f6919aa514p-4                                      \
         }                                                                                                             \
     }
 
@@ -137,6 +146,54 @@ FTTE_HD double ftte_segment(const ftte_consts *K, double *I, double tau)
     double mean = Iin * g;
     if (FTTE_ANY(Iout == 0.0)) mean = (Iout == 0.0) ? 0.0 : mean; /* underflow: rare enough to branch on per wave */
     return mean;
+}
+
+/* log(1 + t) for t >= 0, accurate also for tiny t (where forming 1 + t first would lose t's low bits):
+ * 1 + t = 2^k m, m in [sqrt(1/2), sqrt(2)); for t < sqrt(2) - 1, k = 0 and f = m - 1 = t exactly.
+ * log m = 2 atanh(s), s = f/(2+f), |s| <= 0.1716, degree-6 polynomial in s^2 (approximation error 4.7e-18).
+ * Same bits on host and device: frexp, one correctly rounded division, explicit FMAs. */
+FTTE_HD double ftte_log1p(const ftte_consts *K, double t)
+{
+    int k;
+    double m = FTTE_FREXP(1.0 + t, &k); /* [1/2, 1) */
+    if (m < K->sqrt_half) { m = m + m; k -= 1; }
+    const int small = t < 0x1.a827999fcef32p-2; /* sqrt(2) - 1 */
+    const double f = small ? t : m - 1.0;
+    const double kf = small ? 0.0 : (double)k;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    double p = K->lg[6];
+    p = FTTE_FMA(p, z, K->lg[5]);
+    p = FTTE_FMA(p, z, K->lg[4]);
+    p = FTTE_FMA(p, z, K->lg[3]);
+    p = FTTE_FMA(p, z, K->lg[2]);
+    p = FTTE_FMA(p, z, K->lg[1]);
+    p = FTTE_FMA(p, z, K->lg[0]);
+    const double s2 = s + s;
+    const double logm = FTTE_FMA(s2, z * p, s2);
+    return FTTE_FMA(kf, K->ln2_hi, FTTE_FMA(kf, K->ln2_lo, logm));
+}
+
+/* One segment with emission.  The reference's (never enabled) emission term, transportRoutinesModule.f90:673-678:
+ *     Iout = Iin*exp(-tau) + eta * ((tau > 1e-10) ? (1-exp(-tau))/kappa : dpath) / dpath  =  Iin*e + eta*g(tau)
+ * (note the reference's extra 1/dpath: its eta is not an emissivity per unit length).  `src` adds the physical form
+ * S*(1-exp(-tau)) = (src*tau)*g for a source function S per cell -- the build's own extension for source iterations
+ * (DESIGN.md).  With emission log(Iin/Iout) != tau, so the path mean is the reference's log-mean itself
+ * (transportRoutinesModule.f90:1044-1048), evaluated as (Iin-Iout)/log1p((Iin-Iout)/Iout): the same number, without
+ * the reference's loss of the difference when the quotient Iin/Iout is rounded (fatal near Iout = Iin, i.e. wherever
+ * the radiation field is close to the source function). */
+FTTE_HD double ftte_segment_emit(const ftte_consts *K, double *I, double tau, double eta, double src)
+{
+    double e, g;
+    ftte_attenuation(K, tau, &e, &g);
+    const double Iin = *I;
+    const double emis = FTTE_FMA(src, tau, eta);
+    const double Iout = FTTE_FMA(emis, g, Iin * e);
+    *I = Iout;
+    const double diff = Iin - Iout;
+    const double falling = diff / ftte_log1p(K, diff / Iout); /* Iout == 0: selected away below */
+    const double rising = 0.5 * (Iin + Iout);
+    return (Iout < Iin) ? ((Iout == 0.0) ? 0.0 : falling) : rising;
 }
 
 /* (acc/nseg)*w with acc/nseg correctly rounded for nseg in {1,2,3} without a

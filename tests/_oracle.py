@@ -43,9 +43,9 @@ def lib():
         L.fo_fold_direction.argtypes = [C.c_double, C.c_double, dp, dp, ip]
         L.fo_set_pattern.argtypes = [C.POINTER(Pattern), C.c_double, C.c_double]
         L.fo_layer_patterns.argtypes = [C.c_int, C.c_double, C.c_double, C.POINTER(Pattern)]
-        L.fo_diffuse_sweep_uniform.argtypes = [C.c_int, C.c_int, dp, dp, C.c_double, C.c_int, dp, dp, dp, dp, dp,
+        L.fo_diffuse_sweep_uniform.argtypes = [C.c_int, C.c_int, dp, dp, dp, C.c_double, C.c_int, dp, dp, dp, dp, dp,
                                                C.c_int, C.c_int, dp]
-        L.fo_diffuse_sweep_tree.argtypes = [C.c_int, C.c_int64, C.POINTER(C.c_int32), C.c_int, dp, C.c_double,
+        L.fo_diffuse_sweep_tree.argtypes = [C.c_int, C.c_int64, C.POINTER(C.c_int32), C.c_int, dp, dp, dp, C.c_double,
                                             C.c_int, dp, dp, dp, dp, dp, C.c_int, C.c_int, dp]
         L.fo_compute_opacities.argtypes = [C.c_int64, C.c_int, dp, dp, dp, dp, dp]
         L.fo_compute_opacities.restype = None
@@ -107,23 +107,26 @@ def layer_patterns(n, phi, theta):
     return arr
 
 
-def sweep_uniform(n, kappa, box, phi, theta, w, uvb, eta=None, arith=ARITH_REFERENCE, order=ORDER_SERIAL,
+def sweep_uniform(n, kappa, box, phi, theta, w, uvb, eta=None, src=None, arith=ARITH_REFERENCE, order=ORDER_SERIAL,
                   with_noise=False):
     kappa = _f64(kappa)
     nnu = kappa.shape[0]
     assert kappa.shape == (nnu, n ** 3)
     phi, theta, w, uvb = map(_f64, (phi, theta, w, uvb))
     J = np.empty_like(kappa)
-    eta_p = _dp(_f64(eta)) if eta is not None else None
+    eta = _f64(eta) if eta is not None else None
+    src = _f64(src) if src is not None else None
+    eta_p = _dp(eta) if eta is not None else None
+    src_p = _dp(src) if src is not None else None
     noise = np.empty_like(kappa) if with_noise else None
-    rc = lib().fo_diffuse_sweep_uniform(n, nnu, _dp(kappa), eta_p, box, len(phi), _dp(phi), _dp(theta), _dp(w),
+    rc = lib().fo_diffuse_sweep_uniform(n, nnu, _dp(kappa), eta_p, src_p, box, len(phi), _dp(phi), _dp(theta), _dp(w),
                                         _dp(uvb), _dp(J), arith, order, _dp(noise) if with_noise else None)
     if rc:
         raise ValueError(f"fo_diffuse_sweep_uniform -> {rc}")
     return (J, noise) if with_noise else J
 
 
-def sweep_tree(n, level, kappa, box, phi, theta, w, uvb, arith=ARITH_REFERENCE, order=ORDER_SERIAL,
+def sweep_tree(n, level, kappa, box, phi, theta, w, uvb, eta=None, src=None, arith=ARITH_REFERENCE, order=ORDER_SERIAL,
                with_noise=False):
     kappa = _f64(kappa)
     level = np.ascontiguousarray(level, dtype=np.int32)
@@ -132,7 +135,10 @@ def sweep_tree(n, level, kappa, box, phi, theta, w, uvb, arith=ARITH_REFERENCE, 
     phi, theta, w, uvb = map(_f64, (phi, theta, w, uvb))
     J = np.empty_like(kappa)
     noise = np.empty_like(kappa) if with_noise else None
-    rc = lib().fo_diffuse_sweep_tree(n, ncell, level.ctypes.data_as(C.POINTER(C.c_int32)), nnu, _dp(kappa), box,
+    eta = _f64(eta) if eta is not None else None
+    src = _f64(src) if src is not None else None
+    rc = lib().fo_diffuse_sweep_tree(n, ncell, level.ctypes.data_as(C.POINTER(C.c_int32)), nnu, _dp(kappa),
+                                     _dp(eta) if eta is not None else None, _dp(src) if src is not None else None, box,
                                      len(phi), _dp(phi), _dp(theta), _dp(w), _dp(uvb), _dp(J), arith, order,
                                      _dp(noise) if with_noise else None)
     if rc:
@@ -153,6 +159,15 @@ def device_attenuation(tau):
     e, g = np.empty_like(tau), np.empty_like(tau)
     lib().fo_device_attenuation(tau.size, _dp(tau), _dp(e), _dp(g))
     return e, g
+
+
+def device_log(x):
+    x = _f64(x)
+    out = np.empty_like(x)
+    lib().fo_device_log.argtypes = [C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib().fo_device_log.restype = None
+    lib().fo_device_log(x.size, _dp(x), _dp(out))
+    return out
 
 
 def device_cell_mean(acc, nseg, w):

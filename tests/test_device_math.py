@@ -40,3 +40,17 @@ def test_cell_mean_equals_ieee_division():
     acc = rng.lognormal(0, 3, 200000) * 1e-21
     for nseg in (1, 2, 3):
         assert np.array_equal(O.device_cell_mean(acc, nseg, 0.013), acc / nseg * 0.013)
+
+
+def test_log1p_accuracy():
+    """ftte_log1p (used as log(Iin/Iout) = log1p((Iin-Iout)/Iout) in the emission path), through log(x) = log1p(x-1)."""
+    rng = np.random.default_rng(3)
+    x = np.concatenate([1 + 10 ** rng.uniform(-15.5, 0, 3000), 10 ** rng.uniform(0, 300, 3000), [2.0, np.sqrt(2), 1e308]])
+    y = O.device_log(x)
+    mp.mp.dps = 40
+    worst = 0.0
+    for a, b in zip(x, y):
+        t = mp.log1p(mp.mpf(float(a)) - 1)
+        worst = max(worst, float(abs(mp.mpf(float(b)) / t - 1)))
+    assert worst < 2.5 * EPS, worst
+    assert O.device_log(np.array([1.0]))[0] == 0.0

@@ -173,3 +173,41 @@ def test_opacities_follow_reference_order():
     k = O.compute_opacities(HI, HeI, HeII, beta)
     for g_ in range(5):
         assert np.array_equal(k[g_], HI * beta[0, g_] + HeI * beta[1, g_] + HeII * beta[2, g_])
+
+
+# ---- emission (the reference's never-enabled eta term, and the build's source function) ----------------------------------
+
+def _emitting_case():
+    from radiativetransfer_amd import synthetic
+    n = 12
+    kappa, uvb, box = synthetic.uniform_workload(n, 2, seed=2, tau_median=0.5)
+    phi, theta, w = O.healpix_directions(2)
+    rng = np.random.default_rng(1)
+    return n, kappa, uvb, box, phi, theta, w, rng.random(kappa.shape) * 2e-22, rng.random(kappa.shape) * 3e-21
+
+
+def test_zero_emissivity_array_equals_no_emissivity_in_reference_arithmetic():
+    """eta = 0 everywhere through the emission formula is the reference as shipped (nemi = 0., :673-678)."""
+    n, kappa, uvb, box, phi, theta, w, _, _ = _emitting_case()
+    a = O.sweep_uniform(n, kappa, box, phi, theta, w, uvb)
+    b = O.sweep_uniform(n, kappa, box, phi, theta, w, uvb, eta=np.zeros_like(kappa))
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("which", ["eta", "src", "both"])
+def test_emission_device_arithmetic_within_reference_noise(which):
+    n, kappa, uvb, box, phi, theta, w, eta, src = _emitting_case()
+    kw = dict(eta=eta) if which == "eta" else dict(src=src) if which == "src" else dict(eta=eta, src=src)
+    Jr, noise = O.sweep_uniform(n, kappa, box, phi, theta, w, uvb, with_noise=True, **kw)
+    Jd = O.sweep_uniform(n, kappa, box, phi, theta, w, uvb, arith=O.ARITH_DEVICE, **kw)
+    assert np.all(np.abs(Jd - Jr) <= 8 * noise)
+    assert np.max(noise / Jr) < 1e-8  # the bound is not vacuous
+
+
+def test_radiative_equilibrium_is_a_fixed_point():
+    """S = inflow everywhere: every segment returns Iout = Iin, J = inflow * sum(w).  The device arithmetic keeps this to
+    rounding; the reference's (Iin-Iout)/log(Iin/Iout) does not (its quotient is rounded before the logarithm)."""
+    n, kappa, uvb, box, phi, theta, w, _, _ = _emitting_case()
+    S = np.repeat(uvb[:, None], n ** 3, 1)
+    J = O.sweep_uniform(n, kappa, box, phi, theta, w, uvb, src=S, arith=O.ARITH_DEVICE)
+    assert np.allclose(J, uvb[:, None] * w.sum(), rtol=64 * EPS, atol=0)

@@ -218,8 +218,8 @@ def test_call_order_and_refusals(engine):
             e.transport([0.0], [0.4], [1.0], [1e-21])  # phi on a quadrant boundary: the reference stops
         assert err.value.status == "FTTE_ERR_PHI"
         with pytest.raises(rt.FtteError) as err:
-            e.set_emissivity(np.ones((1, 64)))
-        assert err.value.status == "FTTE_ERR_UNSUPPORTED"
+            e.set_option("rows", 5)
+        assert err.value.status == "FTTE_ERR_ARG"
 
 
 # ---- refined cell arrays (setRaysRefined / findNeighbours / transport with the coarse-neighbour rule) -----------------
@@ -303,6 +303,54 @@ def test_nested_patch_like_config4(engine):
     J2 = engine.transport(phi[[5, 29]], theta[[5, 29]], w[[5, 29]], uvb)
     ref = O.sweep_tree(n, level, kappa[sel], 1.0, phi[[5, 29]], theta[[5, 29]], w[[5, 29]], uvb[sel], arith=O.ARITH_DEVICE)
     assert np.array_equal(J2[sel], ref)
+
+
+# ---- emission: the reference's eta term (:676) and the build's source function -------------------------------------------
+
+@pytest.mark.parametrize("which", ["eta", "src"])
+def test_emission_uniform(engine, which):
+    n = 21
+    kappa, uvb, box = synthetic.uniform_workload(n, 3, seed=12, tau_median=0.4)
+    rng = np.random.default_rng(6)
+    x = rng.random(kappa.shape) * (2e-22 if which == "eta" else 3e-21)
+    kw = {which: x}
+    engine.set_uniform_grid(n, box)
+    engine.set_opacity(kappa)
+    (engine.set_emissivity if which == "eta" else engine.set_source_function)(x)
+    # one direction per izone: bit for bit against the device arithmetic on the host
+    for p, t in one_per_izone()[::3]:
+        phi, theta, w = np.array([p]), np.array([t]), np.array([0.4])
+        J = engine.transport(phi, theta, w, uvb)
+        assert np.array_equal(J, O.sweep_uniform(n, kappa, box, phi, theta, w, uvb, arith=O.ARITH_DEVICE, **kw))
+    # a direction set against the reference's formulae (libm exp/log, (Iin-Iout)/log(Iin/Iout))
+    phi, theta, w = O.healpix_directions(2)
+    J = engine.transport(phi, theta, w, uvb)
+    ref, noise = O.sweep_uniform(n, kappa, box, phi, theta, w, uvb, with_noise=True, **kw)
+    assert np.all(np.abs(J - ref) <= 8 * noise)
+    # switching emission off restores the reference as shipped
+    engine.set_emissivity(None)
+    J0 = engine.transport(phi, theta, w, uvb)
+    assert np.allclose(J0, O.sweep_uniform(n, kappa, box, phi, theta, w, uvb, arith=O.ARITH_DEVICE), rtol=SUM_RTOL, atol=0)
+
+
+def test_emission_refined_and_equilibrium(engine, golden):
+    g = golden("amr8_block_level1")
+    n = int(g["n"])
+    rng = np.random.default_rng(9)
+    S = rng.random(g["kappa"].shape) * 2e-21
+    engine.set_grid(n, g["level"], float(g["box"]))
+    engine.set_opacity(g["kappa"])
+    engine.set_source_function(S)
+    J = engine.transport(g["phi"], g["theta"], g["w"], g["uvb"])
+    ref = O.sweep_tree(n, g["level"], g["kappa"], float(g["box"]), g["phi"], g["theta"], g["w"], g["uvb"], src=S,
+                       arith=O.ARITH_DEVICE)
+    assert np.array_equal(J, ref)
+    # radiative equilibrium: S = inflow is a fixed point, on the refined grid too
+    Seq = np.repeat(g["uvb"][:, None], len(g["level"]), 1)
+    engine.set_source_function(Seq)
+    Jeq = engine.transport(g["phi"], g["theta"], g["w"], g["uvb"])
+    assert np.allclose(Jeq, g["uvb"][:, None] * g["w"].sum(), rtol=64 * EPS, atol=0)
+    engine.set_source_function(None)
 
 
 # ---- BASELINE size: properties that need no oracle run ------------------------------------------------------------
