@@ -57,8 +57,14 @@ module ftte_binding
      integer(c_int) function ftte_set_emissivity(ctx, eta) bind(C, name='ftte_set_emissivity')
        import :: c_ptr, c_int
        type(c_ptr), value :: ctx
-       type(c_ptr), value :: eta                ! c_null_ptr: the reference's zero emissivity
+       type(c_ptr), value :: eta                ! const double* (ncell, nnu); c_null_ptr: the reference's zero emissivity
      end function ftte_set_emissivity
+
+     integer(c_int) function ftte_set_source_function(ctx, S) bind(C, name='ftte_set_source_function')
+       import :: c_ptr, c_int
+       type(c_ptr), value :: ctx
+       type(c_ptr), value :: S                  ! const double* (ncell, nnu), or c_null_ptr: emission off
+     end function ftte_set_source_function
 
      integer(c_int) function ftte_diffuse_sweep(ctx, ndir, phi, theta, w, uvb, J) bind(C, name='ftte_diffuse_sweep')
        import :: c_ptr, c_int, c_double

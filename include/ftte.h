@@ -75,7 +75,8 @@ int ftte_set_grid(ftte_ctx *ctx, int nx, int ny, int nz, int64_t ncell, const in
  * kappa1..3 fields filled by computeOpacities (equiSources.f90:4977-4980); nnu is free
  * (the reference hard-wires 3 groups, definitionsModule.f90:169-171). */
 int ftte_set_opacity(ftte_ctx *ctx, int nnu, const double *kappa);
-/* Same, kappa already resident in device memory (not retained beyond the call). */
+/* Same, kappa already resident in device memory (not retained beyond the call).  The data must be complete when
+ * the call is made (synchronise the stream that produced it); the same holds for the other *_device setters. */
 int ftte_set_opacity_device(ftte_ctx *ctx, int nnu, const double *kappa_dev);
 /* computeOpacities itself (equiSources.f90:4956-4983) for nnu groups, on the device:
  * kappa_g = HI*beta[0][g] + HeI*beta[1][g] + HeII*beta[2][g] (left to right).
@@ -106,8 +107,9 @@ int ftte_set_source_function_device(ftte_ctx *ctx, const double *S_dev);
  * definitionsModule.f90:55-56), J[nnu][ncell] host memory, overwritten. */
 int ftte_diffuse_sweep(ftte_ctx *ctx, int ndir, const double *phi, const double *theta, const double *w,
                        const double *uvb, double *J);
-/* Same with J in device memory.  `stream` is a hipStream_t (NULL = the context's own stream);
- * the call is asynchronous with respect to the host, ordered on that stream. */
+/* Same with J in device memory.  `stream` is a hipStream_t; NULL = the context's own stream, a blocking stream,
+ * i.e. one that is implicitly ordered with the legacy default stream.  The call is asynchronous with respect to the
+ * host, ordered on that stream. */
 int ftte_diffuse_sweep_device(ftte_ctx *ctx, int ndir, const double *phi, const double *theta, const double *w,
                               const double *uvb, double *J_dev, void *stream);
 

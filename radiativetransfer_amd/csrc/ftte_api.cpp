@@ -489,7 +489,7 @@ int ftte_create(ftte_ctx **out, int ndev, const int *dev_ids)
         return fail(nullptr, FTTE_ERR_NO_DEVICE, std::string("ftte_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName);
     ftte_ctx *c = new ftte_ctx;
     c->device = dev;
-    if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamDefault) != hipSuccess) {
         delete c;
         return fail(nullptr, FTTE_ERR_NO_DEVICE, "ftte_create: cannot create a stream on the device");
     }
@@ -582,6 +582,7 @@ int ftte_set_opacity_device(ftte_ctx *c, int nnu, const double *kappa_dev)
     FTTE_HIP(c, hipSetDevice(c->device));
     if ((rc = ensure_kappa(c, nnu))) return rc;
     FTTE_HIP(c, hipMemcpyAsync(c->kappa[0], kappa_dev, sizeof(double) * nnu * c->ncell, hipMemcpyDeviceToDevice, c->stream));
+    FTTE_HIP(c, hipStreamSynchronize(c->stream)); // the sweep may run on another stream: the copy must have landed
     c->nnu = nnu;
     c->kappa_ready[0] = true; c->kappa_ready[1] = c->kappa_ready[2] = false;
     return FTTE_OK;
@@ -624,7 +625,7 @@ static int set_emission(ftte_ctx *c, int mode, const double *values, bool on_dev
     if (!c->emis[0]) FTTE_HIP(c, hipMalloc((void **)&c->emis[0], sizeof(double) * c->kappa_cap));
     const size_t bytes = sizeof(double) * (size_t)c->nnu * c->ncell;
     FTTE_HIP(c, hipMemcpyAsync(c->emis[0], values, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
-    if (!on_device) FTTE_HIP(c, hipStreamSynchronize(c->stream));
+    FTTE_HIP(c, hipStreamSynchronize(c->stream)); // the sweep may run on another stream: the copy must have landed
     c->emit_mode = mode;
     c->emis_ready[0] = true; c->emis_ready[1] = c->emis_ready[2] = false;
     (void)who;

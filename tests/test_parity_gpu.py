@@ -353,6 +353,33 @@ def test_emission_refined_and_equilibrium(engine, golden):
     engine.set_source_function(None)
 
 
+def test_source_iteration_against_host_restatement_and_thick_limit(engine):
+    """Lambda iteration S = (1-eps) J + eps B: three iterations reproduce the same loop done with the oracle on the host;
+    in an optically thick box the interior converges to J = B."""
+    import torch
+    from radiativetransfer_amd.iteration import SourceIteration
+    n, nnu, eps = 16, 2, 0.5
+    kappa = np.stack([np.full(n ** 3, 3.0 * n), np.full(n ** 3, 1.5 * n)])  # tau = 3 and 1.5 per cell
+    phi, theta, w = O.healpix_directions(2)
+    uvb = np.array([1e-21, 1e-21])
+    B = np.array([5e-21, 2e-21])
+    engine.set_uniform_grid(n, 1.0)
+    engine.set_opacity(kappa)
+    it = SourceIteration(engine, nnu, n ** 3, phi, theta, w, uvb, eps, B)
+    J_host = np.zeros((nnu, n ** 3))
+    for k in range(3):
+        it.step()
+        S = (1 - eps) * J_host + eps * B[:, None]
+        J_host = O.sweep_uniform(n, kappa, 1.0, phi, theta, w, uvb, src=S, arith=O.ARITH_DEVICE)
+        assert np.allclose(it.J.cpu().numpy(), J_host, rtol=1e-13, atol=0), k
+    hist = it.run(40, tol=1e-10)
+    assert hist[-1] < 1e-10 and all(b <= a * 1.0001 for a, b in zip(hist[5:], hist[6:]))
+    J = it.J.cpu().numpy().reshape(nnu, n, n, n)
+    core = J[:, 6:10, 6:10, 6:10]
+    assert np.allclose(core, B[:, None, None, None], rtol=2e-3)
+    engine.set_source_function(None)
+
+
 # ---- BASELINE size: properties that need no oracle run ------------------------------------------------------------
 
 @pytest.fixture(scope="module")
