@@ -97,6 +97,27 @@ int fo_diffuse_sweep_tree(int n, int64_t ncell, const int32_t *level, int nnu, c
 void fo_compute_opacities(int64_t ncell, int nnu, const double *HI, const double *HeI, const double *HeII,
                           const double *beta, double *kappa);
 
+/* ---- point sources (ftte_oracle_point.c) -------------------------------------------------------------------------- */
+/* dustCrossSection, dustModule.f90:30-73 (SMC fit); a_smc: [7][5] row-major */
+double fo_dust_cross_section(double lambda_um, const double *a_smc);
+/* stellarBetaTable.f90: tables [6][11^4] = reactionRate1..3, energyRate1..3, flat index ((idust*11+i3)*11+i2)*11+i1;
+ * spec [5][37][1221] log10(erg/s/A), wavelength [1221] cm ascending; iSpectrum, iMetal 1-based;
+ * output_sigma [4][300] (24, 25, 26, dust) or NULL */
+void fo_stellar_beta_table(const double *a_smc, const double *wavelength, const double *spec, int iSpectrum, double coefSpectrum,
+                           int iMetal, double coefMetal, double *tables, double *total_integral, double *output_sigma);
+/* getRatesHydrogenHelium, equiSources.f90:4157-4311 */
+void fo_get_rates(const double *tables, int dust, int reaction, double tau1, double tau2, double tau3, double tau_dust,
+                  double *number_rate, double *heating_rate);
+/* rmax(1:30), equiSources.f90:304-309 */
+void fo_rmax(double *rmax);
+/* the per-source loop equiSources.f90:1256-1329 with startNewLongRay (:3120-3385); rates [6][ncell] = krate24, krate25,
+ * krate26, crate24, crate25, crate26, overwritten; src_leaf 0-based cell-array indices; src_ndot = float(weight) */
+int fo_point_sources(int n, int64_t ncell, const int32_t *level, const double *HI, const double *HeI, const double *HeII,
+                     const double *rho, const double *abun2, double box, int dust, int nsrc, const int64_t *src_leaf,
+                     const double *src_ndot, const double *tables, double *rates, int *highest_pixel_level,
+                     const double *pix /* may be NULL: (phi,theta) of all pixels of levels 1..pix_levels, concatenated */,
+                     int pix_levels);
+
 /* radiativetransfer_amd/csrc/ftte_math.h evaluated on the host, element-wise (for tests of the
  * device arithmetic itself): e = exp(-tau), g = (1-exp(-tau))/tau; out = (acc/nseg)*w. */
 void fo_device_attenuation(int64_t count, const double *tau, double *e, double *g);

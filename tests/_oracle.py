@@ -22,7 +22,7 @@ class Pattern(C.Structure):
 
 
 def build():
-    src = [os.path.join(ORACLE_DIR, f) for f in ("ftte_oracle.c", "ftte_oracle.h")]
+    src = [os.path.join(ORACLE_DIR, f) for f in ("ftte_oracle.c", "ftte_oracle_point.c", "ftte_oracle.h")]
     src.append(os.path.join(ROOT, "radiativetransfer_amd", "csrc", "ftte_math.h"))
     if not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in src):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-B", "libftte_oracle.so"], stdout=subprocess.DEVNULL)
@@ -175,3 +175,62 @@ def device_cell_mean(acc, nseg, w):
     out = np.empty_like(acc)
     lib().fo_device_cell_mean(acc.size, _dp(acc), nseg, w, _dp(out))
     return out
+
+
+# ---- point sources ------------------------------------------------------------------------------------------------------
+NT = 11 ** 4
+
+
+def stellar_beta_table(a_smc, wavelength, spec, iSpectrum, coefSpectrum, iMetal, coefMetal, with_sigma=False):
+    a_smc, wavelength, spec = _f64(a_smc), _f64(wavelength), _f64(spec)
+    tables = np.empty((6, NT))
+    total = C.c_double()
+    sig = np.empty((4, 300)) if with_sigma else None
+    L = lib()
+    L.fo_stellar_beta_table.restype = None
+    L.fo_stellar_beta_table.argtypes = [C.POINTER(C.c_double)] * 3 + [C.c_int, C.c_double, C.c_int, C.c_double,
+                                                                       C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                                                       C.POINTER(C.c_double)]
+    L.fo_stellar_beta_table(_dp(a_smc), _dp(wavelength), _dp(spec), iSpectrum, coefSpectrum, iMetal, coefMetal, _dp(tables),
+                            C.byref(total), _dp(sig) if with_sigma else None)
+    return (tables, total.value, sig) if with_sigma else (tables, total.value)
+
+
+def get_rates(tables, dust, reaction, tau):
+    L = lib()
+    L.fo_get_rates.restype = None
+    L.fo_get_rates.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_int] + [C.c_double] * 4 + [C.POINTER(C.c_double)] * 2
+    nr, hr = C.c_double(), C.c_double()
+    tables = _f64(tables)
+    L.fo_get_rates(_dp(tables), dust, reaction, *[float(t) for t in tau], C.byref(nr), C.byref(hr))
+    return nr.value, hr.value
+
+
+def rmax_table():
+    out = np.empty(30)
+    lib().fo_rmax.restype = None
+    lib().fo_rmax.argtypes = [C.POINTER(C.c_double)]
+    lib().fo_rmax(_dp(out))
+    return out
+
+
+def point_sources(n, level, HI, HeI, HeII, rho, abun2, box, dust, src_leaf, src_ndot, tables, pix=None):
+    level = np.ascontiguousarray(level, dtype=np.int32)
+    HI, HeI, HeII, rho, abun2, tables, src_ndot = map(_f64, (HI, HeI, HeII, rho, abun2, tables, src_ndot))
+    src_leaf = np.ascontiguousarray(src_leaf, dtype=np.int64)
+    rates = np.empty((6, len(level)))
+    hp = C.c_int()
+    L = lib()
+    dp = C.POINTER(C.c_double)
+    L.fo_point_sources.argtypes = [C.c_int, C.c_int64, C.POINTER(C.c_int32), dp, dp, dp, dp, dp, C.c_double, C.c_int, C.c_int,
+                                   C.POINTER(C.c_int64), dp, dp, dp, C.POINTER(C.c_int), dp, C.c_int]
+    pix_levels = 0
+    if pix is not None:
+        pix_levels = len(pix)
+        pix = _f64(np.concatenate([np.asarray(p).reshape(-1, 2) for p in pix]))
+    rc = L.fo_point_sources(n, len(level), level.ctypes.data_as(C.POINTER(C.c_int32)), _dp(HI), _dp(HeI), _dp(HeII), _dp(rho),
+                            _dp(abun2), box, dust, len(src_leaf), src_leaf.ctypes.data_as(C.POINTER(C.c_int64)), _dp(src_ndot),
+                            _dp(tables), _dp(rates), C.byref(hp), _dp(pix) if pix is not None else None, pix_levels)
+    if rc:
+        raise ValueError(f"fo_point_sources -> {rc}")
+    return rates, hp.value
