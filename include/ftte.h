@@ -113,6 +113,68 @@ int ftte_diffuse_sweep(ftte_ctx *ctx, int ndir, const double *phi, const double 
 int ftte_diffuse_sweep_device(ftte_ctx *ctx, int ndir, const double *phi, const double *theta, const double *w,
                               const double *uvb, double *J_dev, void *stream);
 
+/* ---- point sources ---------------------------------------------------------------------------
+ * The `runStellarTransfer` block, equiSources.f90:1256-1370: for each star particle build the rate
+ * tables of its population (stellarBetaTable), then send 12 HEALPix rays from the centre of its host
+ * cell; a ray splits into its four daughter pixels after rmax(level) cells (startNewLongRay,
+ * :3120-3385), crosses cells with drawSegment (:2412-2595) and the neighbour search
+ * (find/zoom??Neighbour, :2647-2960), and deposits in every cell it crosses
+ * ndot * (R(depth) - R(depth + tau)) for the three photo-reactions, R from the tables
+ * (getRatesHydrogenHelium, :4157-4311).
+ *
+ * Host sequence, mirroring the reference:
+ *   ftte_set_grid; ftte_set_medium; ftte_set_zero_rates;
+ *   per population: ftte_stellar_beta_table (or ftte_set_rate_tables); ftte_point_sources(stars of it);
+ *   ftte_get_point_rates.
+ * Rates accumulate on the device between ftte_set_zero_rates and ftte_get_point_rates. */
+
+#define FTTE_TABLE_SIZE 14641 /* (ndepth+1)^4 = 11^4, definitionsModule.f90:72-77 */
+#define FTTE_MAX_PIXEL_LEVEL 6 /* maxPixelLevel, equiSources.f90:9 */
+
+/* stellarBetaTable(nfbins, frequencyBinWidth, totalIntegral, iSpectrum, coefSpectrum, iMetal, coefMetal),
+ * stellarBetaTable.f90:3-289, with the module data it reads passed explicitly, all as the Fortran
+ * arrays lie in memory: a_smc(7,5) (read at dustModule.f90:16-21), wavelength(nwave) [cm, ascending],
+ * specificLuminosity(nmetal, nspectrum, nwave) (definitionsModule.f90:270; 5 x 37 x 1221 in the
+ * reference).  iSpectrum, iMetal are 1-based.  The six tables reactionRate1..3, energyRate1..3 are
+ * accumulated on the device over the 399 frequency bins and stay there; total_integral (may be NULL)
+ * is the reference's totalIntegral. */
+int ftte_stellar_beta_table(ftte_ctx *ctx, const double *a_smc, int nwave, const double *wavelength_cm, int nspectrum,
+                            int nmetal, const double *specific_luminosity, int iSpectrum, double coefSpectrum, int iMetal,
+                            double coefMetal, double *total_integral);
+/* Tables computed elsewhere (e.g. by the reference itself): tables[6][FTTE_TABLE_SIZE], order
+ * reactionRate1, 2, 3, energyRate1, 2, 3, each the Fortran array (0:ndepth,0:ndepth,0:ndepth,0:ndepth)
+ * (tau1, tau2, tau3, tauDust) as it lies in memory. */
+int ftte_set_rate_tables(ftte_ctx *ctx, const double *tables);
+int ftte_get_rate_tables(ftte_ctx *ctx, double *tables);
+/* getRatesHydrogenHelium(reaction, tau1, tau2, tau3, tauDust, numberRate, heatingRate),
+ * equiSources.f90:4157-4311, for nsample depth tuples and all three reactions, evaluated on the device:
+ * tau[nsample][4], rates[nsample][3][2] = (numberRate, heatingRate) per reaction.
+ * dust_approximation: 0 noDust, 1 dust ~ HI, 2 dust ~ total hydrogen (definitionsModule.f90:87). */
+int ftte_get_rates_hydrogen_helium(ftte_ctx *ctx, int dust_approximation, int nsample, const double *tau, double *rates);
+/* Cell fields the tracer reads (zoneType HI, HeI, HeII, rho, abun2, definitionsModule.f90:163-168), cell-array
+ * order, ncell each.  rho / abun2 may be NULL when the dust approximation does not read them. */
+int ftte_set_medium(ftte_ctx *ctx, const double *HI, const double *HeI, const double *HeII, const double *rho,
+                    const double *abun2, int dust_approximation);
+int ftte_set_medium_device(ftte_ctx *ctx, const double *HI, const double *HeI, const double *HeII, const double *rho,
+                           const double *abun2, int dust_approximation);
+/* setZeroRates, equiSources.f90:4128-4155 */
+int ftte_set_zero_rates(ftte_ctx *ctx);
+/* localizeCellFromStar, equiSources.f90:2597-2620: the star's call sequence position(1:3*(level+1)) (base
+ * indices 1..n, then child indices 1..2 per level) -> 0-based cell-array index of its host cell. */
+int ftte_locate_cell(ftte_ctx *ctx, int level, const int32_t *position, int64_t *cell);
+/* The per-star loop body, equiSources.f90:1268-1329, for nsrc stars that share the current tables:
+ * src_cell[nsrc] host cells (0-based cell-array index), src_ndot[nsrc] = float(weight).  Adds into the device
+ * rates.  highest_pixel_level (may be NULL): the largest value of the reference's highestPixelLevel over
+ * these stars.  Deposition uses fp64 atomics: the last bits of the sums depend on the run. */
+int ftte_point_sources(ftte_ctx *ctx, int nsrc, const int64_t *src_cell, const double *src_ndot, int *highest_pixel_level);
+/* rates[6][ncell]: krate24, krate25, krate26, crate24, crate25, crate26 (zoneType, definitionsModule.f90:166) */
+int ftte_get_point_rates(ftte_ctx *ctx, double *rates);
+int ftte_point_rates_device(ftte_ctx *ctx, double **rates_dev);
+/* rmax(1:30), equiSources.f90:296-309 (formula, halved) */
+int ftte_rmax(double *rmax30);
+/* dustCrossSection(lambda [micron]), dustModule.f90:30-73, SMC curve; a_smc(7,5) Fortran order */
+double ftte_dust_cross_section(double lambda_micron, const double *a_smc);
+
 /* ---- tuning and instrumentation ------------------------------------------------------------- */
 
 /* Tuning knobs: "rows" (rays per lane: 4, 8 or 16), "stack" (wavefronts per workgroup, stacked

@@ -47,6 +47,20 @@ SIGNATURES = {
     "ftte_set_source_function_device": (C.c_int, [_vp, _vp]),
     "ftte_diffuse_sweep": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     "ftte_diffuse_sweep_device": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, _vp, _vp]),
+    "ftte_stellar_beta_table": (C.c_int, [_vp, _dp, C.c_int, _dp, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_int,
+                                          C.c_double, _dp]),
+    "ftte_set_rate_tables": (C.c_int, [_vp, _dp]),
+    "ftte_get_rate_tables": (C.c_int, [_vp, _dp]),
+    "ftte_get_rates_hydrogen_helium": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp]),
+    "ftte_set_medium": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, C.c_int]),
+    "ftte_set_medium_device": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int]),
+    "ftte_set_zero_rates": (C.c_int, [_vp]),
+    "ftte_locate_cell": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "ftte_point_sources": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int64), _dp, _ip]),
+    "ftte_get_point_rates": (C.c_int, [_vp, _dp]),
+    "ftte_point_rates_device": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "ftte_rmax": (C.c_int, [_dp]),
+    "ftte_dust_cross_section": (C.c_double, [C.c_double, _dp]),
     "ftte_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "ftte_launch_count": (C.c_int, [_vp]),
     "ftte_launch_info": (C.c_int, [_vp, C.c_int, _dp, C.POINTER(C.c_int64)]),

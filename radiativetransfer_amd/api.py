@@ -16,7 +16,7 @@ import numpy as np
 from . import _lib
 from ._lib import FtteError, Pattern
 
-__all__ = ["DiffuseTransfer", "FtteError", "Pattern", "pix2ang_nest", "healpix_directions", "fold_direction",
+__all__ = ["DiffuseTransfer", "StellarTransfer", "rmax", "dust_cross_section", "FtteError", "Pattern", "pix2ang_nest", "healpix_directions", "fold_direction",
            "rotate_indices", "set_pattern", "layer_patterns", "compute_cell_intensity"]
 
 
@@ -207,3 +207,117 @@ class DiffuseTransfer:
             self._ok(self._lib.ftte_launch_info(self._ctx, i, C.byref(ms), C.byref(upd)))
             out.append((ms.value, upd.value))
         return out
+
+
+# ---- point sources ---------------------------------------------------------------------------------------
+
+TABLE_SHAPE = (6, 11, 11, 11, 11)  # reactionRate1..3, energyRate1..3; then [tauDust][tau3][tau2][tau1]
+RATE_NAMES = ("krate24", "krate25", "krate26", "crate24", "crate25", "crate26")
+
+
+def rmax() -> np.ndarray:
+    """rmax(1:30) of equiSources.f90:296-309: path length (cells) after which a ray of pixel level L splits."""
+    out = np.empty(30)
+    _check(_lib.load().ftte_rmax(_dp(out)), "ftte_rmax")
+    return out
+
+
+def dust_cross_section(lambda_micron: float, a_smc) -> float:
+    """dustCrossSection (dustModule.f90:30-73), SMC curve; a_smc[7][5] as the rows of the reference's data file."""
+    a = np.asfortranarray(_f64(a_smc).reshape(7, 5))
+    return float(_lib.load().ftte_dust_cross_section(float(lambda_micron), a.ctypes.data_as(C.POINTER(C.c_double))))
+
+
+class StellarTransfer(DiffuseTransfer):
+    """The `if (runStellarTransfer)` block of the reference driver (equiSources.f90:1256-1370) on one GPU.
+
+        st = StellarTransfer(device=0)
+        st.set_grid(n, level, box_cm)
+        st.set_medium(HI, HeI, HeII, rho, abun2, dust_approximation)
+        st.set_zero_rates()
+        st.stellar_beta_table(a_smc, wavelength_cm, specific_luminosity, iSpectrum, cS, iMetal, cM)
+        st.point_sources(cells, ndot)            # the stars of that population
+        rates = st.rates()                       # [6][ncell]: krate24, 25, 26, crate24, 25, 26
+    """
+
+    def stellar_beta_table(self, a_smc, wavelength_cm, specific_luminosity, i_spectrum: int, coef_spectrum: float,
+                           i_metal: int, coef_metal: float) -> float:
+        """stellarBetaTable (stellarBetaTable.f90).  specific_luminosity[nmetal][nspectrum][nwave] (log10, as the
+        reference's library); i_spectrum, i_metal 1-based.  Returns totalIntegral; the tables stay on the device."""
+        a = np.asfortranarray(_f64(a_smc).reshape(7, 5))
+        wl = _f64(wavelength_cm)
+        sl = _f64(specific_luminosity)
+        if sl.ndim != 3 or sl.shape[2] != wl.size:
+            raise ValueError("specific_luminosity must have shape [nmetal][nspectrum][nwave]")
+        slf = np.asfortranarray(sl)  # the Fortran array specificLuminosity(nmetal, nspectrum, nwave)
+        total = C.c_double()
+        self._ok(self._lib.ftte_stellar_beta_table(
+            self._ctx, a.ctypes.data_as(C.POINTER(C.c_double)), wl.size, _dp(wl), sl.shape[1], sl.shape[0],
+            slf.ctypes.data_as(C.POINTER(C.c_double)), int(i_spectrum), float(coef_spectrum), int(i_metal),
+            float(coef_metal), C.byref(total)))
+        return total.value
+
+    def set_rate_tables(self, tables):
+        tables = _f64(tables)
+        if tables.size != int(np.prod(TABLE_SHAPE)):
+            raise ValueError("tables must have shape [6][11][11][11][11]")
+        self._ok(self._lib.ftte_set_rate_tables(self._ctx, _dp(tables)))
+
+    def rate_tables(self) -> np.ndarray:
+        out = np.empty(TABLE_SHAPE)
+        self._ok(self._lib.ftte_get_rate_tables(self._ctx, _dp(out)))
+        return out
+
+    def get_rates_hydrogen_helium(self, tau, dust_approximation: int = 0) -> np.ndarray:
+        """getRatesHydrogenHelium (equiSources.f90:4157) for tau[nsample][4] = (tau1, tau2, tau3, tauDust);
+        returns [nsample][3][2] = (numberRate, heatingRate) per reaction, evaluated on the device."""
+        tau = _f64(tau).reshape(-1, 4)
+        out = np.empty((tau.shape[0], 3, 2))
+        self._ok(self._lib.ftte_get_rates_hydrogen_helium(self._ctx, int(dust_approximation), tau.shape[0], _dp(tau), _dp(out)))
+        return out
+
+    def set_medium(self, HI, HeI, HeII, rho=None, abun2=None, dust_approximation: int = 0):
+        f = [None if a is None else _f64(a) for a in (HI, HeI, HeII, rho, abun2)]
+        for a in f:
+            if a is not None and self.ncell and a.size != self.ncell:
+                raise ValueError("cell fields must have ncell elements")
+        self._ok(self._lib.ftte_set_medium(self._ctx, *[None if a is None else _dp(a) for a in f], int(dust_approximation)))
+
+    def set_medium_device(self, HI: int, HeI: int, HeII: int, rho: int = 0, abun2: int = 0, dust_approximation: int = 0):
+        self._ok(self._lib.ftte_set_medium_device(self._ctx, *[C.c_void_p(p) if p else None for p in (HI, HeI, HeII, rho, abun2)],
+                                                  int(dust_approximation)))
+
+    def set_zero_rates(self):
+        """setZeroRates (equiSources.f90:4128)."""
+        self._ok(self._lib.ftte_set_zero_rates(self._ctx))
+
+    def locate_cell(self, position: Sequence[int]) -> int:
+        """localizeCellFromStar (equiSources.f90:2597): call sequence (1-based) -> 0-based cell-array index."""
+        pos = np.ascontiguousarray(position, dtype=np.int32)
+        if pos.size % 3 or pos.size < 3:
+            raise ValueError("a call sequence has 3 (level + 1) entries")
+        cell = C.c_int64()
+        self._ok(self._lib.ftte_locate_cell(self._ctx, pos.size // 3 - 1, pos.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(cell)))
+        return cell.value
+
+    def point_sources(self, cells, ndot) -> int:
+        """Trace the stars in `cells` (0-based cell-array indices) with photon rates `ndot` through the medium, adding
+        to the rates on the device.  Returns highestPixelLevel."""
+        cells = np.ascontiguousarray(cells, dtype=np.int64)
+        ndot = _f64(ndot)
+        if cells.size != ndot.size:
+            raise ValueError("cells and ndot must have equal length")
+        highest = C.c_int()
+        self._ok(self._lib.ftte_point_sources(self._ctx, cells.size, cells.ctypes.data_as(C.POINTER(C.c_int64)), _dp(ndot),
+                                              C.byref(highest)))
+        return highest.value
+
+    def rates(self) -> np.ndarray:
+        out = np.empty((6, max(self.ncell, 1)))
+        self._ok(self._lib.ftte_get_point_rates(self._ctx, _dp(out)))
+        return out
+
+    def rates_device_ptr(self) -> int:
+        p = C.c_void_p()
+        self._ok(self._lib.ftte_point_rates_device(self._ctx, C.byref(p)))
+        return p.value

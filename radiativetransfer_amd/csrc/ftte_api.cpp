@@ -19,6 +19,7 @@
 #include "ftte_geometry.h"
 #include "ftte_internal.h"
 #include "ftte_kernels.h"
+#include "ftte_point.h"
 
 using namespace ftte;
 
@@ -115,6 +116,8 @@ struct ftte_ctx {
     std::vector<double> forest_key; // phi, theta, w of the cached forests (+ box)
     double *amr_Iout = nullptr, *amr_mean = nullptr;
     size_t amr_scratch_cap = 0; // elements per array
+
+    PointState point; // point sources: rate tables, medium, tracer scratch
 };
 
 namespace {
@@ -513,6 +516,7 @@ int ftte_destroy(ftte_ctx *c)
     free_forests(c);
     if (c->amr_Iout) (void)hipFree(c->amr_Iout);
     if (c->amr_mean) (void)hipFree(c->amr_mean);
+    c->point.release();
     for (auto &t : c->timing) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -551,6 +555,7 @@ int ftte_set_grid(ftte_ctx *c, int nx, int ny, int nz, int64_t ncell, const int3
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     free_forests(c);
+    c->point.drop_grid();
     c->n = nx; c->ncell = ncell; c->box = box_cm; c->grid_set = true;
     c->kappa_ready[0] = c->kappa_ready[1] = c->kappa_ready[2] = false;
     c->plan.valid = false;
@@ -856,6 +861,150 @@ void ftte_compute_cell_intensity(double *Jmean, double Iin, double Iout)
     // evaluates the same mean through ftte_math.h)
     if (Iout < Iin) *Jmean += (Iin - Iout) / std::log(Iin / Iout);
     else *Jmean += 0.5 * (Iin + Iout);
+}
+
+// ---- point sources --------------------------------------------------------------------------------------------
+
+int ftte_stellar_beta_table(ftte_ctx *c, const double *a_smc, int nwave, const double *wavelength_cm, int nspectrum, int nmetal,
+                            const double *specific_luminosity, int iSpectrum, double coefSpectrum, int iMetal, double coefMetal,
+                            double *total_integral)
+{
+    if (!c) return FTTE_ERR_ARG;
+    if (!a_smc || !wavelength_cm || !specific_luminosity || nwave < 2 || nspectrum < 2 || nmetal < 2)
+        return fail(c, FTTE_ERR_ARG, "ftte_stellar_beta_table: bad argument");
+    if (iSpectrum < 1 || iSpectrum + 1 > nspectrum || iMetal < 1 || iMetal + 1 > nmetal)
+        return fail(c, FTTE_ERR_ARG, "ftte_stellar_beta_table: iSpectrum / iMetal outside the library");
+    FTTE_HIP(c, hipSetDevice(c->device));
+    const int rc = point_stellar_beta_table(c->point, c->stream, a_smc, nwave, wavelength_cm, nspectrum, nmetal, specific_luminosity,
+                                            iSpectrum, coefSpectrum, iMetal, coefMetal, total_integral, &c->err);
+    return rc;
+}
+
+int ftte_set_rate_tables(ftte_ctx *c, const double *tables)
+{
+    if (!c) return FTTE_ERR_ARG;
+    if (!tables) return fail(c, FTTE_ERR_ARG, "ftte_set_rate_tables: bad argument");
+    FTTE_HIP(c, hipSetDevice(c->device));
+    return point_set_tables(c->point, c->stream, tables, &c->err);
+}
+
+int ftte_get_rate_tables(ftte_ctx *c, double *tables)
+{
+    if (!c) return FTTE_ERR_ARG;
+    if (!tables) return fail(c, FTTE_ERR_ARG, "ftte_get_rate_tables: bad argument");
+    FTTE_HIP(c, hipSetDevice(c->device));
+    return point_get_tables(c->point, c->stream, tables, &c->err);
+}
+
+int ftte_get_rates_hydrogen_helium(ftte_ctx *c, int dust_approximation, int nsample, const double *tau, double *rates)
+{
+    if (!c) return FTTE_ERR_ARG;
+    if (nsample < 0 || (nsample && (!tau || !rates)) || dust_approximation < 0 || dust_approximation > 2)
+        return fail(c, FTTE_ERR_ARG, "ftte_get_rates_hydrogen_helium: bad argument");
+    if (!nsample) return FTTE_OK;
+    FTTE_HIP(c, hipSetDevice(c->device));
+    return point_lookup(c->point, c->stream, dust_approximation, nsample, tau, rates, &c->err);
+}
+
+static int set_medium(ftte_ctx *c, const double *HI, const double *HeI, const double *HeII, const double *rho, const double *abun2,
+                      int dust, bool on_device, const char *who)
+{
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (!HI || !HeI || !HeII || dust < 0 || dust > 2) return fail(c, FTTE_ERR_ARG, std::string(who) + ": bad argument");
+    if ((dust >= 1 && !abun2) || (dust == 2 && !rho)) return fail(c, FTTE_ERR_ARG, std::string(who) + ": this dust approximation needs abun2 (and rho)");
+    FTTE_HIP(c, hipSetDevice(c->device));
+    const double *const field[5] = {HI, HeI, HeII, rho, abun2};
+    return point_set_medium(c->point, c->stream, c->ncell, field, on_device, dust, &c->err);
+}
+
+int ftte_set_medium(ftte_ctx *c, const double *HI, const double *HeI, const double *HeII, const double *rho, const double *abun2,
+                    int dust_approximation)
+{
+    return set_medium(c, HI, HeI, HeII, rho, abun2, dust_approximation, false, "ftte_set_medium");
+}
+
+int ftte_set_medium_device(ftte_ctx *c, const double *HI, const double *HeI, const double *HeII, const double *rho,
+                           const double *abun2, int dust_approximation)
+{
+    return set_medium(c, HI, HeI, HeII, rho, abun2, dust_approximation, true, "ftte_set_medium_device");
+}
+
+int ftte_set_zero_rates(ftte_ctx *c)
+{
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    FTTE_HIP(c, hipSetDevice(c->device));
+    if ((rc = point_zero_rates(c->point, c->stream, c->ncell, &c->err))) return rc;
+    FTTE_HIP(c, hipStreamSynchronize(c->stream));
+    return FTTE_OK;
+}
+
+int ftte_locate_cell(ftte_ctx *c, int level, const int32_t *position, int64_t *cell)
+{
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (level < 0 || !position || !cell) return fail(c, FTTE_ERR_ARG, "ftte_locate_cell: bad argument");
+    const int n = c->n;
+    for (int q = 0; q < 3; ++q)
+        if (position[q] < 1 || position[q] > n) return fail(c, FTTE_ERR_ARG, "ftte_locate_cell: base index outside 1..n");
+    int32_t node = ((position[0] - 1) * n + (position[1] - 1)) * n + (position[2] - 1);
+    for (int l = 0; l < level; ++l) {
+        // localizeCellFromStar, equiSources.f90:2597-2620
+        if (c->tree.child0[node] < 0) return fail(c, FTTE_ERR_LEVELS, "error in star particle position: cell not refined");
+        const int32_t *p = position + 3 * l + 3;
+        for (int q = 0; q < 3; ++q)
+            if (p[q] < 1 || p[q] > 2) return fail(c, FTTE_ERR_ARG, "ftte_locate_cell: child index outside 1..2");
+        node = c->tree.child0[node] + 4 * (p[0] - 1) + 2 * (p[1] - 1) + (p[2] - 1);
+    }
+    if (c->tree.leaf[node] < 0) return fail(c, FTTE_ERR_LEVELS, "ftte_locate_cell: the call sequence ends on a refined cell");
+    *cell = c->tree.leaf[node];
+    return FTTE_OK;
+}
+
+int ftte_point_sources(ftte_ctx *c, int nsrc, const int64_t *src_cell, const double *src_ndot, int *highest_pixel_level)
+{
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (nsrc < 0 || (nsrc && (!src_cell || !src_ndot))) return fail(c, FTTE_ERR_ARG, "ftte_point_sources: bad argument");
+    if (highest_pixel_level) *highest_pixel_level = 0;
+    if (!nsrc) return FTTE_OK;
+    FTTE_HIP(c, hipSetDevice(c->device));
+    return point_trace(c->point, c->stream, c->tree, c->box, nsrc, src_cell, src_ndot, highest_pixel_level, &c->err);
+}
+
+int ftte_get_point_rates(ftte_ctx *c, double *rates)
+{
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (!rates) return fail(c, FTTE_ERR_ARG, "ftte_get_point_rates: bad argument");
+    if (!c->point.rates || c->point.rates_cells != c->ncell) return fail(c, FTTE_ERR_STATE, "no rates: call ftte_set_zero_rates / ftte_point_sources first");
+    FTTE_HIP(c, hipSetDevice(c->device));
+    FTTE_HIP(c, hipMemcpyAsync(rates, c->point.rates, sizeof(double) * 6 * c->ncell, hipMemcpyDeviceToHost, c->stream));
+    FTTE_HIP(c, hipStreamSynchronize(c->stream));
+    return FTTE_OK;
+}
+
+int ftte_point_rates_device(ftte_ctx *c, double **rates_dev)
+{
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (!rates_dev) return fail(c, FTTE_ERR_ARG, "ftte_point_rates_device: bad argument");
+    if (!c->point.rates || c->point.rates_cells != c->ncell) return fail(c, FTTE_ERR_STATE, "no rates: call ftte_set_zero_rates / ftte_point_sources first");
+    *rates_dev = c->point.rates;
+    return FTTE_OK;
+}
+
+int ftte_rmax(double *rmax30)
+{
+    if (!rmax30) return FTTE_ERR_ARG;
+    rmax_table(rmax30);
+    return FTTE_OK;
+}
+
+double ftte_dust_cross_section(double lambda_micron, const double *a_smc)
+{
+    return dust_cross_section(lambda_micron, a_smc);
 }
 
 } // extern "C"

@@ -93,4 +93,54 @@ struct AmrLevelRec {
     ftte_consts math;
 };
 
+// ---- point sources (ftte_point.cpp) --------------------------------------------------------------------------------
+constexpr int kTableDepths = 11;                    // ndepth + 1, definitionsModule.f90:72
+constexpr int kTableSize = 11 * 11 * 11 * 11;       // one rate table
+constexpr int kMaxPixelLevel = 6;                   // localDefinitions, equiSources.f90:9
+constexpr int kPixelCount = 12 * (4096 - 1) / 3;    // pixels of levels 1..6: 12 (4^6 - 1)/3 = 16380
+
+// One frequency bin of stellarBetaTable as the table kernel needs it
+struct FreqBin {
+    double dtmp;                 // photons/s in the bin
+    double r24, r26, r25, rdust; // sigma(nu)/sigma(threshold) per absorber: multiplies the tabulated depth
+    double excess[3];            // (nu - nu_threshold) in erg, per reaction; < 0: below threshold, bin does not count
+};
+
+// A ray waiting to be split into its four daughter pixels (startNewLongRay, equiSources.f90:3280-3383)
+struct SplitRec {
+    double pos[3];   // absolute position of the split point, box units (absoluteCoordinates)
+    double radius;   // base-cell units
+    double depth[4]; // tau1, tau2, tau3, tauDust accumulated so far
+    double ndot;     // photons/s carried by the parent ray
+    int32_t pixel;   // parent's NESTED index at its level
+    int32_t pad;
+};
+
+struct TraceRec {
+    // tree (AmrTree on the device)
+    const int32_t *parent, *child0, *leaf;
+    const int8_t *level;
+    int32_t n;
+    int32_t dust;     // dustApproximation: 0 none, 1 ~HI, 2 ~total H
+    int64_t ncell;
+    double box;
+    // medium, cell-array order
+    const double *HI, *HeI, *HeII, *rho, *abun2;
+    const double *logtab;  // [6][11^4] natural logs of the rate tables
+    const double *pixdir;  // [kPixelCount][3] unit vectors of all pixels of levels 1..6
+    double rmax[kMaxPixelLevel + 1];
+    double *rates;         // [6][ncell] krate24, krate25, krate26, crate24, crate25, crate26
+    // this launch: rays of `pixel_level`
+    int32_t pixel_level;
+    int32_t nrays;         // level 1: 12 * nsources; else 4 * number of split records
+    const int32_t *src_node;  // level 1: host leaf node of each source
+    const double *src_ndot;
+    const SplitRec *in;    // level > 1
+    SplitRec *out;         // rays of this level that split
+    int32_t *out_count;
+    int32_t out_capacity;
+    int32_t *highest_level;
+    int32_t *error;
+};
+
 } // namespace ftte

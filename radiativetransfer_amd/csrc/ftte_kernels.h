@@ -22,4 +22,10 @@ int launch_opacity(const double *HI, const double *HeI, const double *HeII, cons
 int launch_amr_level(const AmrLevelRec &A, hipStream_t stream);
 int launch_amr_combine(const AmrLevelRec &A, double *J, bool zero_first, hipStream_t stream);
 
+// point sources: table accumulation (P3), logs of user tables, one pixel level of the tracer (P1 + P2)
+int launch_rate_table(const FreqBin *bins, int nbins, double *tables, double *logtab, hipStream_t stream);
+int launch_rate_lookup(const double *logtab, int dust, int nsample, const double *tau, double *out, hipStream_t stream);
+int launch_log_table(const double *tables, double *logtab, hipStream_t stream);
+int launch_point_trace(const TraceRec &T, hipStream_t stream);
+
 } // namespace ftte

@@ -554,6 +554,315 @@ int launch_amr_combine(const AmrLevelRec &A, double *J, bool zero_first, hipStre
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Point sources.  The reference follows each source's 12 base HEALPix rays depth-first, splitting a ray
+// into its four daughter pixels when it has travelled rmax(level) cells (startNewLongRay,
+// equiSources.f90:3120-3385).  Here the recursion is unrolled breadth-first by pixel level: one launch
+// per level, a thread per ray; a ray that must split appends its state to a queue that seeds the next
+// launch (four threads per record).  The tree walk (find/zoom??Neighbour, :2647-2960) uses node indices
+// instead of the reference's call sequences: a node's position inside its parent is its index offset.
+// Rates are deposited with hardware fp64 atomics (the only order-dependent step of the whole library:
+// sums over rays differ in the last bits from run to run).
+// ------------------------------------------------------------------------------------------------
+
+// stellarBetaTable's accumulation over frequency bins, one thread per depth tuple (stellarBetaTable.f90:217-285)
+__global__ void __launch_bounds__(256) rate_table_kernel(const FreqBin *__restrict__ bins, int nbins, double *__restrict__ tables,
+                                                         double *__restrict__ logtab)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= kTableSize) return;
+    const int i1 = t % 11, i2 = (t / 11) % 11, i3 = (t / 121) % 11, id = t / 1331;
+    // float(idepth)/float(ndepth)*maxOpticalDepth: a single-precision quotient widened, :236-242
+    const double d1 = (double)((float)i1 / 10.f) * 10.0, d2 = (double)((float)i2 / 10.f) * 10.0;
+    const double d3 = (double)((float)i3 / 10.f) * 10.0, dd = (double)((float)id / 10.f) * 10.0;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < nbins; ++b) {
+        const FreqBin B = bins[b];
+        const double t1 = B.r24 * d1, t2 = B.r26 * d2, t3 = B.r25 * d3, td = B.rdust * dd;
+        const double a = B.dtmp * exp(-(t1 + t2 + t3 + td));
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            if (B.excess[r] >= 0.0) { acc[r] = acc[r] + a; acc[3 + r] = acc[3 + r] + B.excess[r] * a; }
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) { tables[r * kTableSize + t] = acc[r]; logtab[r * kTableSize + t] = log(acc[r]); }
+}
+
+__global__ void __launch_bounds__(256) log_table_kernel(const double *__restrict__ tables, double *__restrict__ logtab)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 6 * kTableSize) logtab[t] = log(tables[t]);
+}
+
+// getRatesHydrogenHelium, equiSources.f90:4157-4311, on the table of logarithms
+__device__ __forceinline__ void lookup_rates(const double *__restrict__ logtab, int dust, int reaction, double tau1, double tau2,
+                                             double tau3, double taud, double &number_rate, double &heating_rate)
+{
+    if (tau1 > 10.0 || tau2 > 10.0 || tau3 > 10.0 || taud > 10.0) { number_rate = 0.0; heating_rate = 0.0; return; }
+    const int i1 = (int)(tau1 / 10.0 * 10.0), i2 = (int)(tau2 / 10.0 * 10.0), i3 = (int)(tau3 / 10.0 * 10.0);
+    const double c1 = tau1 * 10.0 / 10.0 - (double)i1, c2 = tau2 * 10.0 / 10.0 - (double)i2, c3 = tau3 * 10.0 / 10.0 - (double)i3;
+    int id = 0;
+    double cd = 0.0;
+    if (dust != 0) { id = (int)(taud / 10.0 * 10.0); cd = taud * 10.0 / 10.0 - (double)id; }
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        const double *R = logtab + (size_t)((which ? 3 : 0) + reaction - 1) * kTableSize;
+        double v[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const double *P = R + (((size_t)(id + q) * 11 + i3) * 11 + i2) * 11 + i1;
+            // min(): the reference reads one past the table at tau == 10 exactly; stay inside
+            const int s1 = i1 < 10 ? 1 : 0, s2 = i2 < 10 ? 11 : 0, s3 = i3 < 10 ? 121 : 0;
+            v[q] = c1 * ((1. - c3) * (1. - c2) * P[s1] + c3 * (1. - c2) * P[s1 + s3] + c2 * (1. - c3) * P[s1 + s2] + c3 * c2 * P[s1 + s2 + s3]) +
+                   (1. - c1) * ((1. - c3) * (1. - c2) * P[0] + c3 * (1. - c2) * P[s3] + c2 * (1. - c3) * P[s2] + c3 * c2 * P[s2 + s3]);
+            if (id + q >= 10 && q == 0) { v[1] = v[0]; break; } // dust index 10: no slab above
+        }
+        const double out = exp((1. - cd) * v[0] + cd * v[1]);
+        if (which) heating_rate = out; else number_rate = out;
+    }
+}
+
+struct Neighbour { int node; double a, b; bool boundary; };
+
+// zoom??Neighbour, equiSources.f90:2827-2960: down into the leaf that holds (a,b) on the face the ray crosses.
+// axis: 0 the ray crosses an x face (coordinates y,z), 1 a y face (x,z), 2 a z face (x,y).
+__device__ __forceinline__ Neighbour zoom(const TraceRec &T, int c, double a, double b, int axis, int side)
+{
+    while (T.child0[c] >= 0) {
+        const int ia = a < 0.5 ? 0 : 1, ib = b < 0.5 ? 0 : 1;
+        a = ia ? 2. * a - 1. : 2. * a;
+        b = ib ? 2. * b - 1. : 2. * b;
+        const int ic = side == 0 ? 1 : 0; // coming down through the face (side 0): the child on the far side
+        int i, j, k;
+        if (axis == 2) { i = ia; j = ib; k = ic; }
+        else if (axis == 0) { i = ic; j = ia; k = ib; }
+        else { i = ia; j = ic; k = ib; }
+        c = T.child0[c] + 4 * i + 2 * j + k;
+    }
+    Neighbour N;
+    N.node = c; N.a = a; N.b = b; N.boundary = false;
+    return N;
+}
+
+// find??Neighbour, equiSources.f90:2647-2825
+__device__ __forceinline__ Neighbour find_neighbour(const TraceRec &T, int c, double a, double b, int axis, int side)
+{
+    const int pos = axis == 2 ? 2 : (axis == 0 ? 0 : 1);
+    const int pa = axis == 2 ? 0 : (axis == 0 ? 1 : 0), pb = axis == 2 ? 1 : 2;
+    int lvl = T.level[c];
+    while (lvl > 0) {
+        const int par = T.parent[c];
+        const int idx = c - T.child0[par];
+        int ijk[3] = {(idx >> 2) & 1, (idx >> 1) & 1, idx & 1};
+        if ((side == 0 && ijk[pos] == 0) || (side == 1 && ijk[pos] == 1)) {
+            a = ijk[pa] == 0 ? 0.5 * a : 0.5 * a + 0.5;
+            b = ijk[pb] == 0 ? 0.5 * b : 0.5 * b + 0.5;
+            c = par;
+            --lvl;
+        } else {
+            ijk[pos] = side == 0 ? 0 : 1;
+            return zoom(T, T.child0[par] + 4 * ijk[0] + 2 * ijk[1] + ijk[2], a, b, axis, side);
+        }
+    }
+    const int n = T.n;
+    int ijk[3] = {c / (n * n), (c / n) % n, c % n};
+    if ((side == 0 && ijk[pos] == 0) || (side == 1 && ijk[pos] == n - 1)) {
+        Neighbour N;
+        N.node = -1; N.a = a; N.b = b; N.boundary = true;
+        return N;
+    }
+    ijk[pos] += side == 0 ? -1 : 1;
+    return zoom(T, (ijk[0] * n + ijk[1]) * n + ijk[2], a, b, axis, side);
+}
+
+__global__ void __launch_bounds__(64) point_trace_kernel(const TraceRec T)
+{
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= T.nrays) return;
+    const int L = T.pixel_level;
+    const int n = T.n;
+    const double fn = (double)(float)n;
+    int pixel, cell;
+    double pt[3], radius, d1, d2, d3, dd, ndot;
+    const int level_off = 4 * ((1 << (2 * (L - 1))) - 1); // 12 (4^(L-1) - 1) / 3
+
+    if (L == 1) {
+        const int s = tid / 12;
+        pixel = tid % 12;
+        cell = T.src_node[s];
+        pt[0] = pt[1] = pt[2] = 0.5;
+        radius = 0.0; d1 = d2 = d3 = dd = 0.0;
+        ndot = T.src_ndot[s] / 12.0;
+    } else {
+        const SplitRec R = T.in[tid >> 2];
+        const int which = tid & 3;
+        pixel = 4 * R.pixel + which;
+        const double *pd = T.pixdir + 3 * (size_t)(4 * ((1 << (2 * (L - 2))) - 1) + R.pixel);
+        double base[3] = {0, 0, 0};
+        // the reference walks the four daughters in order and gives up on the rest once one starts outside the box
+        // (strategy = boundary is never reset, equiSources.f90:3336-3345): daughter `which` exists only if it and all
+        // its elder sisters start inside
+        for (int sis = 0; sis <= which; ++sis) {
+            const double *cd = T.pixdir + 3 * (size_t)(level_off + 4 * R.pixel + sis);
+            base[0] = R.pos[0] + R.radius / fn * (cd[0] - pd[0]);
+            base[1] = R.pos[1] + R.radius / fn * (cd[1] - pd[1]);
+            base[2] = R.pos[2] + R.radius / fn * (cd[2] - pd[2]);
+            if (base[0] < 0. || base[0] > 1. || base[1] < 0. || base[1] > 1. || base[2] < 0. || base[2] > 1.) return;
+        }
+        // localizeSplitContinuationCell, :3049-3118
+        int ijk[3];
+        for (int q = 0; q < 3; ++q) {
+            ijk[q] = (int)(base[q] * n);
+            if (ijk[q] < 0 || ijk[q] >= n) { atomicMax(T.error, 1); return; }
+            pt[q] = base[q] * fn - (double)(float)ijk[q];
+        }
+        cell = (ijk[0] * n + ijk[1]) * n + ijk[2];
+        while (T.child0[cell] >= 0) {
+            int h[3];
+            for (int q = 0; q < 3; ++q) { h[q] = pt[q] < 0.5 ? 0 : 1; pt[q] = h[q] ? 2. * pt[q] - 1. : 2. * pt[q]; }
+            cell = T.child0[cell] + 4 * h[0] + 2 * h[1] + h[2];
+        }
+        radius = R.radius; d1 = R.depth[0]; d2 = R.depth[1]; d3 = R.depth[2]; dd = R.depth[3];
+        ndot = R.ndot / 4.0;
+    }
+    if (pt[0] < 0. || pt[0] > 1. || pt[1] < 0. || pt[1] > 1. || pt[2] < 0. || pt[2] > 1.) { atomicMax(T.error, 2); return; }
+
+    const double *dir = T.pixdir + 3 * (size_t)(level_off + pixel);
+    const double prox = dir[0], proy = dir[1], proz = dir[2];
+    const double rm = T.rmax[L];
+    const long nc = T.ncell;
+    bool split = false;
+    for (int step = 0; step < 1000000; ++step) {
+        // ---- drawSegment, :2412-2595
+        const int lvl = T.level[cell];
+        const double scale = (double)(1 << lvl);
+        const double t1 = proz > 0. ? (1. - pt[2]) / proz : -pt[2] / proz;
+        const double t2 = prox > 0. ? (1. - pt[0]) / prox : -pt[0] / prox;
+        const double t3 = proy > 0. ? (1. - pt[1]) / proy : -pt[1] / proy;
+        int axis;
+        double len;
+        if (t1 < fmin(t2, t3)) { axis = 2; len = t1; }
+        else if (t2 < fmin(t1, t3)) { axis = 0; len = t2; }
+        else { axis = 1; len = t3; }
+        bool stop = false;
+        Neighbour N;
+        N.node = -1; N.a = N.b = 0.0; N.boundary = false;
+        int side = 0;
+        if (radius * scale + len < rm || L == kMaxPixelLevel) {
+            radius = radius + len / scale;
+            const double ex = pt[0] + len * prox, ey = pt[1] + len * proy, ez = pt[2] + len * proz;
+            if (axis == 2) { side = proz < 0. ? 0 : 1; N = find_neighbour(T, cell, ex, ey, 2, side); }
+            else if (axis == 0) { side = prox < 0. ? 0 : 1; N = find_neighbour(T, cell, ey, ez, 0, side); }
+            else { side = proy < 0. ? 0 : 1; N = find_neighbour(T, cell, ex, ez, 1, side); }
+            stop = N.boundary;
+        } else if (radius * scale >= rm) {
+            split = true; len = 0.0;
+        } else {
+            split = true;
+            len = rm - radius * scale;
+            radius = radius + len / scale;
+            pt[0] = pt[0] + len * prox; pt[1] = pt[1] + len * proy; pt[2] = pt[2] + len * proz;
+        }
+        // ---- optical depths of the piece and what it absorbs, :3176-3269
+        const double cell_size = T.box / ((double)((float)(1 << lvl) * (float)n));
+        const double path = cell_size * len;
+        const long c = T.leaf[cell];
+        const double tau1 = path * T.HI[c] * (double)6.3e-18f, tau2 = path * T.HeI[c] * (double)7.42e-18f,
+                     tau3 = path * T.HeII[c] * (double)1.58e-18f;
+        double taud = 0.0;
+        if (T.dust == 1) taud = path * T.HI[c] * (double)5.4116737e-22f * T.abun2[c] / (double)0.2f;
+        else if (T.dust == 2) taud = path * (double)0.76f * T.rho[c] / (double)1.6726231e-24f * (double)5.4116737e-22f * T.abun2[c] / (double)0.2f;
+        if (fmin(fmin(d1 + tau1, d2 + tau2), fmin(d3 + tau3, dd + taud)) > 100.) { stop = true; split = false; }
+        double a, b, ea, eb;
+        lookup_rates(T.logtab, T.dust, 1, d1, d2, d3, dd, a, ea);
+        lookup_rates(T.logtab, T.dust, 1, d1 + tau1, d2, d3, dd, b, eb);
+        unsafeAtomicAdd(&T.rates[0 * nc + c], ndot * (a - b));
+        unsafeAtomicAdd(&T.rates[3 * nc + c], ndot * (ea - eb));
+        lookup_rates(T.logtab, T.dust, 2, d1, d2, d3, dd, a, ea);
+        lookup_rates(T.logtab, T.dust, 2, d1, d2 + tau2, d3, dd, b, eb);
+        unsafeAtomicAdd(&T.rates[2 * nc + c], ndot * (a - b));
+        unsafeAtomicAdd(&T.rates[5 * nc + c], ndot * (ea - eb));
+        lookup_rates(T.logtab, T.dust, 3, d1, d2, d3, dd, a, ea);
+        lookup_rates(T.logtab, T.dust, 3, d1, d2, d3 + tau3, dd, b, eb);
+        unsafeAtomicAdd(&T.rates[1 * nc + c], ndot * (a - b));
+        unsafeAtomicAdd(&T.rates[4 * nc + c], ndot * (ea - eb));
+        d1 = d1 + tau1; d2 = d2 + tau2; d3 = d3 + tau3; dd = dd + taud;
+        if (stop || split) break;
+        // ---- into the neighbour, :2512-2558
+        const double face = side == 0 ? 1. : 0.;
+        if (axis == 2) { pt[2] = face; pt[0] = N.a; pt[1] = N.b; }
+        else if (axis == 0) { pt[0] = face; pt[1] = N.a; pt[2] = N.b; }
+        else { pt[1] = face; pt[0] = N.a; pt[2] = N.b; }
+        if (pt[0] < 0. || pt[0] > 1. || pt[1] < 0. || pt[1] > 1. || pt[2] < 0. || pt[2] > 1.) { atomicMax(T.error, 3); return; }
+        cell = N.node;
+        if (step == 999999) atomicMax(T.error, 4);
+    }
+    if (!split) return;
+
+    // ---- hand the ray over to its four daughters: absoluteCoordinates, :3011-3047
+    atomicMax(T.highest_level, L + 1);
+    double p[3] = {pt[0], pt[1], pt[2]};
+    int c = cell;
+    for (int lvl = T.level[c]; lvl > 0; --lvl) {
+        const int par = T.parent[c];
+        const int idx = c - T.child0[par];
+        const int h[3] = {(idx >> 2) & 1, (idx >> 1) & 1, idx & 1};
+        for (int q = 0; q < 3; ++q) p[q] = h[q] == 0 ? 0.5 * p[q] : 0.5 * p[q] + 0.5;
+        c = par;
+    }
+    const int bi[3] = {c / (n * n), (c / n) % n, c % n};
+    const int slot = atomicAdd(T.out_count, 1);
+    if (slot >= T.out_capacity) { atomicMax(T.error, 5); return; }
+    SplitRec R;
+    for (int q = 0; q < 3; ++q) R.pos[q] = ((double)(float)bi[q] + p[q]) / fn;
+    R.radius = radius;
+    R.depth[0] = d1; R.depth[1] = d2; R.depth[2] = d3; R.depth[3] = dd;
+    R.ndot = ndot;
+    R.pixel = pixel;
+    R.pad = 0;
+    T.out[slot] = R;
+}
+
+// getRatesHydrogenHelium for a list of depth tuples: tau[nsample][4] -> out[nsample][3][2] (number rate, heating rate)
+__global__ void __launch_bounds__(256) rate_lookup_kernel(const double *__restrict__ logtab, int dust, int nsample,
+                                                          const double *__restrict__ tau, double *__restrict__ out)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsample) return;
+    for (int r = 1; r <= 3; ++r) {
+        double a, e;
+        lookup_rates(logtab, dust, r, tau[4 * s], tau[4 * s + 1], tau[4 * s + 2], tau[4 * s + 3], a, e);
+        out[6 * s + 2 * (r - 1)] = a;
+        out[6 * s + 2 * (r - 1) + 1] = e;
+    }
+}
+
+int launch_rate_lookup(const double *logtab, int dust, int nsample, const double *tau, double *out, hipStream_t stream)
+{
+    if (nsample <= 0) return 0;
+    hipLaunchKernelGGL(rate_lookup_kernel, dim3((nsample + 255) / 256), dim3(256), 0, stream, logtab, dust, nsample, tau, out);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_rate_table(const FreqBin *bins, int nbins, double *tables, double *logtab, hipStream_t stream)
+{
+    hipLaunchKernelGGL(rate_table_kernel, dim3((kTableSize + 255) / 256), dim3(256), 0, stream, bins, nbins, tables, logtab);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_log_table(const double *tables, double *logtab, hipStream_t stream)
+{
+    hipLaunchKernelGGL(log_table_kernel, dim3((6 * kTableSize + 255) / 256), dim3(256), 0, stream, tables, logtab);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_point_trace(const TraceRec &T, hipStream_t stream)
+{
+    if (T.nrays <= 0) return 0;
+    hipLaunchKernelGGL(point_trace_kernel, dim3((T.nrays + 63) / 64), dim3(64), 0, stream, T);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 // kappa[g][c] = HI[c]*beta[0][g] + HeI[c]*beta[1][g] + HeII[c]*beta[2][g]   (equiSources.f90:4977-4980)
 __global__ void __launch_bounds__(256) opacity_kernel(const double *__restrict__ HI, const double *__restrict__ HeI,
                                                       const double *__restrict__ HeII, const double *__restrict__ beta,

@@ -1,0 +1,359 @@
+// ftte_point.cpp -- host side of the point-source path.  See ftte_point.h.
+#include "ftte_point.h"
+
+#include <cmath>
+#include <cstring>
+
+#include "ftte_geometry.h"
+#include "ftte_kernels.h"
+
+namespace ftte {
+
+namespace {
+
+// The reference writes most constants as default-real literals; they reach the double-precision arithmetic widened
+// from single precision.  W() spells that out.
+#define W(x) ((double)(x##f))
+
+const double kHydrogen = W(13.598), kHeI = W(24.587), kHeII = W(54.418); // definitionsModule.f90:30-32
+inline double c_light() { return W(2.99792458e10); }
+inline double ev_to_erg() { return 1.60217646e-12; }
+inline double ev_to_hz() { return 1.60217646e-12 / W(6.6260693e-27); }
+inline double pi_ref() { return (double)3.141592654f; }
+
+inline double pow4(double x) { return x * x * x * x; }
+
+int hip_fail(std::string *err, const char *what, hipError_t e)
+{
+    *err = std::string(what) + ": " + hipGetErrorString(e);
+    return FTTE_ERR_NO_DEVICE;
+}
+
+#define POINT_HIP(call)                                                                                            \
+    do {                                                                                                           \
+        hipError_t e_ = (call);                                                                                    \
+        if (e_ != hipSuccess) return hip_fail(err, #call, e_);                                                     \
+    } while (0)
+
+template <class T> int ensure(T *&p, size_t count, std::string *err)
+{
+    if (p) return 0;
+    POINT_HIP(hipMalloc((void **)&p, sizeof(T) * count));
+    return 0;
+}
+
+template <class T> void drop(T *&p)
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+// hydrogenic photoionisation cross-section above threshold, stellarBetaTable.f90:40-44 and :52-56
+inline double hydrogenic(double sigma0, double threshold, double nu)
+{
+    const double dum = std::sqrt(nu / threshold - 1);
+    return sigma0 * pow4(threshold / nu) * std::exp(4.0 - 4.0 * std::atan(dum) / dum) / (1 - std::exp(-2.0 * pi_ref() / dum));
+}
+
+} // namespace
+
+void PointState::drop_grid()
+{
+    drop(parent); drop(child0); drop(leaf); drop(level);
+    tree_ready = false;
+    for (auto &m : medium) drop(m);
+    medium_cells = 0;
+    medium_ready = false;
+    drop(rates);
+    rates_cells = 0;
+}
+
+void PointState::release()
+{
+    drop_grid();
+    drop(tables); drop(logtab); drop(bins); drop(pixdir);
+    drop(queue[0]); drop(queue[1]); drop(counters); drop(src_node); drop(src_ndot); drop(sample_in); drop(sample_out);
+    tables_ready = false;
+    queue_capacity = src_capacity = sample_capacity = 0;
+}
+
+double dust_cross_section(double lambda_um, const double *a_smc)
+{
+    double sigma = 0.0;
+    for (int i = 0; i < 7; ++i) {
+        // a_smc(i,1:5): lambda_i, a_i, b_i, p_i, q_i
+        const double l = a_smc[i], a = a_smc[i + 7], b = a_smc[i + 14], p = a_smc[i + 21], q = a_smc[i + 28];
+        const double x = lambda_um / l;
+        sigma = sigma + a / (std::pow(x, p) + std::pow(x, -q) + b);
+    }
+    return W(1.1) * sigma * (double)0.9210340372f;
+}
+
+double stellar_population(const double *spec, int nmetal, int nspectrum, int nwave, const double *wavelength, int iSpectrum,
+                          double cS, int iMetal, double cM, double freq_ev)
+{
+    auto SL = [&](int m, int s, int w) { return spec[(size_t)(m - 1) + (size_t)nmetal * ((size_t)(s - 1) + (size_t)nspectrum * (size_t)(w - 1))]; };
+    const double lam = c_light() / (freq_ev * ev_to_hz());
+    int iw = 1;
+    while (iw + 1 < nwave && lam > wavelength[iw]) ++iw;
+    double cw = (lam - wavelength[iw - 1]) / (wavelength[iw] - wavelength[iw - 1]);
+    cw = std::fmin(std::fmax(0.0, cw), 1.0);
+    const double sp1 = cS * ((1.0 - cw) * SL(iMetal, iSpectrum + 1, iw) + cw * 1.0 * SL(iMetal, iSpectrum + 1, iw + 1)) +
+                       (1.0 - cS) * ((1.0 - cw) * SL(iMetal, iSpectrum, iw) + cw * SL(iMetal, iSpectrum, iw + 1));
+    const double sp2 = cS * ((1.0 - cw) * SL(iMetal + 1, iSpectrum + 1, iw) + cw * 1.0 * SL(iMetal + 1, iSpectrum + 1, iw + 1)) +
+                       (1.0 - cS) * ((1.0 - cw) * SL(iMetal + 1, iSpectrum, iw) + cw * SL(iMetal + 1, iSpectrum, iw + 1));
+    double sp = (1.0 - cM) * sp1 + cM * sp2;
+    const double nu_hz = freq_ev * ev_to_hz();
+    sp = std::pow(10.0, sp) / W(1.e-8) * c_light() / (nu_hz * nu_hz);
+    return sp;
+}
+
+void rmax_table(double *rmax30)
+{
+    for (int ir = 1; ir <= 30; ++ir) {
+        const float v = std::sqrt(3.f) * (std::sqrt(0.5f * std::pow(4.f, (float)(ir - 1)) - 1.f / 12.f) + 0.5f);
+        rmax30[ir - 1] = (double)v / 2.0;
+    }
+}
+
+int point_stellar_beta_table(PointState &P, hipStream_t stream, const double *a_smc, int nwave, const double *wavelength,
+                             int nspectrum, int nmetal, const double *spec, int iSpectrum, double cS, int iMetal, double cM,
+                             double *total_integral, std::string *err)
+{
+    // the frequency grid and the cross-sections on it, stellarBetaTable.f90:27-66
+    static thread_local double nu[kFrequencies], s24[kFrequencies], s25[kFrequencies], s26[kFrequencies], sd[kFrequencies];
+    const double freqdel = W(0.02);
+    for (int i = 0; i < kFrequencies; ++i) {
+        nu[i] = std::pow(10.0, (double)i * freqdel);
+        const double lambda = c_light() / (nu[i] * ev_to_hz()) * W(1.e8); // Angstrom
+        sd[i] = dust_cross_section(lambda / W(1.e4), a_smc) * W(1.e-22);
+        s24[i] = nu[i] > kHydrogen ? hydrogenic(W(6.3e-18), kHydrogen, nu[i]) : 0.0;
+        s25[i] = nu[i] > kHeII ? hydrogenic(W(1.58e-18), kHeII, nu[i]) : 0.0;
+        s26[i] = nu[i] > kHeI ? W(7.42e-18) * (W(1.66) * std::pow(nu[i] / kHeI, (double)(-2.05f)) -
+                                               W(0.66) * std::pow(nu[i] / kHeI, (double)(-3.05f)))
+                              : 0.0;
+    }
+    // what every depth tuple needs from a frequency bin, :217-232 and :243-246
+    std::vector<FreqBin> bins(kFrequencies - 1);
+    double total = 0.0;
+    const double thr[3] = {kHydrogen, kHeI, kHeII};
+    for (int i = 1; i < kFrequencies; ++i) {
+        const double freq = nu[i], delta_nu = nu[i] - nu[i - 1];
+        const double lum = stellar_population(spec, nmetal, nspectrum, nwave, wavelength, iSpectrum, cS, iMetal, cM, freq);
+        FreqBin &B = bins[i - 1];
+        B.dtmp = lum / (freq * ev_to_erg()) * delta_nu * ev_to_hz();
+        if (freq >= kHydrogen) total = total + B.dtmp;
+        B.r24 = s24[i] / W(6.3e-18);
+        B.r26 = s26[i] / W(7.42e-18);
+        B.r25 = s25[i] / W(1.58e-18);
+        B.rdust = sd[i] / W(5.4116737e-22);
+        for (int r = 0; r < 3; ++r) B.excess[r] = freq >= thr[r] ? (freq - thr[r]) * ev_to_erg() : -1.0;
+    }
+    if (total_integral) *total_integral = total;
+
+    int rc;
+    if ((rc = ensure(P.tables, (size_t)6 * kTableSize, err))) return rc;
+    if ((rc = ensure(P.logtab, (size_t)6 * kTableSize, err))) return rc;
+    if ((rc = ensure(P.bins, (size_t)kFrequencies, err))) return rc;
+    POINT_HIP(hipMemcpyAsync(P.bins, bins.data(), sizeof(FreqBin) * bins.size(), hipMemcpyHostToDevice, stream));
+    if (launch_rate_table(P.bins, (int)bins.size(), P.tables, P.logtab, stream)) { *err = "rate table kernel failed to launch"; return FTTE_ERR_NO_DEVICE; }
+    POINT_HIP(hipStreamSynchronize(stream)); // `bins` leaves scope
+    P.tables_ready = true;
+    return 0;
+}
+
+int point_set_tables(PointState &P, hipStream_t stream, const double *tables, std::string *err)
+{
+    int rc;
+    if ((rc = ensure(P.tables, (size_t)6 * kTableSize, err))) return rc;
+    if ((rc = ensure(P.logtab, (size_t)6 * kTableSize, err))) return rc;
+    POINT_HIP(hipMemcpyAsync(P.tables, tables, sizeof(double) * 6 * kTableSize, hipMemcpyHostToDevice, stream));
+    if (launch_log_table(P.tables, P.logtab, stream)) { *err = "table kernel failed to launch"; return FTTE_ERR_NO_DEVICE; }
+    POINT_HIP(hipStreamSynchronize(stream));
+    P.tables_ready = true;
+    return 0;
+}
+
+int point_get_tables(PointState &P, hipStream_t stream, double *tables, std::string *err)
+{
+    if (!P.tables_ready) { *err = "no rate tables: call ftte_stellar_beta_table or ftte_set_rate_tables first"; return FTTE_ERR_STATE; }
+    POINT_HIP(hipMemcpyAsync(tables, P.tables, sizeof(double) * 6 * kTableSize, hipMemcpyDeviceToHost, stream));
+    POINT_HIP(hipStreamSynchronize(stream));
+    return 0;
+}
+
+int point_lookup(PointState &P, hipStream_t stream, int dust, int nsample, const double *tau, double *rates, std::string *err)
+{
+    if (!P.tables_ready) { *err = "no rate tables: call ftte_stellar_beta_table or ftte_set_rate_tables first"; return FTTE_ERR_STATE; }
+    if (nsample > P.sample_capacity) {
+        drop(P.sample_in); drop(P.sample_out);
+        P.sample_capacity = 0;
+        POINT_HIP(hipMalloc((void **)&P.sample_in, sizeof(double) * 4 * nsample));
+        POINT_HIP(hipMalloc((void **)&P.sample_out, sizeof(double) * 6 * nsample));
+        P.sample_capacity = nsample;
+    }
+    POINT_HIP(hipMemcpyAsync(P.sample_in, tau, sizeof(double) * 4 * nsample, hipMemcpyHostToDevice, stream));
+    if (launch_rate_lookup(P.logtab, dust, nsample, P.sample_in, P.sample_out, stream)) { *err = "look-up kernel failed to launch"; return FTTE_ERR_NO_DEVICE; }
+    POINT_HIP(hipMemcpyAsync(rates, P.sample_out, sizeof(double) * 6 * nsample, hipMemcpyDeviceToHost, stream));
+    POINT_HIP(hipStreamSynchronize(stream));
+    return 0;
+}
+
+int point_set_medium(PointState &P, hipStream_t stream, int64_t ncell, const double *const field[5], bool on_device, int dust,
+                     std::string *err)
+{
+    if (P.medium_cells != ncell) {
+        for (auto &m : P.medium) drop(m);
+        P.medium_cells = 0;
+        P.medium_ready = false;
+    }
+    for (int f = 0; f < 5; ++f) {
+        int rc;
+        if ((rc = ensure(P.medium[f], (size_t)ncell, err))) return rc;
+        if (field[f])
+            POINT_HIP(hipMemcpyAsync(P.medium[f], field[f], sizeof(double) * ncell, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
+        else
+            POINT_HIP(hipMemsetAsync(P.medium[f], 0, sizeof(double) * ncell, stream)); // rho, abun2 are only read with dust
+    }
+    POINT_HIP(hipStreamSynchronize(stream));
+    P.medium_cells = ncell;
+    P.dust = dust;
+    P.medium_ready = true;
+    return 0;
+}
+
+int point_zero_rates(PointState &P, hipStream_t stream, int64_t ncell, std::string *err)
+{
+    if (P.rates_cells != ncell) { drop(P.rates); P.rates_cells = 0; }
+    int rc;
+    if ((rc = ensure(P.rates, (size_t)6 * ncell, err))) return rc;
+    P.rates_cells = ncell;
+    POINT_HIP(hipMemsetAsync(P.rates, 0, sizeof(double) * 6 * ncell, stream));
+    return 0;
+}
+
+int point_trace(PointState &P, hipStream_t stream, const AmrTree &tree, double box, int nsrc, const int64_t *src_cell,
+                const double *src_ndot, int *highest_pixel_level, std::string *err)
+{
+    if (!P.tables_ready) { *err = "no rate tables: call ftte_stellar_beta_table or ftte_set_rate_tables first"; return FTTE_ERR_STATE; }
+    if (!P.medium_ready || P.medium_cells != tree.ncell) { *err = "no medium: call ftte_set_medium after ftte_set_grid"; return FTTE_ERR_STATE; }
+    int rc;
+    if (!P.rates || P.rates_cells != tree.ncell)
+        if ((rc = point_zero_rates(P, stream, tree.ncell, err))) return rc;
+
+    const size_t nnode = tree.parent.size();
+    if (!P.tree_ready) {
+        drop(P.parent); drop(P.child0); drop(P.leaf); drop(P.level);
+        if ((rc = ensure(P.parent, nnode, err)) || (rc = ensure(P.child0, nnode, err)) || (rc = ensure(P.leaf, nnode, err)) ||
+            (rc = ensure(P.level, nnode, err)))
+            return rc;
+        POINT_HIP(hipMemcpyAsync(P.parent, tree.parent.data(), sizeof(int32_t) * nnode, hipMemcpyHostToDevice, stream));
+        POINT_HIP(hipMemcpyAsync(P.child0, tree.child0.data(), sizeof(int32_t) * nnode, hipMemcpyHostToDevice, stream));
+        POINT_HIP(hipMemcpyAsync(P.leaf, tree.leaf.data(), sizeof(int32_t) * nnode, hipMemcpyHostToDevice, stream));
+        POINT_HIP(hipMemcpyAsync(P.level, tree.level.data(), sizeof(int8_t) * nnode, hipMemcpyHostToDevice, stream));
+        POINT_HIP(hipStreamSynchronize(stream));
+        P.tree_ready = true;
+    }
+    if (!P.pixdir) {
+        // unit vectors of every pixel of levels 1..6.  The reference evaluates cos(phi)*cos(theta), sin(phi)*cos(theta),
+        // sin(theta) where it needs them (equiSources.f90:2437-2439, :3331-3333); the products are formed here once.
+        std::vector<double> dir((size_t)3 * kPixelCount);
+        size_t at = 0;
+        for (int L = 1; L <= kMaxPixelLevel; ++L) {
+            const int nside = 1 << (L - 1);
+            const int64_t npix = (int64_t)12 * nside * nside;
+            for (int64_t ip = 0; ip < npix; ++ip, ++at) {
+                double phi, theta;
+                if (pix2ang_nest(nside, ip, &phi, &theta)) { *err = "pix2ang_nest failed"; return FTTE_ERR_PIXEL; }
+                dir[3 * at + 0] = std::cos(phi) * std::cos(theta);
+                dir[3 * at + 1] = std::sin(phi) * std::cos(theta);
+                dir[3 * at + 2] = std::sin(theta);
+            }
+        }
+        if ((rc = ensure(P.pixdir, dir.size(), err))) return rc;
+        POINT_HIP(hipMemcpyAsync(P.pixdir, dir.data(), sizeof(double) * dir.size(), hipMemcpyHostToDevice, stream));
+        POINT_HIP(hipStreamSynchronize(stream));
+        rmax_table(P.rmax);
+    }
+    if (!P.counters) {
+        if ((rc = ensure(P.counters, 4, err))) return rc;
+    }
+    const int batch_max = nsrc < kSplitBatch ? nsrc : kSplitBatch;
+    const int32_t need = batch_max * 3072; // at most 12 * 4^4 rays of one source split into level 6
+    if (need > P.queue_capacity) {
+        drop(P.queue[0]); drop(P.queue[1]);
+        P.queue_capacity = 0;
+        POINT_HIP(hipMalloc((void **)&P.queue[0], sizeof(SplitRec) * need));
+        POINT_HIP(hipMalloc((void **)&P.queue[1], sizeof(SplitRec) * need));
+        P.queue_capacity = need;
+    }
+    if (batch_max > P.src_capacity) {
+        drop(P.src_node); drop(P.src_ndot);
+        P.src_capacity = 0;
+        POINT_HIP(hipMalloc((void **)&P.src_node, sizeof(int32_t) * batch_max));
+        POINT_HIP(hipMalloc((void **)&P.src_ndot, sizeof(double) * batch_max));
+        P.src_capacity = batch_max;
+    }
+
+    // cell-array index -> tree node
+    std::vector<int32_t> node_of(nsrc);
+    {
+        std::vector<int32_t> inverse((size_t)tree.ncell, -1);
+        for (size_t v = 0; v < nnode; ++v)
+            if (tree.leaf[v] >= 0) inverse[(size_t)tree.leaf[v]] = (int32_t)v;
+        for (int s = 0; s < nsrc; ++s) {
+            if (src_cell[s] < 0 || src_cell[s] >= tree.ncell) { *err = "ftte_point_sources: source cell outside the cell array"; return FTTE_ERR_ARG; }
+            node_of[s] = inverse[(size_t)src_cell[s]];
+        }
+    }
+
+    TraceRec T;
+    std::memset(&T, 0, sizeof(T));
+    T.parent = P.parent; T.child0 = P.child0; T.leaf = P.leaf; T.level = P.level;
+    T.n = tree.n; T.dust = P.dust; T.ncell = tree.ncell; T.box = box;
+    T.HI = P.medium[0]; T.HeI = P.medium[1]; T.HeII = P.medium[2]; T.rho = P.medium[3]; T.abun2 = P.medium[4];
+    T.logtab = P.logtab; T.pixdir = P.pixdir;
+    T.rmax[0] = 0.0;
+    for (int L = 1; L <= kMaxPixelLevel; ++L) T.rmax[L] = P.rmax[L - 1];
+    T.rates = P.rates;
+    T.src_node = P.src_node; T.src_ndot = P.src_ndot;
+    T.out_count = P.counters; T.highest_level = P.counters + 1; T.error = P.counters + 2;
+    T.out_capacity = P.queue_capacity;
+
+    int32_t host_counters[4] = {0, 0, 0, 0};
+    int highest = 0;
+    for (int s0 = 0; s0 < nsrc; s0 += batch_max) {
+        const int ns = nsrc - s0 < batch_max ? nsrc - s0 : batch_max;
+        POINT_HIP(hipMemcpyAsync(P.src_node, node_of.data() + s0, sizeof(int32_t) * ns, hipMemcpyHostToDevice, stream));
+        POINT_HIP(hipMemcpyAsync(P.src_ndot, src_ndot + s0, sizeof(double) * ns, hipMemcpyHostToDevice, stream));
+        int32_t nrec = 0;
+        for (int L = 1; L <= kMaxPixelLevel; ++L) {
+            T.pixel_level = L;
+            T.nrays = L == 1 ? 12 * ns : 4 * nrec;
+            if (T.nrays == 0) break;
+            T.in = P.queue[L & 1];
+            T.out = P.queue[(L + 1) & 1];
+            // queue length back to zero, highest level and error carried over
+            host_counters[0] = 0;
+            host_counters[1] = highest;
+            POINT_HIP(hipMemcpyAsync(P.counters, host_counters, sizeof(int32_t) * 2, hipMemcpyHostToDevice, stream));
+            if (L == 1 && s0 == 0) POINT_HIP(hipMemsetAsync(P.counters + 2, 0, sizeof(int32_t) * 2, stream));
+            if (launch_point_trace(T, stream)) { *err = "tracer kernel failed to launch"; return FTTE_ERR_NO_DEVICE; }
+            POINT_HIP(hipMemcpyAsync(host_counters, P.counters, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, stream));
+            POINT_HIP(hipStreamSynchronize(stream));
+            nrec = host_counters[0];
+            highest = host_counters[1];
+            if (host_counters[2]) {
+                static const char *what[] = {"", "continuation cell outside the base grid", "error in checkPoint (start)",
+                                             "error in checkPoint", "ray did not terminate", "split queue overflow"};
+                const int e = host_counters[2] < 6 ? host_counters[2] : 3;
+                *err = std::string("ftte_point_sources: ") + what[e];
+                return FTTE_ERR_PATTERN;
+            }
+        }
+    }
+    if (highest_pixel_level) *highest_pixel_level = highest;
+    return 0;
+}
+
+} // namespace ftte

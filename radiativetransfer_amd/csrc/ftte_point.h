@@ -1,0 +1,74 @@
+// ftte_point.h -- host side of the point-source path (rows P1-P3 of the scope table): the stellar rate
+// tables (stellarBetaTable.f90), the table look-up (getRatesHydrogenHelium, equiSources.f90:4157-4311) and
+// the long-characteristics tracer with HEALPix ray splitting (startNewLongRay, equiSources.f90:3120-3385).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "ftte_amr.h"
+#include "ftte_internal.h"
+
+namespace ftte {
+
+constexpr int kFrequencies = 400;    // nfreq, stellarBetaTable.f90:14
+constexpr int kSplitBatch = 1024;    // sources traced together; bounds the split queues (3072 records each)
+
+// Everything the point-source path keeps on the device.  Owned by the context.
+struct PointState {
+    // the tree, uploaded on first use after ftte_set_grid
+    int32_t *parent = nullptr, *child0 = nullptr, *leaf = nullptr;
+    int8_t *level = nullptr;
+    bool tree_ready = false;
+    // HI, HeI, HeII, rho, abun2 in cell-array order
+    double *medium[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int64_t medium_cells = 0;
+    int dust = 0;
+    bool medium_ready = false;
+    // [6][11^4] rate tables and their logarithms
+    double *tables = nullptr, *logtab = nullptr;
+    bool tables_ready = false;
+    FreqBin *bins = nullptr;
+    double *pixdir = nullptr; // [kPixelCount][3]
+    double rmax[30];
+    // [6][ncell] krate24, krate25, krate26, crate24, crate25, crate26
+    double *rates = nullptr;
+    int64_t rates_cells = 0;
+    // tracer scratch
+    SplitRec *queue[2] = {nullptr, nullptr};
+    int32_t queue_capacity = 0;
+    int32_t *counters = nullptr; // [0] queue length, [1] highest pixel level, [2] error
+    int32_t *src_node = nullptr;
+    double *src_ndot = nullptr;
+    int32_t src_capacity = 0;
+    double *sample_in = nullptr, *sample_out = nullptr;
+    int32_t sample_capacity = 0;
+
+    void release();
+    void drop_grid(); // after ftte_set_grid: tree, medium and rates belong to the old grid
+};
+
+// dustCrossSection, dustModule.f90:30-73 (SMC branch); a_smc is the Fortran array a_smc(7,5), lambda in micron
+double dust_cross_section(double lambda_um, const double *a_smc);
+// stellarPopulation, stellarPopulationModule.f90:7-50.  spec is the Fortran array specificLuminosity(nmetal,nspectrum,nwave)
+double stellar_population(const double *spec, int nmetal, int nspectrum, int nwave, const double *wavelength, int iSpectrum,
+                          double coefSpectrum, int iMetal, double coefMetal, double freq_ev);
+// rmax(1:30), equiSources.f90:296-309
+void rmax_table(double *rmax30);
+
+// Each returns 0 or an ftte_status and fills *err.
+int point_stellar_beta_table(PointState &P, hipStream_t stream, const double *a_smc, int nwave, const double *wavelength,
+                             int nspectrum, int nmetal, const double *spec, int iSpectrum, double coefSpectrum, int iMetal,
+                             double coefMetal, double *total_integral, std::string *err);
+int point_set_tables(PointState &P, hipStream_t stream, const double *tables, std::string *err);
+int point_get_tables(PointState &P, hipStream_t stream, double *tables, std::string *err);
+int point_lookup(PointState &P, hipStream_t stream, int dust, int nsample, const double *tau, double *rates, std::string *err);
+int point_set_medium(PointState &P, hipStream_t stream, int64_t ncell, const double *const field[5], bool on_device, int dust,
+                     std::string *err);
+int point_zero_rates(PointState &P, hipStream_t stream, int64_t ncell, std::string *err);
+int point_trace(PointState &P, hipStream_t stream, const AmrTree &tree, double box, int nsrc, const int64_t *src_cell,
+                const double *src_ndot, int *highest_pixel_level, std::string *err);
+
+} // namespace ftte

@@ -3,6 +3,7 @@ its host geometry reproduces the reference's vectors, and it fails loudly (never
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -120,3 +121,23 @@ def test_shard_bounds():
                 cover.extend(range(lo, hi))
                 assert 0 <= hi - lo - count // world <= 1
             assert cover == list(range(count))
+
+
+def test_point_source_host_pieces_match_reference_vectors(rt, golden):
+    """rmax (equiSources.f90:296-309) and dustCrossSection (dustModule.f90:30-73) of the product's host side against
+    what the reference's compiled code wrote (tests/golden/point16_homogeneous.npz)."""
+    import math
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden_point as M
+    g = golden("point16_homogeneous")
+    assert np.array_equal(rt.rmax(), g["rmax"])
+    a_smc = M.synthetic_population()[0]
+    f32 = lambda x: float(np.float32(x))  # noqa: E731  a default-real literal of the reference, widened
+    nu1 = f32(13.598)
+    ev_to_hz = 1.60217646e-12 / f32(6.6260693e-27)
+    lower, upper = nu1, 10.0 * nu1
+    for ie in range(1, 301, 13):
+        frac = float(np.float32(ie - 1) / np.float32(299))
+        freq = lower * math.exp(frac * (math.log(upper) - math.log(lower)))   # stellarBetaTable.f90:122
+        lam = f32(2.99792458e10) / (freq * ev_to_hz) * f32(1.e8)
+        assert rt.dust_cross_section(lam / f32(1.e4), a_smc) * f32(1.e-22) == g["outputSigma"][3][ie - 1]

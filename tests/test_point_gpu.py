@@ -1,0 +1,248 @@
+"""Point sources on the GPU (rows P1-P3): libftte.so through the C ABI against the vectors the reference's own compiled
+code produced (tests/golden/point*.npz) and against the CPU oracle on seeded cases.
+
+Tolerances.  The device evaluates exp/log with the ROCm math library, the reference with its compiler's: tables and
+look-ups agree to a few ulp (1e-13 relative asserted).  A ray deposits ndot*(R(d) - R(d + tau)), a difference of nearly
+equal numbers in thin cells, and rays are summed with atomics in arbitrary order: 1e-9 relative to the rate plus 1e-13 of
+the largest rate of that reaction is asserted (the oracle itself is 1e-10/1e-14 from the reference for the same reason).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import _oracle as O
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import make_golden_point as M  # noqa: E402  (synthetic_population() only)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pop():
+    return M.synthetic_population()
+
+
+@pytest.fixture(scope="module")
+def stellar():
+    import radiativetransfer_amd as rt
+    st = rt.StellarTransfer()
+    yield st
+    st.close()
+
+
+def _close(mine, ref, rel=1e-9, floor=1e-13):
+    scale = np.abs(ref).max(axis=-1, keepdims=True)
+    err = np.abs(mine - ref) - (rel * np.abs(ref) + floor * scale)
+    assert np.all(err <= 0), f"worst excess {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
+
+
+def test_rate_tables_against_reference(stellar, golden, pop):
+    for name in ("point16_homogeneous", "point10_refined_dust"):
+        g = golden(name)
+        total = stellar.stellar_beta_table(pop[0], pop[1], pop[2], int(g["iSpectrum"]), float(g["coefSpectrum"]),
+                                           int(g["iMetal"]), float(g["coefMetal"]))
+        if "totalIntegral" in g.files:
+            assert total == float(g["totalIntegral"])  # host arithmetic: bit for bit
+        mine = stellar.rate_tables().reshape(6, -1)
+        ref = g["tables"].reshape(6, -1)
+        assert np.all(np.abs(mine - ref) <= 1e-13 * np.abs(ref))
+
+
+def test_lookup_against_reference(stellar, golden):
+    g = golden("point16_homogeneous")
+    stellar.set_rate_tables(g["tables"])
+    assert np.array_equal(stellar.rate_tables().reshape(-1), g["tables"].reshape(-1))
+    mine = stellar.get_rates_hydrogen_helium(g["samples"], 0)
+    ref = g["rates"]  # [nsample][3][2]
+    assert np.all(np.abs(mine - ref) <= 1e-13 * np.abs(ref))
+    # beyond the table the reference returns zero (equiSources.f90:4170-4174); on its edge the device stays inside it
+    edge = stellar.get_rates_hydrogen_helium([[10.0, 0.0, 0.0, 0.0], [10.000001, 0, 0, 0], [0, 0, 0, 11.0], [10.0, 10.0, 10.0, 0.0]], 0)
+    assert np.all(edge[1] == 0) and np.all(edge[2] == 0)
+    t = g["tables"].reshape(6, 11, 11, 11, 11)
+    assert np.all(np.abs(edge[0][:, 0] - t[0:3, 0, 0, 0, 10]) <= 1e-13 * t[0:3, 0, 0, 0, 10])
+    assert np.all(np.abs(edge[3][:, 1] - t[3:6, 0, 10, 10, 10]) <= 1e-13 * t[3:6, 0, 10, 10, 10])
+    # with dust the fourth depth interpolates too: against the oracle
+    rng = np.random.default_rng(5)
+    tau = rng.uniform(0, 10, (200, 4))
+    mine = stellar.get_rates_hydrogen_helium(tau, 1)
+    for s in range(0, 200, 7):
+        for r in (1, 2, 3):
+            a, e = O.get_rates(g["tables"].reshape(6, -1), 1, r, tau[s])
+            assert abs(mine[s, r - 1, 0] - a) <= 1e-13 * a and abs(mine[s, r - 1, 1] - e) <= 1e-13 * e
+
+
+def _device_trace(st, g, tables=None):
+    st.set_grid(int(g["n"]), g["level"], float(g["box"]))
+    st.set_medium(g["HI"], g["HeI"], g["HeII"], g["rho"], g["abun2"], int(g["dust"]))
+    st.set_rate_tables(g["tables"] if tables is None else tables)
+    st.set_zero_rates()
+    hp = st.point_sources(g["src_leaf"], g["src_weight"].astype(float))
+    return st.rates(), hp
+
+
+@pytest.mark.parametrize("name", ["point16_homogeneous", "point10_refined_dust"])
+def test_tracer_against_reference(stellar, golden, name):
+    g = golden(name)
+    rates, hp = _device_trace(stellar, g)
+    assert hp == int(g["highestPixelLevel"])
+    _close(rates, g["krate"])
+    # the same cells are lit and the same are dark
+    assert np.array_equal(rates == 0, g["krate"] == 0)
+
+
+def _random_tree(rng, n, p1, p2):
+    level = []
+    for _ in range(n ** 3):
+        if rng.random() < p1:
+            for _ in range(8):
+                if rng.random() < p2:
+                    level += [2] * 8
+                else:
+                    level.append(1)
+        else:
+            level.append(0)
+    return np.array(level, np.int32)
+
+
+@pytest.mark.parametrize("dust", [0, 1, 2])
+def test_tracer_against_oracle_refined(stellar, golden, dust):
+    tables = golden("point16_homogeneous")["tables"]
+    rng = np.random.default_rng(100 + dust)
+    n = 12
+    level = _random_tree(rng, n, 0.15, 0.2)
+    nc = level.size
+    box = 3.0e22
+    HI = 10 ** rng.uniform(-5.5, -3.2, nc)
+    HeI, HeII = 0.08 * HI, 10 ** rng.uniform(-7, -5, nc)
+    rho, abun2 = 1.7e-24 * 10 ** rng.uniform(-4, -2, nc), 10 ** rng.uniform(-3, -0.5, nc)
+    src = rng.choice(nc, 9, replace=False)
+    ndot = rng.integers(1, 50, 9).astype(float)
+    ref, hp_ref = O.point_sources(n, level, HI, HeI, HeII, rho, abun2, box, dust, src, ndot, tables.reshape(6, -1))
+    stellar.set_grid(n, level, box)
+    stellar.set_medium(HI, HeI, HeII, rho, abun2, dust)
+    stellar.set_rate_tables(tables)
+    stellar.set_zero_rates()
+    hp = stellar.point_sources(src, ndot)
+    mine = stellar.rates()
+    assert hp == hp_ref
+    _close(mine, ref)
+    assert np.array_equal(mine == 0, ref == 0)
+
+
+def test_many_sources_batches_and_linearity(stellar, golden):
+    """More sources than one batch of the split queue (1024); rates are linear in ndot and additive over sources."""
+    g = golden("point16_homogeneous")
+    n = 16
+    rng = np.random.default_rng(7)
+    stellar.set_grid(n, np.zeros(n ** 3, np.int32), float(g["box"]))
+    HI = g["HI"] * 10 ** rng.uniform(-0.5, 0.5, n ** 3)
+    stellar.set_medium(HI, g["HeI"], g["HeII"], None, None, 0)
+    stellar.set_rate_tables(g["tables"])
+    src = rng.choice(n ** 3, 1500, replace=False)
+    ndot = rng.uniform(1, 3, 1500)
+    stellar.set_zero_rates()
+    stellar.point_sources(src, ndot)
+    all_at_once = stellar.rates()
+    stellar.set_zero_rates()
+    stellar.point_sources(src[:700], ndot[:700])
+    stellar.point_sources(src[700:], 2 * ndot[700:])   # accumulates
+    stellar.point_sources(src[700:], -ndot[700:])
+    in_parts = stellar.rates()
+    _close(in_parts, all_at_once, rel=1e-11, floor=1e-14)
+    # a sample of the sources against the oracle
+    pick = np.arange(0, 1500, 150)
+    ref, _ = O.point_sources(n, np.zeros(n ** 3, np.int32), HI, g["HeI"], g["HeII"], g["rho"], g["abun2"], float(g["box"]), 0,
+                             src[pick], ndot[pick], g["tables"].reshape(6, -1))
+    stellar.set_zero_rates()
+    stellar.point_sources(src[pick], ndot[pick])
+    _close(stellar.rates(), ref)
+
+
+def test_photon_conservation_full_size(stellar, golden):
+    """128^3 cells, 64 sources: what is absorbed never exceeds what is emitted, and an opaque box absorbs all of it."""
+    g = golden("point16_homogeneous")
+    tables = g["tables"].reshape(6, -1)
+    n = 128
+    rng = np.random.default_rng(11)
+    stellar.set_grid(n, np.zeros(n ** 3, np.int32), float(g["box"]))
+    stellar.set_rate_tables(g["tables"])
+    src = rng.choice(n ** 3, 64, replace=False)
+    ndot = rng.uniform(1, 5, 64)
+    emitted = tables[0, 0] * ndot.sum()
+    HI0 = float(g["HI"][0]) * 16 / n
+    zeros = np.zeros(n ** 3)
+    for factor, lo, hi in ((1.0, 0.05, 1.0), (3000.0, 1 - 2e-3, 1 + 1e-9)):
+        stellar.set_medium(np.full(n ** 3, HI0 * factor), zeros, zeros, None, None, 0)
+        stellar.set_zero_rates()
+        hp = stellar.point_sources(src, ndot)
+        k = stellar.rates()
+        assert np.all(k >= -1e-12 * np.abs(k).max())
+        frac = k[0].sum() / emitted
+        assert lo < frac < hi, frac
+        assert 1 <= hp <= 6 or factor > 1
+
+
+def test_locate_cell_and_errors(stellar, golden):
+    from radiativetransfer_amd import FtteError
+    g = golden("point10_refined_dust")
+    level = g["level"]
+    n = int(g["n"])
+    stellar.set_grid(n, level, float(g["box"]))
+    # the call sequence of every cell-array entry, from the depth-first level list (readCellArray.f90:154-187)
+    seqs, cursor = [], 0
+
+    def grow(lvl, path):
+        nonlocal cursor
+        if level[cursor] == lvl:
+            seqs.append(path)
+            cursor += 1
+        else:
+            for a in (1, 2):
+                for b in (1, 2):
+                    for c in (1, 2):
+                        grow(lvl + 1, path + [a, b, c])
+    for i in range(1, n + 1):
+        for j in range(1, n + 1):
+            for k in range(1, n + 1):
+                grow(0, [i, j, k])
+    assert len(seqs) == level.size
+    for leaf in list(range(0, level.size, 37)) + [level.size - 1, int(np.argmax(level))]:
+        assert stellar.locate_cell(seqs[leaf]) == leaf
+    deep = seqs[int(np.argmax(level))]
+    with pytest.raises(FtteError) as e:
+        stellar.locate_cell(deep[:-3])  # stops on a refined cell
+    assert e.value.status == "FTTE_ERR_LEVELS"
+    with pytest.raises(FtteError) as e:
+        stellar.locate_cell(deep + [1, 1, 1])  # 'error in star particle position: cell not refined'
+    assert e.value.status == "FTTE_ERR_LEVELS"
+    with pytest.raises(FtteError) as e:
+        stellar.locate_cell([n + 1, 1, 1])
+    assert e.value.status == "FTTE_ERR_ARG"
+    # call order and arguments
+    import radiativetransfer_amd as rt
+    with rt.StellarTransfer() as fresh:
+        with pytest.raises(FtteError) as e:
+            fresh.point_sources([0], [1.0])
+        assert e.value.status == "FTTE_ERR_STATE"
+        fresh.set_grid(4, np.zeros(64, np.int32), 1.0e22)
+        with pytest.raises(FtteError) as e:
+            fresh.point_sources([0], [1.0])
+        assert e.value.status == "FTTE_ERR_STATE"  # no tables
+        fresh.set_rate_tables(golden("point16_homogeneous")["tables"])
+        with pytest.raises(FtteError) as e:
+            fresh.point_sources([0], [1.0])
+        assert e.value.status == "FTTE_ERR_STATE"  # no medium
+        z = np.full(64, 1e-6)
+        fresh.set_medium(z, z, z, None, None, 0)
+        with pytest.raises(FtteError) as e:
+            fresh.point_sources([64], [1.0])
+        assert e.value.status == "FTTE_ERR_ARG"
+        with pytest.raises(FtteError) as e:
+            fresh.set_medium(z, z, z, None, None, 2)
+        assert e.value.status == "FTTE_ERR_ARG"
+        assert fresh.point_sources([], []) == 0
+        fresh.point_sources([21], [1.0])
+        assert fresh.rates()[0].sum() > 0
