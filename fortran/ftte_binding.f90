@@ -102,6 +102,91 @@ module ftte_binding
        integer(c_int), intent(out) :: icell, jcell, kcell
      end function ftte_rotate_indices
 
+     ! ---- point sources (the runStellarTransfer block, equiSources.f90:1256-1370)
+
+     integer(c_int) function ftte_stellar_beta_table(ctx, a_smc, nwave, wavelength_cm, nspectrum, nmetal, &
+          specific_luminosity, iSpectrum, coefSpectrum, iMetal, coefMetal, total_integral) &
+          bind(C, name='ftte_stellar_beta_table')
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: a_smc(7,5)               ! module dust
+       integer(c_int), value :: nwave, nspectrum, nmetal
+       real(c_double), intent(in) :: wavelength_cm(*)         ! wavelength(nWavelengths)
+       real(c_double), intent(in) :: specific_luminosity(*)   ! specificLuminosity(nMetallicity,nSpectra,nWavelengths), as is
+       integer(c_int), value :: iSpectrum, iMetal
+       real(c_double), value :: coefSpectrum, coefMetal
+       real(c_double), intent(out) :: total_integral
+     end function ftte_stellar_beta_table
+
+     integer(c_int) function ftte_set_rate_tables(ctx, tables) bind(C, name='ftte_set_rate_tables')
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: tables(*)   ! reactionRate1..3, energyRate1..3, each (0:10,0:10,0:10,0:10)
+     end function ftte_set_rate_tables
+
+     integer(c_int) function ftte_get_rate_tables(ctx, tables) bind(C, name='ftte_get_rate_tables')
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(out) :: tables(*)
+     end function ftte_get_rate_tables
+
+     integer(c_int) function ftte_get_rates_hydrogen_helium(ctx, dust_approximation, nsample, tau, rates) &
+          bind(C, name='ftte_get_rates_hydrogen_helium')
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: dust_approximation, nsample
+       real(c_double), intent(in) :: tau(*)      ! (4, nsample)
+       real(c_double), intent(out) :: rates(*)   ! (2, 3, nsample): numberRate, heatingRate per reaction
+     end function ftte_get_rates_hydrogen_helium
+
+     integer(c_int) function ftte_set_medium(ctx, HI, HeI, HeII, rho, abun2, dust_approximation) &
+          bind(C, name='ftte_set_medium')
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: HI(*), HeI(*), HeII(*), rho(*), abun2(*)
+       integer(c_int), value :: dust_approximation
+     end function ftte_set_medium
+
+     integer(c_int) function ftte_set_zero_rates(ctx) bind(C, name='ftte_set_zero_rates')
+       import :: c_ptr, c_int
+       type(c_ptr), value :: ctx
+     end function ftte_set_zero_rates
+
+     integer(c_int) function ftte_locate_cell(ctx, level, position, cell) bind(C, name='ftte_locate_cell')
+       import :: c_ptr, c_int, c_int32_t, c_int64_t
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: level
+       integer(c_int32_t), intent(in) :: position(*)   ! starType%position(1:3*level+3)
+       integer(c_int64_t), intent(out) :: cell         ! 0-based cell-array index
+     end function ftte_locate_cell
+
+     integer(c_int) function ftte_point_sources(ctx, nsrc, src_cell, src_ndot, highest_pixel_level) &
+          bind(C, name='ftte_point_sources')
+       import :: c_ptr, c_int, c_int64_t, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: nsrc
+       integer(c_int64_t), intent(in) :: src_cell(*)
+       real(c_double), intent(in) :: src_ndot(*)
+       integer(c_int), intent(out) :: highest_pixel_level
+     end function ftte_point_sources
+
+     integer(c_int) function ftte_get_point_rates(ctx, rates) bind(C, name='ftte_get_point_rates')
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(out) :: rates(*)   ! (ncell, 6): krate24, krate25, krate26, crate24, crate25, crate26
+     end function ftte_get_point_rates
+
+     integer(c_int) function ftte_rmax(rmax30) bind(C, name='ftte_rmax')
+       import :: c_int, c_double
+       real(c_double), intent(out) :: rmax30(30)
+     end function ftte_rmax
+
+     real(c_double) function ftte_dust_cross_section(lambda_micron, a_smc) bind(C, name='ftte_dust_cross_section')
+       import :: c_double
+       real(c_double), value :: lambda_micron
+       real(c_double), intent(in) :: a_smc(7,5)
+     end function ftte_dust_cross_section
+
   end interface
 
 contains

@@ -43,6 +43,7 @@ program point_harness
   real(kind=RealKind) :: box, coefSpectrum, coefMetal, totalIntegral, ndot1
   character(len=512) :: caseName, outName
   integer :: bi, bj, bk, want, pathLen
+  integer(kind=8) :: tick0, tick1, tickRate
   integer, target :: path(33)
   type(zoneType), pointer :: host
   type(pixelType), target :: sphere
@@ -130,6 +131,7 @@ program point_harness
   sphere%refined = .false.
   sphere%level = 0
   highestPixelLevel = 0
+  call system_clock(tick0, tickRate)
   do is = 1, nsrc
      ndotRemaining = 0.
      ndotBoundary = 0.
@@ -174,6 +176,9 @@ program point_harness
              ndot1/12.d0, 0.d0, 0.d0, 0.d0, 0.d0, n, n, n)
      enddo
   enddo
+
+  call system_clock(tick1)
+  write(*,'(a,f12.4)') ' TRACE_SECONDS ', dble(tick1-tick0)/dble(tickRate)
 
   allocate(kout(ncell,6))
   cursor = 0

@@ -66,6 +66,7 @@ void PointState::drop_grid()
     medium_ready = false;
     drop(rates);
     rates_cells = 0;
+    std::vector<int32_t>().swap(node_of_leaf);
 }
 
 void PointState::release()
@@ -295,16 +296,16 @@ int point_trace(PointState &P, hipStream_t stream, const AmrTree &tree, double b
         P.src_capacity = batch_max;
     }
 
-    // cell-array index -> tree node
-    std::vector<int32_t> node_of(nsrc);
-    {
-        std::vector<int32_t> inverse((size_t)tree.ncell, -1);
+    // cell-array index -> tree node (kept until the grid changes)
+    if (P.node_of_leaf.size() != (size_t)tree.ncell) {
+        P.node_of_leaf.assign((size_t)tree.ncell, -1);
         for (size_t v = 0; v < nnode; ++v)
-            if (tree.leaf[v] >= 0) inverse[(size_t)tree.leaf[v]] = (int32_t)v;
-        for (int s = 0; s < nsrc; ++s) {
-            if (src_cell[s] < 0 || src_cell[s] >= tree.ncell) { *err = "ftte_point_sources: source cell outside the cell array"; return FTTE_ERR_ARG; }
-            node_of[s] = inverse[(size_t)src_cell[s]];
-        }
+            if (tree.leaf[v] >= 0) P.node_of_leaf[(size_t)tree.leaf[v]] = (int32_t)v;
+    }
+    std::vector<int32_t> node_of(nsrc);
+    for (int s = 0; s < nsrc; ++s) {
+        if (src_cell[s] < 0 || src_cell[s] >= tree.ncell) { *err = "ftte_point_sources: source cell outside the cell array"; return FTTE_ERR_ARG; }
+        node_of[s] = P.node_of_leaf[(size_t)src_cell[s]];
     }
 
     TraceRec T;

@@ -22,6 +22,7 @@ struct PointState {
     int32_t *parent = nullptr, *child0 = nullptr, *leaf = nullptr;
     int8_t *level = nullptr;
     bool tree_ready = false;
+    std::vector<int32_t> node_of_leaf; // cell-array index -> node
     // HI, HeI, HeII, rho, abun2 in cell-array order
     double *medium[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int64_t medium_cells = 0;

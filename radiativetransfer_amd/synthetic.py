@@ -86,3 +86,24 @@ def refine_levels(n: int, blocks, depth: int = 1) -> np.ndarray:
                 else:
                     out.append(0)
     return np.asarray(out, dtype=np.int32)
+
+
+def stellar_population():
+    """A stand-in for the reference's stellar library and dust-curve data files (neither ships with it): black-body
+    spectra on the library's grid.  Returns a_smc[7][5] (rows: lambda_i [micron], a_i, b_i, p_i, q_i of the SMC fit the
+    reference reads, dustModule.f90:16-21), wavelength[1221] (cm, ascending) and
+    specificLuminosity[5][37][1221] (log10 erg/s/Angstrom; metallicity, age, wavelength)."""
+    lam_um = np.array([0.042, 0.08, 0.22, 9.7, 18.0, 25.0, 0.067])
+    a_smc = np.stack([lam_um, np.array([185.0, 27.0, 0.005, 0.010, 0.012, 0.030, 10.0]),
+                      np.array([90.0, 5.5, -1.95, -1.95, -1.8, 0.0, 1.9]), np.array([2.0, 4.0, 2.0, 2.0, 2.0, 2.0, 4.0]),
+                      np.array([2.0, 4.0, 2.0, 2.0, 2.0, 2.0, 15.0])], axis=1)
+    lam_A = np.logspace(np.log10(91.0), np.log10(1.6e6), 1221)
+    hc_k = 1.43877688e8  # h c / k in Angstrom Kelvin
+    spec = np.empty((5, 37, 1221))
+    for im in range(5):
+        for isp in range(37):
+            T = 5.0e4 * (1.0 - 0.015 * isp) * (1.0 + 0.03 * im)
+            x = hc_k / (lam_A * T)
+            planck = lam_A ** -5.0 / np.expm1(np.minimum(x, 600.0))
+            spec[im, isp] = 36.0 + np.log10(planck / planck.max() + 1e-30) + 0.01 * isp
+    return a_smc, lam_A * 1e-8, spec

@@ -76,6 +76,9 @@ def run_reference(n, level, HI, HeI, HeII, rho, abun2, box, dust, src_leaf, src_
         off += count * np.dtype(dtype).itemsize
         return a.copy()
     o = {"totalIntegral": take(1)[0]}
+    for line in res.stdout.splitlines():
+        if "TRACE_SECONDS" in line:
+            o["trace_seconds"] = float(line.split()[-1])  # the star loop alone, as the harness timed it
     o["tables"] = take(6 * NT).reshape(6, 11, 11, 11, 11)  # [table][idust][i3][i2][i1]  (Fortran order reversed)
     o["outputSigma"] = take(4 * 300).reshape(4, 300)
     o["rates"] = take(nsample * 6).reshape(nsample, 3, 2)   # Fortran rates(2,3,nsample)

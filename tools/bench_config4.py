@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
-"""BASELINE configs[3], diffuse part: 128^3 base grid with the central 32^3 block refined once (2 326 528 leaves),
-8 frequency groups, 96 directions, one GPU.  Prints plan-build time (host, once per tree + direction list) and the
-per-iteration rate of the segment-forest path."""
+"""BASELINE configs[3]: 128^3 base grid with the central 32^3 block refined once (2 326 528 leaves), one GPU.
+  * diffuse part: 8 frequency groups, 96 directions, the segment-forest path; plan-build time (host, once per tree +
+    direction list) and the per-iteration rate;
+  * point source (the Stromgren-sphere set-up): one star in the centre of the refined patch, homogeneous hydrogen;
+    stellarBetaTable on the device, the splitting tracer, and -- when oracle/_ref/point_harness has been built -- the
+    reference's own tracer timed on this box's host on the same case, with the rates compared.
+usage: bench_config4.py [n] [--no-diffuse] [--no-reference]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,32 +14,76 @@ import torch
 import radiativetransfer_amd as rt
 from radiativetransfer_amd import synthetic
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+n = int(args[0]) if args else 128
 q = n // 4
 blocks = [(n // 2 - q // 2 + a, n // 2 - q // 2 + b, n // 2 - q // 2 + c) for a in range(q) for b in range(q) for c in range(q)]
 t0 = time.perf_counter()
 level = synthetic.refine_levels(n, blocks, depth=1)
-nnu, ndir = 8, 96
-rho = synthetic.lognormal_density(len(level), seed=4)
-_, s_nu, uvb = synthetic.frequency_groups(nnu)
-kappa_host = (0.1 * n) * s_nu[:, None] * rho[None, :] * (2.0 ** level)[None, :]
-print(f"{len(level)} leaves ({n}^3 base, central {q}^3 block refined once); inputs built in {time.perf_counter() - t0:.1f} s", flush=True)
-ang = np.array([rt.pix2ang_nest(4, i) for i in range(ndir)])
-phi, theta, w = ang[:, 0].copy(), ang[:, 1].copy(), np.full(ndir, 1.0 / ndir)
-dev = torch.device("cuda", 0)
-kappa = torch.from_numpy(kappa_host).to(dev)
-J = torch.empty((nnu, len(level)), dtype=torch.float64, device=dev)
-eng = rt.DiffuseTransfer(device=0)
-t0 = time.perf_counter(); eng.set_grid(n, level, 1.0); print(f"set_grid (tree rebuild): {time.perf_counter() - t0:.2f} s", flush=True)
-stream = torch.cuda.current_stream().cuda_stream
-for it in range(4):
-    t0 = time.perf_counter()
-    eng.set_opacity_device(nnu, kappa.data_ptr())
-    eng.transport_device(phi, theta, w, uvb, J.data_ptr(), stream)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    upd = len(level) * nnu * ndir
-    kms = sum(ms for ms, _ in eng.launch_records())
-    print(f"iteration {it}: {dt * 1e3:9.1f} ms ({'includes building and uploading 96 forests' if it == 0 else 'plan cached'}); "
-          f"device {kms:8.1f} ms -> {upd / dt:.3e} updates/s", flush=True)
-print("J range", float(J.min()), float(J.max()), "uvb", uvb[0], uvb[-1])
+ncell = len(level)
+print(f"{ncell} leaves ({n}^3 base, central {q}^3 block refined once); levels built in {time.perf_counter() - t0:.1f} s", flush=True)
+eng = rt.StellarTransfer(device=0)
+t0 = time.perf_counter(); eng.set_grid(n, level, 3.0e22); print(f"set_grid (tree rebuild): {time.perf_counter() - t0:.2f} s", flush=True)
+
+if "--no-diffuse" not in sys.argv:
+    nnu, ndir = 8, 96
+    rho = synthetic.lognormal_density(ncell, seed=4)
+    _, s_nu, uvb = synthetic.frequency_groups(nnu)
+    kappa_host = (0.1 * n / 3.0e22) * s_nu[:, None] * rho[None, :] * (2.0 ** level)[None, :]
+    ang = np.array([rt.pix2ang_nest(4, i) for i in range(ndir)])
+    phi, theta, w = ang[:, 0].copy(), ang[:, 1].copy(), np.full(ndir, 1.0 / ndir)
+    dev = torch.device("cuda", 0)
+    kappa = torch.from_numpy(kappa_host).to(dev)
+    J = torch.empty((nnu, ncell), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    for it in range(4):
+        t0 = time.perf_counter()
+        eng.set_opacity_device(nnu, kappa.data_ptr())
+        eng.transport_device(phi, theta, w, uvb, J.data_ptr(), stream)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        upd = ncell * nnu * ndir
+        kms = sum(ms for ms, _ in eng.launch_records())
+        print(f"diffuse iteration {it}: {dt * 1e3:9.1f} ms ({'includes building and uploading 96 forests' if it == 0 else 'plan cached'}); "
+              f"device {kms:8.1f} ms -> {upd / dt:.3e} updates/s", flush=True)
+    print("J range", float(J.min()), float(J.max()), "uvb", uvb[0], uvb[-1])
+    del kappa, J
+
+# ---- the point source
+box = 3.0e22
+pop = synthetic.stellar_population()
+isp, csp, im, cm = 3, 0.4, 2, 0.3
+t0 = time.perf_counter(); total = eng.stellar_beta_table(*pop, isp, csp, im, cm); t_table = time.perf_counter() - t0
+tau_box = 6.0  # hydrogen optical depth across the box at threshold: the front sits well inside
+HI = np.full(ncell, tau_box / (6.3e-18 * box))
+HeI, HeII = 0.08 * HI, 1e-3 * HI
+rho, abun2 = HI * 1.67e-24 / 0.76, np.full(ncell, 0.02)
+eng.set_medium(HI, HeI, HeII, rho, abun2, 0)
+centre = [n // 2, n // 2, n // 2, 2, 2, 2]  # the fine cell just past the centre of the box
+src = eng.locate_cell(centre)
+weight = 1000
+for rep in range(3):
+    eng.set_zero_rates()
+    t0 = time.perf_counter(); hp = eng.point_sources([src], [float(weight)]); t_trace = time.perf_counter() - t0
+k = eng.rates()
+tab = eng.rate_tables()
+emitted = tab[0, 0, 0, 0, 0] * weight
+print(f"point source: stellarBetaTable {t_table * 1e3:.1f} ms (device), tracer {t_trace * 1e3:.2f} ms, highestPixelLevel {hp}, "
+      f"absorbed/emitted (HI) = {k[0].sum() / emitted:.6f}", flush=True)
+
+if "--no-reference" not in sys.argv:
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden_point as M
+    if os.path.exists(M.HARNESS):
+        t0 = time.perf_counter()
+        ref = M.run_reference(n, level, HI, HeI, HeII, rho, abun2, box, 0, np.array([src]), np.array([weight]), pop, isp, im, csp, cm,
+                              np.zeros((1, 4)), npixlevel=1)
+        t_ref = time.perf_counter() - t0
+        scale = np.abs(ref["krate"]).max(axis=1, keepdims=True)
+        err = np.abs(k - ref["krate"]) / (np.abs(ref["krate"]) + 1e-4 * scale)
+        print(f"reference (1 host core): star loop {ref.get('trace_seconds', float('nan')):.2f} s (whole harness run {t_ref:.1f} s); "
+              f"device tracer is {ref.get('trace_seconds', float('nan')) / t_trace:.0f} x faster; "
+              f"worst |device - reference| / (|reference| + 1e-4 max) = {err.max():.2e}; tables worst rel "
+              f"{np.abs(tab / ref['tables'] - 1).max():.1e}", flush=True)
+    else:
+        print("oracle/_ref/point_harness not built: no reference timing")
