@@ -180,7 +180,7 @@ double ftte_dust_cross_section(double lambda_micron, const double *a_smc);
 /* Tuning knobs: "rows" (rays per lane: 4, 8 or 16), "stack" (wavefronts per workgroup, stacked
  * along the row axis and exchanging their boundary row through LDS: 1, 2, 4 or 8), "slots"
  * (directions in flight per launch, 1..16), "waves" (waves per SIMD the sweep kernel's register
- * allocation is held to: 2, 3, 4 or 6), "forest" (1: use the refined-grid path on a uniform grid
+ * allocation is held to: 2..6), "forest" (1: use the refined-grid path on a uniform grid
  * too, for cross-checks).  Built variants: rows x stack = 4x{1,4,8}, 8x{1,2,4}, 16x1.
  * Results do not depend on any of them except through the order in which "slots" sums
  * directions.  Unknown keys return FTTE_ERR_ARG. */

@@ -21,6 +21,7 @@ HEADERS = ["ftte_internal.h", "ftte_kernels.h", "ftte_geometry.h", "ftte_math.h"
 # -ffp-contract=off: the sweep arithmetic spells out its fused multiply-adds (ftte_math.h); nothing else may be fused,
 # so that the device rounds exactly like the host evaluation the parity tests compare against.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-gpu-rdc", "-Wall"]
+FLAGS += os.environ.get("FTTE_CXXFLAGS", "").split()  # experiments only (e.g. -DFTTE_TOUCH=1)
 
 
 def hipcc() -> str:

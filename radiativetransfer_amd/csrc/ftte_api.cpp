@@ -652,7 +652,7 @@ int ftte_set_option(ftte_ctx *c, const char *key, int value)
         if (value < 1 || value > kMaxSlots) return fail(c, FTTE_ERR_ARG, "slots must be 1..16");
         c->slots = value;
     } else if (!std::strcmp(key, "waves")) {
-        if (value != 2 && value != 3 && value != 4 && value != 6) return fail(c, FTTE_ERR_ARG, "waves must be 2, 3, 4 or 6");
+        if (value < 2 || value > 6) return fail(c, FTTE_ERR_ARG, "waves must be 2..6");
         c->waves = value;
     } else if (!std::strcmp(key, "forest")) {
         if (value != 0 && value != 1) return fail(c, FTTE_ERR_ARG, "forest must be 0 or 1");

@@ -346,6 +346,7 @@ static int launch_variant(const LaunchRec &L, int waves, dim3 grid, hipStream_t 
     case 2: hipLaunchKernelGGL((sweep_kernel<ROWS, 2, STACK, 0>), grid, block, g_lds_pad, stream, L); break;
     case 3: hipLaunchKernelGGL((sweep_kernel<ROWS, 3, STACK, 0>), grid, block, g_lds_pad, stream, L); break;
     case 4: hipLaunchKernelGGL((sweep_kernel<ROWS, 4, STACK, 0>), grid, block, g_lds_pad, stream, L); break;
+    case 5: hipLaunchKernelGGL((sweep_kernel<ROWS, 5, STACK, 0>), grid, block, g_lds_pad, stream, L); break;
     case 6: hipLaunchKernelGGL((sweep_kernel<ROWS, 6, STACK, 0>), grid, block, g_lds_pad, stream, L); break;
     default: return -1;
     }

@@ -24,6 +24,20 @@ template <int VEC, int UNROLL> __global__ void __launch_bounds__(256) rmw(const 
     }
 }
 
+// j += k with the add done by the L2 (fp64 atomic without return): no J load, no J register, same HBM traffic
+template <int UNROLL> __global__ void __launch_bounds__(256) rmw_atomic(const double *__restrict__ k, double *__restrict__ j, long n)
+{
+    const long chunk = (long)gridDim.x * blockDim.x;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (UNROLL - 1) * chunk < n; i += UNROLL * chunk) {
+        double a[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) a[u] = k[i + u * chunk];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) unsafeAtomicAdd(&j[i + u * chunk], a[u]);
+    }
+}
+
 template <int VEC> __global__ void __launch_bounds__(256) copy(const double *__restrict__ k, double *__restrict__ j, long n)
 {
     const long chunk = (long)gridDim.x * blockDim.x * VEC;
@@ -66,6 +80,8 @@ int main()
         RUN("rmw (k,J->J)  8 B/lane x4", n * 24.0, hipLaunchKernelGGL((rmw<1, 4>), dim3(blocks), dim3(256), 0, 0, k, j, n));
         RUN("rmw (k,J->J) 16 B/lane x1", n * 24.0, hipLaunchKernelGGL((rmw<2, 1>), dim3(blocks), dim3(256), 0, 0, k, j, n));
         RUN("rmw (k,J->J) 16 B/lane x4", n * 24.0, hipLaunchKernelGGL((rmw<2, 4>), dim3(blocks), dim3(256), 0, 0, k, j, n));
+        RUN("rmw atomic (k -> J += k) x1", n * 24.0, hipLaunchKernelGGL((rmw_atomic<1>), dim3(blocks), dim3(256), 0, 0, k, j, n));
+        RUN("rmw atomic (k -> J += k) x4", n * 24.0, hipLaunchKernelGGL((rmw_atomic<4>), dim3(blocks), dim3(256), 0, 0, k, j, n));
     }
     return 0;
 }
