@@ -80,13 +80,13 @@ struct ftte_ctx {
 
     int nnu = 0;
     double *kappa[3] = {nullptr, nullptr, nullptr}; // layouts 0,1,2
-    bool kappa_ready[3] = {false, false, false};
+    bool kappa_ready[4] = {false, false, false, false}; // [3]: the cell-major copy of the forest path
     size_t kappa_cap = 0; // elements per layout buffer
 
     // emissivity (mode 1: the reference's eta) or source function (mode 2), same three layouts as kappa
     int emit_mode = 0;
     double *emis[3] = {nullptr, nullptr, nullptr};
-    bool emis_ready[3] = {false, false, false};
+    bool emis_ready[4] = {false, false, false, false};
 
     double *acc[3][kMaxSlots] = {};
     size_t acc_cap = 0; // elements per accumulator
@@ -107,14 +107,16 @@ struct ftte_ctx {
     bool use_forest = false;  // refined grid (or option "forest" = 1 on a uniform one, for cross-checks)
     int force_forest = 0;
     struct ForestDev {
-        int32_t *up = nullptr, *up2 = nullptr, *order = nullptr;
-        double *dpath = nullptr;
+        SegRec *rec = nullptr;
+        uint8_t *active = nullptr;
         std::vector<int64_t> depth_off;
         double w = 0;
     };
     std::vector<ForestDev> forests;
     std::vector<double> forest_key; // phi, theta, w of the cached forests (+ box)
     double *amr_Iout = nullptr, *amr_mean = nullptr;
+    double *amr_kappa = nullptr, *amr_emis = nullptr; // [ncell][nnu] copies
+    size_t amr_kappa_cap = 0, amr_emis_cap = 0;
     size_t amr_scratch_cap = 0; // elements per array
 
     PointState point; // point sources: rate tables, medium, tracer scratch
@@ -330,10 +332,8 @@ int check_ready(ftte_ctx *c, bool need_kappa)
 void free_forests(ftte_ctx *c)
 {
     for (auto &f : c->forests) {
-        if (f.up) (void)hipFree(f.up);
-        if (f.up2) (void)hipFree(f.up2);
-        if (f.order) (void)hipFree(f.order);
-        if (f.dpath) (void)hipFree(f.dpath);
+        if (f.rec) (void)hipFree(f.rec);
+        if (f.active) (void)hipFree(f.active);
     }
     c->forests.clear();
     c->forest_key.clear();
@@ -373,25 +373,38 @@ int forest_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
         for (int d0 = 0; d0 < ndir; d0 += nthreads) {
             const int nb = std::min(nthreads, ndir - d0);
             std::vector<AmrForest> F(nb);
+            std::vector<std::vector<SegRec>> rec(nb);
+            std::vector<std::vector<uint8_t>> active(nb);
             std::vector<int> st(nb, 0);
             std::vector<std::string> msg(nb);
             std::vector<std::thread> pool;
             for (int t = 0; t < nb; ++t)
-                pool.emplace_back([&, t] { st[t] = build_forest(c->tree, fphi[d0 + t], ftheta[d0 + t], fzone[d0 + t], c->box, &F[t], &msg[t]); });
+                pool.emplace_back([&, t] {
+                    st[t] = build_forest(c->tree, fphi[d0 + t], ftheta[d0 + t], fzone[d0 + t], c->box, &F[t], &msg[t]);
+                    if (st[t]) return;
+                    // pack what the device reads per segment into one record, in processing order
+                    const AmrForest &f = F[t];
+                    const size_t nact = f.order.size();
+                    rec[t].resize(std::max<size_t>(nact, 1));
+                    for (size_t q = 0; q < nact; ++q) {
+                        const int32_t sg = f.order[q];
+                        rec[t][q].seg = sg; rec[t][q].up = f.up[sg]; rec[t][q].up2 = f.up2[sg]; rec[t][q].pad = 0;
+                        rec[t][q].dpath = f.dpath[sg];
+                    }
+                    active[t].resize((size_t)ncell);
+                    for (int64_t q = 0; q < ncell; ++q)
+                        active[t][q] = (uint8_t)((f.up[3 * q + 1] != AmrForest::kInactive ? 1 : 0) | (f.up[3 * q + 2] != AmrForest::kInactive ? 2 : 0));
+                });
             for (auto &th : pool) th.join();
             for (int t = 0; t < nb; ++t) {
                 if (st[t]) { free_forests(c); return fail(c, st[t], "direction " + std::to_string(d0 + t) + ": " + msg[t]); }
                 ftte_ctx::ForestDev &D = c->forests[d0 + t];
                 D.w = w[d0 + t];
                 D.depth_off = F[t].depth_off;
-                FTTE_HIP(c, hipMalloc((void **)&D.up, sizeof(int32_t) * nseg));
-                FTTE_HIP(c, hipMalloc((void **)&D.up2, sizeof(int32_t) * nseg));
-                FTTE_HIP(c, hipMalloc((void **)&D.order, sizeof(int32_t) * std::max<size_t>(F[t].order.size(), 1)));
-                FTTE_HIP(c, hipMalloc((void **)&D.dpath, sizeof(double) * nseg));
-                FTTE_HIP(c, hipMemcpy(D.up, F[t].up.data(), sizeof(int32_t) * nseg, hipMemcpyHostToDevice));
-                FTTE_HIP(c, hipMemcpy(D.up2, F[t].up2.data(), sizeof(int32_t) * nseg, hipMemcpyHostToDevice));
-                FTTE_HIP(c, hipMemcpy(D.order, F[t].order.data(), sizeof(int32_t) * F[t].order.size(), hipMemcpyHostToDevice));
-                FTTE_HIP(c, hipMemcpy(D.dpath, F[t].dpath.data(), sizeof(double) * nseg, hipMemcpyHostToDevice));
+                FTTE_HIP(c, hipMalloc((void **)&D.rec, sizeof(SegRec) * rec[t].size()));
+                FTTE_HIP(c, hipMalloc((void **)&D.active, (size_t)ncell));
+                FTTE_HIP(c, hipMemcpy(D.rec, rec[t].data(), sizeof(SegRec) * rec[t].size(), hipMemcpyHostToDevice));
+                FTTE_HIP(c, hipMemcpy(D.active, active[t].data(), (size_t)ncell, hipMemcpyHostToDevice));
             }
         }
         c->forest_key = key;
@@ -410,6 +423,24 @@ int forest_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
     if ((rc = ensure(c, &c->d_uvb, &c->d_uvb_cap, (size_t)nnu))) return rc;
     FTTE_HIP(c, hipMemcpy(c->d_uvb, uvb, sizeof(double) * nnu, hipMemcpyHostToDevice));
 
+    // the forest path gathers by cell: all groups of a cell side by side (beyond 96 groups the transposing kernel's
+    // tile no longer fits the LDS of a workgroup; the strided layout is read as it is)
+    const bool cell_major = nnu <= 96;
+    if (cell_major) {
+    if ((rc = ensure(c, &c->amr_kappa, &c->amr_kappa_cap, (size_t)nnu * ncell))) return rc;
+    if (!c->kappa_ready[3]) {
+        if (launch_cell_major(c->kappa[0], c->amr_kappa, ncell, nnu, stream)) return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
+        c->kappa_ready[3] = true;
+    }
+    if (c->emit_mode) {
+        if ((rc = ensure(c, &c->amr_emis, &c->amr_emis_cap, (size_t)nnu * ncell))) return rc;
+        if (!c->emis_ready[3]) {
+            if (launch_cell_major(c->emis[0], c->amr_emis, ncell, nnu, stream)) return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
+            c->emis_ready[3] = true;
+        }
+    }
+    }
+
     const int nbatch = (ndir + kAmrBatch - 1) / kAmrBatch;
     while ((int)c->timing.size() < nbatch) {
         LaunchTiming t;
@@ -425,8 +456,10 @@ int forest_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
         const int d0 = b * kAmrBatch, nb = std::min(kAmrBatch, ndir - d0);
         AmrLevelRec A;
         std::memset(&A, 0, sizeof A);
-        A.kappa = c->kappa[0];
-        A.emis = c->emit_mode ? c->emis[0] : nullptr;
+        A.kappa = cell_major ? c->amr_kappa : c->kappa[0];
+        A.emis = !c->emit_mode ? nullptr : cell_major ? c->amr_emis : c->emis[0];
+        A.group_stride = cell_major ? 1 : ncell;
+        A.cell_stride = cell_major ? nnu : 1;
         A.emit = c->emit_mode;
         A.uvb = c->d_uvb;
         A.ncell = ncell;
@@ -436,7 +469,7 @@ int forest_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
         size_t maxdepth = 0;
         for (int t = 0; t < nb; ++t) {
             const ftte_ctx::ForestDev &D = c->forests[d0 + t];
-            A.dir[t].up = D.up; A.dir[t].up2 = D.up2; A.dir[t].order = D.order; A.dir[t].dpath = D.dpath;
+            A.dir[t].rec = D.rec; A.dir[t].active = D.active;
             A.dir[t].Iout = c->amr_Iout + per_dir * t;
             A.dir[t].mean = c->amr_mean + per_dir * t;
             A.dir[t].w = D.w;
@@ -516,6 +549,8 @@ int ftte_destroy(ftte_ctx *c)
     free_forests(c);
     if (c->amr_Iout) (void)hipFree(c->amr_Iout);
     if (c->amr_mean) (void)hipFree(c->amr_mean);
+    if (c->amr_kappa) (void)hipFree(c->amr_kappa);
+    if (c->amr_emis) (void)hipFree(c->amr_emis);
     c->point.release();
     for (auto &t : c->timing) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -549,7 +584,9 @@ int ftte_set_grid(ftte_ctx *c, int nx, int ny, int nz, int64_t ncell, const int3
         c->emit_mode = 0;
         if (c->amr_Iout) { (void)hipFree(c->amr_Iout); c->amr_Iout = nullptr; }
         if (c->amr_mean) { (void)hipFree(c->amr_mean); c->amr_mean = nullptr; }
-        c->kappa_cap = c->acc_cap = c->amr_scratch_cap = 0;
+        if (c->amr_kappa) { (void)hipFree(c->amr_kappa); c->amr_kappa = nullptr; }
+        if (c->amr_emis) { (void)hipFree(c->amr_emis); c->amr_emis = nullptr; }
+        c->kappa_cap = c->acc_cap = c->amr_scratch_cap = c->amr_kappa_cap = c->amr_emis_cap = 0;
         c->nnu = 0;
     }
     (void)hipSetDevice(c->device);
@@ -557,7 +594,7 @@ int ftte_set_grid(ftte_ctx *c, int nx, int ny, int nz, int64_t ncell, const int3
     free_forests(c);
     c->point.drop_grid();
     c->n = nx; c->ncell = ncell; c->box = box_cm; c->grid_set = true;
-    c->kappa_ready[0] = c->kappa_ready[1] = c->kappa_ready[2] = false;
+    c->kappa_ready[0] = c->kappa_ready[1] = c->kappa_ready[2] = c->kappa_ready[3] = false;
     c->plan.valid = false;
     c->tree = std::move(tree);
     c->use_forest = c->tree.refined() || c->force_forest;
@@ -575,7 +612,7 @@ int ftte_set_opacity(ftte_ctx *c, int nnu, const double *kappa)
     FTTE_HIP(c, hipMemcpyAsync(c->kappa[0], kappa, sizeof(double) * nnu * c->ncell, hipMemcpyHostToDevice, c->stream));
     FTTE_HIP(c, hipStreamSynchronize(c->stream));
     c->nnu = nnu;
-    c->kappa_ready[0] = true; c->kappa_ready[1] = c->kappa_ready[2] = false;
+    c->kappa_ready[0] = true; c->kappa_ready[1] = c->kappa_ready[2] = c->kappa_ready[3] = false;
     return FTTE_OK;
 }
 
@@ -589,7 +626,7 @@ int ftte_set_opacity_device(ftte_ctx *c, int nnu, const double *kappa_dev)
     FTTE_HIP(c, hipMemcpyAsync(c->kappa[0], kappa_dev, sizeof(double) * nnu * c->ncell, hipMemcpyDeviceToDevice, c->stream));
     FTTE_HIP(c, hipStreamSynchronize(c->stream)); // the sweep may run on another stream: the copy must have landed
     c->nnu = nnu;
-    c->kappa_ready[0] = true; c->kappa_ready[1] = c->kappa_ready[2] = false;
+    c->kappa_ready[0] = true; c->kappa_ready[1] = c->kappa_ready[2] = c->kappa_ready[3] = false;
     return FTTE_OK;
 }
 
@@ -615,7 +652,7 @@ int ftte_set_species(ftte_ctx *c, int nnu, const double *HI, const double *HeI, 
     if (e != hipSuccess) return fail(c, FTTE_ERR_NO_DEVICE, std::string("ftte_set_species: ") + hipGetErrorString(e));
     if (lrc) return fail(c, FTTE_ERR_NO_DEVICE, "ftte_set_species: kernel launch failed");
     c->nnu = nnu;
-    c->kappa_ready[0] = true; c->kappa_ready[1] = c->kappa_ready[2] = false;
+    c->kappa_ready[0] = true; c->kappa_ready[1] = c->kappa_ready[2] = c->kappa_ready[3] = false;
     return FTTE_OK;
 }
 
@@ -632,7 +669,7 @@ static int set_emission(ftte_ctx *c, int mode, const double *values, bool on_dev
     FTTE_HIP(c, hipMemcpyAsync(c->emis[0], values, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
     FTTE_HIP(c, hipStreamSynchronize(c->stream)); // the sweep may run on another stream: the copy must have landed
     c->emit_mode = mode;
-    c->emis_ready[0] = true; c->emis_ready[1] = c->emis_ready[2] = false;
+    c->emis_ready[0] = true; c->emis_ready[1] = c->emis_ready[2] = c->emis_ready[3] = false;
     (void)who;
     return FTTE_OK;
 }

@@ -73,12 +73,20 @@ struct LaunchRec {
 };
 
 // ---- refined cell arrays (ftte_amr.h) ------------------------------------------------------------------
-constexpr int kAmrBatch = 32; // directions in flight in the forest path
+constexpr int kAmrBatch = 48; // directions in flight in the forest path
+
+// One active segment of a direction's forest, in processing order (sorted by depth)
+struct SegRec {
+    int32_t seg;     // 3 * leaf + slot: where its outgoing intensity and mean are stored
+    int32_t up, up2; // upstream segment (AmrForest::kInflow: the boundary), second one of the mean-of-two rule or -1
+    int32_t pad;
+    double dpath;    // cell size * segment length
+};
 
 struct AmrDirRec {
-    const int32_t *up, *up2, *order; // device copies of AmrForest::up / up2 / order
-    const double *dpath;
-    double *Iout, *mean;             // [3 ncell][nnu] scratch of this direction's slot
+    const SegRec *rec;       // [active segments], depth after depth
+    const uint8_t *active;   // [ncell] bit 0: the leaf has an xz segment, bit 1: a yz segment
+    double *Iout, *mean;     // [3 ncell][nnu] scratch of this direction's slot
     double w;
 };
 
@@ -87,7 +95,8 @@ struct AmrLevelRec {
     int64_t first[kAmrBatch + 1]; // prefix of the per-direction element counts of this depth
     int64_t begin[kAmrBatch];     // where this depth starts in each direction's `order`
     int64_t total;                // first[ndir]
-    const double *kappa, *uvb, *emis; // cell-array order
+    const double *kappa, *uvb, *emis; // element (group g, cell c) at g * group_stride + c * cell_stride
+    int64_t group_stride, cell_stride;
     int64_t ncell;
     int32_t ndir, nnu, emit;
     ftte_consts math;

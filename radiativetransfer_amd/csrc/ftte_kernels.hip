@@ -487,35 +487,39 @@ int launch_merge(const double *const *acc, const int *layout, int count, double 
 // segment left (or the inflow, or the mean of two segments: transportRoutinesModule.f90:594-649),
 // crosses its own segment (ftte_math.h), and stores the outgoing intensity and the segment's mean.
 // ------------------------------------------------------------------------------------------------
+// grid: x over the (segment, frequency group) pairs of the fullest direction, y = direction of the batch.
+// NNU_SHIFT >= 0: nnu = 1 << NNU_SHIFT (no division); -1: any nnu.
+template <int NNU_SHIFT>
 __global__ void __launch_bounds__(256) amr_level_kernel(const AmrLevelRec A)
 {
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int nnu = A.nnu;
-    const long e = tid / nnu;
-    const int nu = (int)(tid - e * nnu);
-    if (e >= A.total) return;
-    int d = 0;
-    while (d + 1 < A.ndir && e >= A.first[d + 1]) ++d;
+    const int d = blockIdx.y;
+    const unsigned count = (unsigned)(A.first[d + 1] - A.first[d]);
+    const unsigned nnu = (unsigned)A.nnu;
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    const unsigned e = NNU_SHIFT >= 0 ? t >> (NNU_SHIFT >= 0 ? NNU_SHIFT : 0) : t / nnu;
+    const unsigned nu = NNU_SHIFT >= 0 ? t & (nnu - 1u) : t - e * nnu;
+    if (e >= count) return;
     const AmrDirRec &D = A.dir[d];
-    const int seg = D.order[A.begin[d] + (e - A.first[d])];
-    const int up = D.up[seg], up2 = D.up2[seg];
-    double *Io = D.Iout + (long)seg * nnu;
+    const SegRec R = D.rec[A.begin[d] + e];
+    const int seg = R.seg, up = R.up, up2 = R.up2;
+    const size_t at = (size_t)(unsigned)seg * nnu + nu;
     double I;
     if (up < 0) I = A.uvb[nu];
     else {
-        I = D.Iout[(long)up * nnu + nu];
-        if (up2 >= 0) I = 0.5 * (I + D.Iout[(long)up2 * nnu + nu]);
+        I = D.Iout[(size_t)(unsigned)up * nnu + nu];
+        if (up2 >= 0) I = 0.5 * (I + D.Iout[(size_t)(unsigned)up2 * nnu + nu]);
     }
-    const int cell = seg / 3;
-    const double kap = A.kappa[(long)nu * A.ncell + cell];
+    const unsigned cell = (unsigned)seg / 3u;
+    const size_t kat = (size_t)nu * A.group_stride + (size_t)cell * A.cell_stride;
+    const double kap = A.kappa[kat];
     double m;
-    if (A.emit == 0) m = ftte_segment(&A.math, &I, kap * D.dpath[seg]);
+    if (A.emit == 0) m = ftte_segment(&A.math, &I, kap * R.dpath);
     else {
-        const double x = A.emis[(long)nu * A.ncell + cell];
-        m = ftte_segment_emit(&A.math, &I, kap * D.dpath[seg], A.emit == 1 ? x : 0.0, A.emit == 2 ? x : 0.0);
+        const double x = A.emis[kat];
+        m = ftte_segment_emit(&A.math, &I, kap * R.dpath, A.emit == 1 ? x : 0.0, A.emit == 2 ? x : 0.0);
     }
-    Io[nu] = I;
-    D.mean[(long)seg * nnu + nu] = m;
+    D.Iout[at] = I;
+    D.mean[at] = m;
 }
 
 // J[g][leaf] += (w / nseg) * (mean_xy + mean_xz + mean_yz), one direction after the other in list order
@@ -524,7 +528,8 @@ __global__ void __launch_bounds__(256) amr_combine_kernel(const AmrLevelRec A, d
 {
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int nnu = A.nnu;
-    const long cell = tid / nnu;
+    const bool pow2 = (nnu & (nnu - 1)) == 0; // wave-uniform: a shift instead of a 64-bit division
+    const long cell = pow2 ? tid >> (31 - __builtin_clz(nnu)) : tid / nnu;
     const int nu = (int)(tid - cell * nnu);
     if (cell >= A.ncell) return;
     double acc_J = zero_first ? 0.0 : J[(long)nu * A.ncell + cell];
@@ -532,18 +537,53 @@ __global__ void __launch_bounds__(256) amr_combine_kernel(const AmrLevelRec A, d
         const AmrDirRec &D = A.dir[d];
         double acc = D.mean[(3 * cell) * nnu + nu];
         int nseg = 1;
-        if (D.up[3 * cell + 1] != -2) { acc += D.mean[(3 * cell + 1) * nnu + nu]; ++nseg; }
-        if (D.up[3 * cell + 2] != -2) { acc += D.mean[(3 * cell + 2) * nnu + nu]; ++nseg; }
+        const int active = D.active[cell];
+        if (active & 1) { acc += D.mean[(3 * cell + 1) * nnu + nu]; ++nseg; }
+        if (active & 2) { acc += D.mean[(3 * cell + 2) * nnu + nu]; ++nseg; }
         acc_J += ftte_cell_mean(acc, nseg, D.w);
     }
     J[(long)nu * A.ncell + cell] = acc_J;
 }
 
+// dst[cell][g] = src[g][cell]: the forest path reads all groups of a cell together, one 8 * nnu byte run per segment
+__global__ void __launch_bounds__(256) cell_major_kernel(const double *__restrict__ src, double *__restrict__ dst, long ncell, int nnu)
+{
+    extern __shared__ double tile[]; // [nnu][64 + 1]
+    const long c0 = (long)blockIdx.x * 64;
+    for (int i = threadIdx.x; i < nnu * 64; i += 256) {
+        const int g = i >> 6, c = i & 63;
+        if (c0 + c < ncell) tile[g * 65 + c] = src[(long)g * ncell + c0 + c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nnu * 64; i += 256) {
+        const int c = i / nnu, g = i - c * nnu;
+        if (c0 + c < ncell) dst[(c0 + c) * nnu + g] = tile[g * 65 + c];
+    }
+}
+
+int launch_cell_major(const double *src, double *dst, long ncell, int nnu, hipStream_t stream)
+{
+    hipLaunchKernelGGL(cell_major_kernel, dim3((unsigned)((ncell + 63) / 64)), dim3(256), (size_t)nnu * 65 * sizeof(double), stream, src, dst,
+                       ncell, nnu);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 int launch_amr_level(const AmrLevelRec &A, hipStream_t stream)
 {
     if (A.total <= 0) return 0;
-    const long threads = A.total * A.nnu;
-    hipLaunchKernelGGL(amr_level_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, A);
+    int64_t most = 0;
+    for (int d = 0; d < A.ndir; ++d) most = A.first[d + 1] - A.first[d] > most ? A.first[d + 1] - A.first[d] : most;
+    const int64_t threads = most * A.nnu;
+    if (threads >= ((int64_t)1 << 32)) return -1;
+    const dim3 grid((unsigned)((threads + 255) / 256), (unsigned)A.ndir);
+    switch (A.nnu) {
+    case 1: hipLaunchKernelGGL(amr_level_kernel<0>, grid, dim3(256), 0, stream, A); break;
+    case 2: hipLaunchKernelGGL(amr_level_kernel<1>, grid, dim3(256), 0, stream, A); break;
+    case 4: hipLaunchKernelGGL(amr_level_kernel<2>, grid, dim3(256), 0, stream, A); break;
+    case 8: hipLaunchKernelGGL(amr_level_kernel<3>, grid, dim3(256), 0, stream, A); break;
+    case 16: hipLaunchKernelGGL(amr_level_kernel<4>, grid, dim3(256), 0, stream, A); break;
+    default: hipLaunchKernelGGL(amr_level_kernel<-1>, grid, dim3(256), 0, stream, A); break;
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
