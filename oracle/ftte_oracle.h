@@ -124,6 +124,12 @@ void fo_device_attenuation(int64_t count, const double *tau, double *e, double *
 void fo_device_log(int64_t count, const double *x, double *out);
 void fo_device_cell_mean(int64_t count, const double *acc, int nseg, double w, double *out);
 
+/* ---- ionisation equilibrium (ftte_oracle_chem.c): solveRateEquations, equiSources.f90:3459-3677 ---- */
+long fo_solve_rate_equations(int n, long ncell, const int32_t *level, double box, const double *rho, const double *tgas,
+                             double *HI_io, double *HeI_io, double *HeII_io, const double *krate, int run_uvb, const double *J,
+                             const double *ksi, const double *uniform, double threshold, int nratec, double logtem0,
+                             double logtem9, double dlogtem, const double *k, long *iterations);
+
 #ifdef __cplusplus
 }
 #endif

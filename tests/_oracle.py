@@ -234,3 +234,27 @@ def point_sources(n, level, HI, HeI, HeII, rho, abun2, box, dust, src_leaf, src_
     if rc:
         raise ValueError(f"fo_point_sources -> {rc}")
     return rates, hp.value
+
+
+def solve_rate_equations(n, level, box, rho, tgas, HI, HeI, HeII, krate, run_uvb, J, ksi, uniform, threshold, logtem0, logtem9,
+                         dlogtem, k):
+    """fo_solve_rate_equations: returns (HI, HeI, HeII, status, bisection steps); status 0 or 1 + first stopping cell."""
+    level = np.ascontiguousarray(level, dtype=np.int32)
+    nc = len(level)
+    rho, tgas, k = _f64(rho), _f64(tgas), _f64(k)
+    HI, HeI, HeII = (np.array(a, dtype=np.float64, copy=True) for a in (HI, HeI, HeII))
+    krate = None if krate is None else _f64(krate)
+    J = None if J is None else _f64(J)
+    ksi = _f64(ksi if ksi is not None else np.zeros(9))
+    uniform = _f64(uniform if uniform is not None else np.zeros(3))
+    L = lib()
+    dp = C.POINTER(C.c_double)
+    L.fo_solve_rate_equations.restype = C.c_long
+    L.fo_solve_rate_equations.argtypes = [C.c_int, C.c_long, C.POINTER(C.c_int32), C.c_double, dp, dp, dp, dp, dp, dp, C.c_int, dp, dp, dp,
+                                          C.c_double, C.c_int, C.c_double, C.c_double, C.c_double, dp, C.POINTER(C.c_long)]
+    its = C.c_long()
+    st = L.fo_solve_rate_equations(n, nc, level.ctypes.data_as(C.POINTER(C.c_int32)), box, _dp(rho), _dp(tgas), _dp(HI), _dp(HeI), _dp(HeII),
+                                   _dp(krate) if krate is not None else None, int(run_uvb), _dp(J) if J is not None else None, _dp(ksi),
+                                   _dp(uniform), float(threshold), k.shape[1], float(logtem0), float(logtem9), float(dlogtem), _dp(k),
+                                   C.byref(its))
+    return HI, HeI, HeII, int(st), its.value
