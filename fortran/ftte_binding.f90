@@ -187,6 +187,54 @@ module ftte_binding
        real(c_double), intent(in) :: a_smc(7,5)
      end function ftte_dust_cross_section
 
+     ! ---- ionisation equilibrium (solveRateEquations, equiSources.f90:3459-3677)
+
+     integer(c_int) function ftte_set_rate_coefficients(ctx, nratec, logtem0, logtem9, dlogtem, k1a, k2a, k3a, k4a, k5a, k6a) &
+          bind(C, name='ftte_set_rate_coefficients')
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: nratec
+       real(c_double), value :: logtem0, logtem9, dlogtem
+       real(c_double), intent(in) :: k1a(*), k2a(*), k3a(*), k4a(*), k5a(*), k6a(*)
+     end function ftte_set_rate_coefficients
+
+     integer(c_int) function ftte_set_temperature(ctx, tgas) bind(C, name='ftte_set_temperature')
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: tgas(*)
+     end function ftte_set_temperature
+
+     integer(c_int) function ftte_solve_rate_equations(ctx, run_uvb_transfer, J, ksi, uniform, self_shielding_threshold, &
+          use_point_rates, max_change) bind(C, name='ftte_solve_rate_equations')
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: run_uvb_transfer, use_point_rates
+       real(c_double), intent(in) :: J(*)          ! (ncell, 3): Jmean1..3
+       real(c_double), intent(in) :: ksi(3,3)      ! (ksi24, ksi25, ksi26) x (group1, group2, group3)
+       real(c_double), intent(in) :: uniform(3)
+       real(c_double), value :: self_shielding_threshold
+       real(c_double), intent(out) :: max_change
+     end function ftte_solve_rate_equations
+
+     integer(c_int) function ftte_get_medium(ctx, HI, HeI, HeII) bind(C, name='ftte_get_medium')
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(out) :: HI(*), HeI(*), HeII(*)
+     end function ftte_get_medium
+
+     integer(c_int) function ftte_compute_opacities(ctx, nnu, beta) bind(C, name='ftte_compute_opacities')
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: nnu
+       real(c_double), intent(in) :: beta(*)       ! (nnu, 3)
+     end function ftte_compute_opacities
+
+     integer(c_int) function ftte_set_point_rates(ctx, rates) bind(C, name='ftte_set_point_rates')
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: rates(*)      ! (ncell, 6)
+     end function ftte_set_point_rates
+
   end interface
 
 contains

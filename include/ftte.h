@@ -47,7 +47,8 @@ typedef enum {
     FTTE_ERR_DOMINANT_AXIS = -9,  /* equiSources.f90:1450 'error in theta or phi' (tie)            */
     FTTE_ERR_PATTERN = -10,       /* transportRoutinesModule.f90:33-36,60-63; equiSources.f90:1523 */
     FTTE_ERR_IZONE = -11,         /* rotateIndices called with izone outside 1..24                 */
-    FTTE_ERR_PIXEL = -12          /* equiSources.f90:2152-2160 'nside/ipix out of range'           */
+    FTTE_ERR_PIXEL = -12,         /* equiSources.f90:2152-2160 'nside/ipix out of range'           */
+    FTTE_ERR_RATES = -13          /* equiSources.f90:3637-3654: a species fraction left [0, 1]     */
 } ftte_status;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
@@ -170,10 +171,47 @@ int ftte_point_sources(ftte_ctx *ctx, int nsrc, const int64_t *src_cell, const d
 /* rates[6][ncell]: krate24, krate25, krate26, crate24, crate25, crate26 (zoneType, definitionsModule.f90:166) */
 int ftte_get_point_rates(ftte_ctx *ctx, double *rates);
 int ftte_point_rates_device(ftte_ctx *ctx, double **rates_dev);
+/* Replace the device-resident rates, e.g. by the sum over the GPUs that traced different stars; same layout */
+int ftte_set_point_rates(ftte_ctx *ctx, const double *rates);
 /* rmax(1:30), equiSources.f90:296-309 (formula, halved) */
 int ftte_rmax(double *rmax30);
 /* dustCrossSection(lambda [micron]), dustModule.f90:30-73, SMC curve; a_smc(7,5) Fortran order */
 double ftte_dust_cross_section(double lambda_micron, const double *a_smc);
+
+/* ---- ionisation equilibrium --------------------------------------------------------------------
+ * solveRateEquations(currentCell, nx, runUVBTransfer), equiSources.f90:3459-3677, for every leaf: the
+ * consumer of J (Jmean1..3) and of the point-source rates (krate24..26), and the producer of the next
+ * iteration's HI, HeI, HeII (driver loop equiSources.f90:1811-1819).  Per cell: photo-rates per
+ * absorber, collisional rate coefficients interpolated in log T, bisection on the electron density.
+ * The update works on the device-resident medium of ftte_set_medium (which must have been given rho)
+ * and leaves the new HI, HeI, HeII there; every operation is the reference's, in its order. */
+
+/* k1a..k6a(nratec) of calc_rates / coll_rates (calc_rates.f:324-337) and the table's logtem0, logtem9,
+ * dlogtem (equiSources.f90:174-176) */
+int ftte_set_rate_coefficients(ftte_ctx *ctx, int nratec, double logtem0, double logtem9, double dlogtem, const double *k1a,
+                               const double *k2a, const double *k3a, const double *k4a, const double *k5a, const double *k6a);
+/* zoneType%tgas per leaf [K] */
+int ftte_set_temperature(ftte_ctx *ctx, const double *tgas);
+/* run_uvb_transfer != 0 (:3545-3553): J[3][ncell] (Jmean1..3) and ksi[3][3] = (ksi24, ksi25, ksi26) of group1..3
+ * (normCrossSectionType, definitionsModule.f90:94-103); uniform may be NULL.
+ * run_uvb_transfer == 0 (:3554-3562): uniform[3] = uniformQuasar*quasar%ksi2x + uniformStellar*stellar%ksi2x for
+ * x = 4, 5, 6, applied where the Lyman-limit mean free path is at least self_shielding_threshold; J, ksi may be NULL.
+ * use_point_rates != 0: krate24..26 of the device-resident point-source rates enter (:3520-3542); 0: they are zero.
+ * max_change (may be NULL): largest change of HI/nH, HeI/nHe, HeII/nHe over the cells.
+ * FTTE_ERR_RATES where the reference prints the species and stops; the medium is then left unchanged. */
+int ftte_solve_rate_equations(ftte_ctx *ctx, int run_uvb_transfer, const double *J, const double *ksi, const double *uniform,
+                              double self_shielding_threshold, int use_point_rates, double *max_change);
+/* Same with J in device memory, e.g. the output of ftte_diffuse_sweep_device: the iteration stays on the device */
+int ftte_solve_rate_equations_device(ftte_ctx *ctx, int run_uvb_transfer, const double *J_dev, const double *ksi,
+                                     const double *uniform, double self_shielding_threshold, int use_point_rates,
+                                     double *max_change);
+/* HI, HeI, HeII of the device-resident medium, ncell each */
+int ftte_get_medium(ftte_ctx *ctx, double *HI, double *HeI, double *HeII);
+/* computeOpacities (equiSources.f90:4956-4983) on the device-resident medium: kappa[g] = HI beta[0][g] + HeI beta[1][g] +
+ * HeII beta[2][g]; equivalent to ftte_set_species with the medium's arrays, without the host round trip */
+int ftte_compute_opacities(ftte_ctx *ctx, int nnu, const double *beta);
+/* bisection steps of the last ftte_solve_rate_equations*, summed over the cells */
+long long ftte_rate_equation_steps(const ftte_ctx *ctx);
 
 /* ---- tuning and instrumentation ------------------------------------------------------------- */
 

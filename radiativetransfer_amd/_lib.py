@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(PKG, "libftte.so")
 STATUS = {
     0: "FTTE_OK", -1: "FTTE_ERR_ARG", -2: "FTTE_ERR_STATE", -3: "FTTE_ERR_NO_DEVICE", -4: "FTTE_ERR_UNSUPPORTED",
     -5: "FTTE_ERR_NOT_CUBIC", -6: "FTTE_ERR_LEVELS", -7: "FTTE_ERR_PHI", -8: "FTTE_ERR_THETA",
-    -9: "FTTE_ERR_DOMINANT_AXIS", -10: "FTTE_ERR_PATTERN", -11: "FTTE_ERR_IZONE", -12: "FTTE_ERR_PIXEL",
+    -9: "FTTE_ERR_DOMINANT_AXIS", -10: "FTTE_ERR_PATTERN", -11: "FTTE_ERR_IZONE", -12: "FTTE_ERR_PIXEL", -13: "FTTE_ERR_RATES",
 }
 
 
@@ -59,6 +59,14 @@ SIGNATURES = {
     "ftte_point_sources": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int64), _dp, _ip]),
     "ftte_get_point_rates": (C.c_int, [_vp, _dp]),
     "ftte_point_rates_device": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "ftte_set_point_rates": (C.c_int, [_vp, _dp]),
+    "ftte_set_rate_coefficients": (C.c_int, [_vp, C.c_int, C.c_double, C.c_double, C.c_double, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "ftte_set_temperature": (C.c_int, [_vp, _dp]),
+    "ftte_solve_rate_equations": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, C.c_double, C.c_int, _dp]),
+    "ftte_solve_rate_equations_device": (C.c_int, [_vp, C.c_int, _vp, _dp, _dp, C.c_double, C.c_int, _dp]),
+    "ftte_get_medium": (C.c_int, [_vp, _dp, _dp, _dp]),
+    "ftte_compute_opacities": (C.c_int, [_vp, C.c_int, _dp]),
+    "ftte_rate_equation_steps": (C.c_longlong, [_vp]),
     "ftte_rmax": (C.c_int, [_dp]),
     "ftte_dust_cross_section": (C.c_double, [C.c_double, _dp]),
     "ftte_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),

@@ -317,7 +317,67 @@ class StellarTransfer(DiffuseTransfer):
         self._ok(self._lib.ftte_get_point_rates(self._ctx, _dp(out)))
         return out
 
+    def set_rates(self, rates):
+        """Replace the device-resident rates (e.g. by their sum over the ranks that traced different stars)."""
+        rates = _f64(rates)
+        if rates.shape != (6, self.ncell):
+            raise ValueError("rates must have shape [6][ncell]")
+        self._ok(self._lib.ftte_set_point_rates(self._ctx, _dp(rates)))
+
     def rates_device_ptr(self) -> int:
         p = C.c_void_p()
         self._ok(self._lib.ftte_point_rates_device(self._ctx, C.byref(p)))
         return p.value
+
+    # -- ionisation equilibrium: solveRateEquations (equiSources.f90:3459-3677) on the device-resident medium
+    def set_rate_coefficients(self, logtem0: float, logtem9: float, dlogtem: float, k):
+        """k[6][nratec] = k1a..k6a of the reference's calc_rates / coll_rates; table bounds of equiSources.f90:174-176."""
+        k = _f64(k)
+        if k.ndim != 2 or k.shape[0] != 6:
+            raise ValueError("k must have shape [6][nratec]")
+        self._ok(self._lib.ftte_set_rate_coefficients(self._ctx, k.shape[1], float(logtem0), float(logtem9), float(dlogtem),
+                                                      *[_dp(k[r]) for r in range(6)]))
+
+    def set_temperature(self, tgas):
+        tgas = _f64(tgas)
+        if self.ncell and tgas.size != self.ncell:
+            raise ValueError("tgas must have ncell elements")
+        self._ok(self._lib.ftte_set_temperature(self._ctx, _dp(tgas)))
+
+    def _solve(self, fn, J, run_uvb, ksi, uniform, threshold, use_point_rates):
+        ksi = None if ksi is None else _f64(ksi).reshape(3, 3)
+        uniform = None if uniform is None else _f64(uniform).reshape(3)
+        change = C.c_double()
+        self._ok(fn(self._ctx, int(bool(run_uvb)), J, None if ksi is None else _dp(ksi), None if uniform is None else _dp(uniform),
+                    float(threshold), int(bool(use_point_rates)), C.byref(change)))
+        return change.value
+
+    def solve_rate_equations(self, run_uvb: bool, J=None, ksi=None, uniform=None, threshold: float = 0.0,
+                             use_point_rates: bool = False) -> float:
+        """One equilibrium update of HI, HeI, HeII in the device-resident medium; J[3][ncell] host array (run_uvb) or the
+        uniform background rates.  Returns the largest change of a species fraction."""
+        J = None if J is None else _f64(J)
+        if J is not None and J.shape != (3, self.ncell):
+            raise ValueError("J must have shape [3][ncell]")
+        return self._solve(self._lib.ftte_solve_rate_equations, None if J is None else _dp(J), run_uvb, ksi, uniform, threshold,
+                           use_point_rates)
+
+    def solve_rate_equations_device(self, j_device_ptr: int, ksi, use_point_rates: bool = False) -> float:
+        """Same with J[3][ncell] in device memory (e.g. what transport_device wrote)."""
+        return self._solve(self._lib.ftte_solve_rate_equations_device, C.c_void_p(j_device_ptr), True, ksi, None, 0.0, use_point_rates)
+
+    def medium(self):
+        out = [np.empty(max(self.ncell, 1)) for _ in range(3)]
+        self._ok(self._lib.ftte_get_medium(self._ctx, *[_dp(a) for a in out]))
+        return out
+
+    def compute_opacities_from_medium(self, beta):
+        """computeOpacities (equiSources.f90:4956) on the device-resident HI, HeI, HeII; beta[3][nnu]."""
+        beta = _f64(beta)
+        if beta.ndim != 2 or beta.shape[0] != 3:
+            raise ValueError("beta must have shape [3][nnu]")
+        self._ok(self._lib.ftte_compute_opacities(self._ctx, beta.shape[1], _dp(beta)))
+        self.nnu = beta.shape[1]
+
+    def rate_equation_steps(self) -> int:
+        return int(self._lib.ftte_rate_equation_steps(self._ctx))

@@ -120,6 +120,27 @@ struct ftte_ctx {
     size_t amr_scratch_cap = 0; // elements per array
 
     PointState point; // point sources: rate tables, medium, tracer scratch
+
+    // ionisation equilibrium (solveRateEquations)
+    std::vector<int8_t> leaf_level;  // per leaf, as handed to ftte_set_grid
+    int8_t *chem_level = nullptr;
+    double *chem_k = nullptr;        // [6][nratec]
+    int chem_nratec = 0;
+    double chem_logtem0 = 0, chem_logtem9 = 0, chem_dlogtem = 0;
+    double *chem_logtem = nullptr;   // [ncell] log of the gas temperature
+    bool chem_temperature_set = false;
+    double *chem_out = nullptr, *chem_J = nullptr; // [3][ncell] each
+    unsigned long long *chem_counters = nullptr;   // first bad cell, bits of the largest change, bisection steps
+    long long chem_steps = 0;
+
+    void drop_chem_grid()
+    {
+        if (chem_level) { (void)hipFree(chem_level); chem_level = nullptr; }
+        if (chem_logtem) { (void)hipFree(chem_logtem); chem_logtem = nullptr; }
+        if (chem_out) { (void)hipFree(chem_out); chem_out = nullptr; }
+        if (chem_J) { (void)hipFree(chem_J); chem_J = nullptr; }
+        chem_temperature_set = false;
+    }
 };
 
 namespace {
@@ -552,6 +573,9 @@ int ftte_destroy(ftte_ctx *c)
     if (c->amr_kappa) (void)hipFree(c->amr_kappa);
     if (c->amr_emis) (void)hipFree(c->amr_emis);
     c->point.release();
+    c->drop_chem_grid();
+    if (c->chem_k) (void)hipFree(c->chem_k);
+    if (c->chem_counters) (void)hipFree(c->chem_counters);
     for (auto &t : c->timing) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -593,6 +617,8 @@ int ftte_set_grid(ftte_ctx *c, int nx, int ny, int nz, int64_t ncell, const int3
     (void)hipStreamSynchronize(c->stream);
     free_forests(c);
     c->point.drop_grid();
+    c->drop_chem_grid();
+    c->leaf_level.assign(level, level + ncell);
     c->n = nx; c->ncell = ncell; c->box = box_cm; c->grid_set = true;
     c->kappa_ready[0] = c->kappa_ready[1] = c->kappa_ready[2] = c->kappa_ready[3] = false;
     c->plan.valid = false;
@@ -1022,6 +1048,18 @@ int ftte_get_point_rates(ftte_ctx *c, double *rates)
     return FTTE_OK;
 }
 
+int ftte_set_point_rates(ftte_ctx *c, const double *rates)
+{
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (!rates) return fail(c, FTTE_ERR_ARG, "ftte_set_point_rates: bad argument");
+    FTTE_HIP(c, hipSetDevice(c->device));
+    if ((rc = point_zero_rates(c->point, c->stream, c->ncell, &c->err))) return rc;
+    FTTE_HIP(c, hipMemcpyAsync(c->point.rates, rates, sizeof(double) * 6 * (size_t)c->ncell, hipMemcpyHostToDevice, c->stream));
+    FTTE_HIP(c, hipStreamSynchronize(c->stream));
+    return FTTE_OK;
+}
+
 int ftte_point_rates_device(ftte_ctx *c, double **rates_dev)
 {
     int rc = check_ready(c, false);
@@ -1031,6 +1069,165 @@ int ftte_point_rates_device(ftte_ctx *c, double **rates_dev)
     *rates_dev = c->point.rates;
     return FTTE_OK;
 }
+
+// ---- ionisation equilibrium ---------------------------------------------------------------------------------------
+
+int ftte_set_rate_coefficients(ftte_ctx *c, int nratec, double logtem0, double logtem9, double dlogtem, const double *k1a,
+                               const double *k2a, const double *k3a, const double *k4a, const double *k5a, const double *k6a)
+{
+    if (!c) return FTTE_ERR_ARG;
+    if (nratec < 2 || !(dlogtem > 0.0) || !(logtem9 > logtem0) || !k1a || !k2a || !k3a || !k4a || !k5a || !k6a)
+        return fail(c, FTTE_ERR_ARG, "ftte_set_rate_coefficients: bad argument");
+    FTTE_HIP(c, hipSetDevice(c->device));
+    FTTE_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->chem_k && c->chem_nratec != nratec) { FTTE_HIP(c, hipFree(c->chem_k)); c->chem_k = nullptr; }
+    if (!c->chem_k) FTTE_HIP(c, hipMalloc((void **)&c->chem_k, sizeof(double) * 6 * (size_t)nratec));
+    const double *src[6] = {k1a, k2a, k3a, k4a, k5a, k6a};
+    for (int r = 0; r < 6; ++r)
+        FTTE_HIP(c, hipMemcpyAsync(c->chem_k + (size_t)r * nratec, src[r], sizeof(double) * nratec, hipMemcpyHostToDevice, c->stream));
+    FTTE_HIP(c, hipStreamSynchronize(c->stream));
+    c->chem_nratec = nratec;
+    c->chem_logtem0 = logtem0; c->chem_logtem9 = logtem9; c->chem_dlogtem = dlogtem;
+    return FTTE_OK;
+}
+
+int ftte_set_temperature(ftte_ctx *c, const double *tgas)
+{
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (!tgas) return fail(c, FTTE_ERR_ARG, "ftte_set_temperature: bad argument");
+    FTTE_HIP(c, hipSetDevice(c->device));
+    // the logarithm is taken here, on the host, so that the device update consists of IEEE-exact operations only
+    std::vector<double> logtem((size_t)c->ncell);
+    for (int64_t q = 0; q < c->ncell; ++q) logtem[(size_t)q] = std::log(tgas[q]);
+    if (!c->chem_logtem) FTTE_HIP(c, hipMalloc((void **)&c->chem_logtem, sizeof(double) * (size_t)c->ncell));
+    FTTE_HIP(c, hipMemcpyAsync(c->chem_logtem, logtem.data(), sizeof(double) * (size_t)c->ncell, hipMemcpyHostToDevice, c->stream));
+    FTTE_HIP(c, hipStreamSynchronize(c->stream));
+    c->chem_temperature_set = true;
+    return FTTE_OK;
+}
+
+static int solve_rates(ftte_ctx *c, int run_uvb, const double *J, bool J_on_device, const double *ksi, const double *uniform,
+                       double threshold, int use_point_rates, double *max_change, const char *who)
+{
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    PointState &P = c->point;
+    if (!c->chem_k) return fail(c, FTTE_ERR_STATE, std::string(who) + ": no rate coefficients (ftte_set_rate_coefficients)");
+    if (!c->chem_temperature_set) return fail(c, FTTE_ERR_STATE, std::string(who) + ": no temperature (ftte_set_temperature)");
+    if (!P.medium_ready || P.medium_cells != c->ncell || !P.rho_given)
+        return fail(c, FTTE_ERR_STATE, std::string(who) + ": no medium with density (ftte_set_medium with rho)");
+    if (run_uvb && (!J || !ksi)) return fail(c, FTTE_ERR_ARG, std::string(who) + ": the transfer-driven update needs J and ksi");
+    if (!run_uvb && !uniform) return fail(c, FTTE_ERR_ARG, std::string(who) + ": the uniform-background update needs the background rates");
+    if (use_point_rates && (!P.rates || P.rates_cells != c->ncell))
+        return fail(c, FTTE_ERR_STATE, std::string(who) + ": no point-source rates (ftte_set_zero_rates / ftte_point_sources)");
+    FTTE_HIP(c, hipSetDevice(c->device));
+    const size_t nc = (size_t)c->ncell;
+    if (!c->chem_level) {
+        FTTE_HIP(c, hipMalloc((void **)&c->chem_level, nc));
+        FTTE_HIP(c, hipMemcpyAsync(c->chem_level, c->leaf_level.data(), nc, hipMemcpyHostToDevice, c->stream));
+    }
+    if (!c->chem_out) FTTE_HIP(c, hipMalloc((void **)&c->chem_out, sizeof(double) * 3 * nc));
+    if (!c->chem_counters) FTTE_HIP(c, hipMalloc((void **)&c->chem_counters, sizeof(unsigned long long) * 4));
+    const double *J_dev = nullptr;
+    if (run_uvb) {
+        if (J_on_device) J_dev = J;
+        else {
+            if (!c->chem_J) FTTE_HIP(c, hipMalloc((void **)&c->chem_J, sizeof(double) * 3 * nc));
+            FTTE_HIP(c, hipMemcpyAsync(c->chem_J, J, sizeof(double) * 3 * nc, hipMemcpyHostToDevice, c->stream));
+            J_dev = c->chem_J;
+        }
+    }
+    const unsigned long long init[4] = {~0ull, 0ull, 0ull, 0ull};
+    FTTE_HIP(c, hipMemcpyAsync(c->chem_counters, init, sizeof init, hipMemcpyHostToDevice, c->stream));
+
+    ChemRec R;
+    std::memset(&R, 0, sizeof R);
+    R.level = c->chem_level;
+    R.rho = P.medium[3]; R.logtem = c->chem_logtem;
+    R.HI = P.medium[0]; R.HeI = P.medium[1]; R.HeII = P.medium[2];
+    R.HI_out = c->chem_out; R.HeI_out = c->chem_out + nc; R.HeII_out = c->chem_out + 2 * nc;
+    R.krate = use_point_rates ? P.rates : nullptr;
+    R.J = J_dev;
+    R.k = c->chem_k;
+    R.ncell = c->ncell; R.n = c->n; R.nratec = c->chem_nratec; R.run_uvb = run_uvb ? 1 : 0;
+    R.box = c->box; R.logtem0 = c->chem_logtem0; R.logtem9 = c->chem_logtem9; R.dlogtem = c->chem_dlogtem;
+    if (ksi) std::memcpy(R.ksi, ksi, sizeof R.ksi);
+    if (uniform) std::memcpy(R.uniform, uniform, sizeof R.uniform);
+    R.threshold = threshold;
+    R.first_bad = c->chem_counters; R.max_change = c->chem_counters + 1; R.steps = c->chem_counters + 2;
+    if (launch_rate_equations(R, c->stream)) return fail(c, FTTE_ERR_NO_DEVICE, std::string(who) + ": kernel launch failed");
+    unsigned long long out[4];
+    FTTE_HIP(c, hipMemcpyAsync(out, c->chem_counters, sizeof out, hipMemcpyDeviceToHost, c->stream));
+    FTTE_HIP(c, hipStreamSynchronize(c->stream));
+    if (out[0] != ~0ull) {
+        // the reference prints the species of the cell and stops (equiSources.f90:3637-3654); the state is left as it was
+        return fail(c, FTTE_ERR_RATES, std::string(who) + ": species fraction outside [0, 1] in cell " + std::to_string(out[0]) +
+                                           " (0-based cell-array index)");
+    }
+    for (int f = 0; f < 3; ++f)
+        FTTE_HIP(c, hipMemcpyAsync(P.medium[f], c->chem_out + f * nc, sizeof(double) * nc, hipMemcpyDeviceToDevice, c->stream));
+    FTTE_HIP(c, hipStreamSynchronize(c->stream));
+    double change;
+    std::memcpy(&change, &out[1], sizeof change);
+    if (max_change) *max_change = change;
+    c->chem_steps = (long long)out[2];
+    return FTTE_OK;
+}
+
+int ftte_solve_rate_equations(ftte_ctx *c, int run_uvb_transfer, const double *J, const double *ksi, const double *uniform,
+                              double self_shielding_threshold, int use_point_rates, double *max_change)
+{
+    return solve_rates(c, run_uvb_transfer, J, false, ksi, uniform, self_shielding_threshold, use_point_rates, max_change,
+                       "ftte_solve_rate_equations");
+}
+
+int ftte_solve_rate_equations_device(ftte_ctx *c, int run_uvb_transfer, const double *J_dev, const double *ksi, const double *uniform,
+                                     double self_shielding_threshold, int use_point_rates, double *max_change)
+{
+    return solve_rates(c, run_uvb_transfer, J_dev, true, ksi, uniform, self_shielding_threshold, use_point_rates, max_change,
+                       "ftte_solve_rate_equations_device");
+}
+
+int ftte_get_medium(ftte_ctx *c, double *HI, double *HeI, double *HeII)
+{
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (!HI || !HeI || !HeII) return fail(c, FTTE_ERR_ARG, "ftte_get_medium: bad argument");
+    if (!c->point.medium_ready || c->point.medium_cells != c->ncell) return fail(c, FTTE_ERR_STATE, "no medium: call ftte_set_medium first");
+    FTTE_HIP(c, hipSetDevice(c->device));
+    double *dst[3] = {HI, HeI, HeII};
+    for (int f = 0; f < 3; ++f)
+        FTTE_HIP(c, hipMemcpyAsync(dst[f], c->point.medium[f], sizeof(double) * (size_t)c->ncell, hipMemcpyDeviceToHost, c->stream));
+    FTTE_HIP(c, hipStreamSynchronize(c->stream));
+    return FTTE_OK;
+}
+
+int ftte_compute_opacities(ftte_ctx *c, int nnu, const double *beta)
+{
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (nnu < 1 || !beta) return fail(c, FTTE_ERR_ARG, "ftte_compute_opacities: bad argument");
+    if (!c->point.medium_ready || c->point.medium_cells != c->ncell) return fail(c, FTTE_ERR_STATE, "no medium: call ftte_set_medium first");
+    FTTE_HIP(c, hipSetDevice(c->device));
+    FTTE_HIP(c, hipStreamSynchronize(c->stream));
+    if ((rc = ensure_kappa(c, nnu))) return rc;
+    double *dbeta = nullptr;
+    FTTE_HIP(c, hipMalloc((void **)&dbeta, sizeof(double) * 3 * (size_t)nnu));
+    hipError_t e = hipMemcpyAsync(dbeta, beta, sizeof(double) * 3 * nnu, hipMemcpyHostToDevice, c->stream);
+    int lrc = 0;
+    if (e == hipSuccess)
+        lrc = launch_opacity(c->point.medium[0], c->point.medium[1], c->point.medium[2], dbeta, c->kappa[0], (long)c->ncell, nnu, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(dbeta);
+    if (e != hipSuccess) return fail(c, FTTE_ERR_NO_DEVICE, std::string("ftte_compute_opacities: ") + hipGetErrorString(e));
+    if (lrc) return fail(c, FTTE_ERR_NO_DEVICE, "ftte_compute_opacities: kernel launch failed");
+    c->nnu = nnu;
+    c->kappa_ready[0] = true; c->kappa_ready[1] = c->kappa_ready[2] = c->kappa_ready[3] = false;
+    return FTTE_OK;
+}
+
+long long ftte_rate_equation_steps(const ftte_ctx *c) { return c ? c->chem_steps : 0; }
 
 int ftte_rmax(double *rmax30)
 {

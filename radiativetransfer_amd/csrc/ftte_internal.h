@@ -152,4 +152,25 @@ struct TraceRec {
     int32_t *error;
 };
 
+// ---- ionisation equilibrium (solveRateEquations, equiSources.f90:3459-3677) -------------------------------------------
+struct ChemRec {
+    // cell arrays, cell-array order
+    const int8_t *level;       // per leaf (not per node)
+    const double *rho, *logtem;
+    const double *HI, *HeI, *HeII;       // state on entry
+    double *HI_out, *HeI_out, *HeII_out; // state on return
+    const double *krate;       // [6][ncell] point-source rates or nullptr
+    const double *J;           // [3][ncell] or nullptr (uniform background)
+    const double *k;           // [6][nratec] rate coefficients k1a..k6a
+    int64_t ncell;
+    int32_t n, nratec, run_uvb, pad;
+    double box, logtem0, logtem9, dlogtem;
+    double ksi[9];             // [group][ksi24, ksi25, ksi26]
+    double uniform[3];         // uniformQuasar * quasar%ksi + uniformStellar * stellar%ksi, per reaction
+    double threshold;          // selfShieldingThreshold
+    unsigned long long *first_bad; // lowest cell index at which the reference would stop, or ~0
+    unsigned long long *max_change; // bits of the largest change of a species fraction
+    unsigned long long *steps;      // bisection steps taken, all cells
+};
+
 } // namespace ftte

@@ -29,4 +29,7 @@ int launch_rate_lookup(const double *logtab, int dust, int nsample, const double
 int launch_log_table(const double *tables, double *logtab, hipStream_t stream);
 int launch_point_trace(const TraceRec &T, hipStream_t stream);
 
+// ionisation equilibrium of every leaf (solveRateEquations)
+int launch_rate_equations(const ChemRec &R, hipStream_t stream);
+
 } // namespace ftte

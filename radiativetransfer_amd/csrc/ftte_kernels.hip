@@ -904,6 +904,109 @@ int launch_point_trace(const TraceRec &T, hipStream_t stream)
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Ionisation equilibrium per leaf: solveRateEquations, equiSources.f90:3459-3677.  The reference's arithmetic statement by
+// statement (every operation is an IEEE add, multiply or divide; the logarithm of the temperature comes from the host),
+// bisection on the electron density until HeI moves by less than 1e-10 of the helium density.
+// ------------------------------------------------------------------------------------------------
+struct ChemEq { double k1, k2, k3, k4, k5, k6, nh, nhe, kr24, kr25, kr26; };
+
+__device__ __forceinline__ double chem_residual(const ChemEq &q, double de, double &HeI)
+{
+    // :3592-3596 (repeated at :3600-3604 and :3618-3622)
+    const double X = q.k3 * de + q.kr26, Y = q.k4 * de;
+    HeI = (de - q.nh / (1. + q.k2 * de / (q.k1 * de + q.kr24)) - 2. * q.nhe) / (X / Y - 2. - 2. * X / Y);
+    return q.k3 * HeI * de + q.k6 * (q.nhe - HeI - HeI * X / Y) * de + q.kr26 * HeI - HeI * X / Y * (q.k4 * de + q.k5 * de + q.kr25);
+}
+
+__global__ void __launch_bounds__(256) rate_equations_kernel(const ChemRec R)
+{
+    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= R.ncell) return;
+    const double psi = (double)0.76f, mp = (double)1.6726231e-24f, mn = (double)1.67492728e-24f; // definitionsModule.f90:25-28, 261
+    const double mh = mp, mhe = 2. * (mp + mn), pi = (double)3.141592654f;
+    ChemEq q;
+    const double rho = R.rho[c];
+    q.nh = psi * rho / mh;
+    q.nhe = (1. - psi) * rho / mhe;
+    const double HI0 = R.HI[c], HeI0 = R.HeI[c], HeII0 = R.HeII[c];
+    double HI = fmin(HI0, q.nh), HeI = HeI0, HeII = HeII0;
+    if (q.nhe - HeI0 - HeII0 < 0. && HeII < 0.) HeII = 0.; // :3504-3513: only this survives of the branch
+    // rates per cell -> per absorber, :3520-3542
+    const double size = R.box / (double)((float)(1 << R.level[c]) * (float)R.n);
+    const double vol = size * size * size;
+    q.kr24 = (R.krate && HI > 0.) ? R.krate[c] / (vol * HI) : 0.;
+    q.kr25 = (R.krate && HeII > 0.) ? R.krate[R.ncell + c] / (vol * HeII) : 0.;
+    q.kr26 = (R.krate && HeI > 0.) ? R.krate[2 * R.ncell + c] / (vol * HeI) : 0.;
+    q.kr24 = fmax(q.kr24, 0.); q.kr25 = fmax(q.kr25, 0.); q.kr26 = fmax(q.kr26, 0.);
+    if (R.run_uvb) { // :3545-3553
+        const double t1 = 4. * pi * R.J[c], t2 = 4. * pi * R.J[R.ncell + c], t3 = 4. * pi * R.J[2 * R.ncell + c];
+        q.kr24 = q.kr24 + t1 * R.ksi[0] + t2 * R.ksi[3] + t3 * R.ksi[6];
+        q.kr25 = q.kr25 + t3 * R.ksi[7];
+        q.kr26 = q.kr26 + t2 * R.ksi[5] + t3 * R.ksi[8];
+    } else { // :3554-3562
+        const double mfp = 1. / (HI * (double)6.3e-18f + HeI * (double)7.42e-18f + HeII * (double)1.58e-18f);
+        if (mfp >= R.threshold) {
+            q.kr24 = q.kr24 + 4. * pi * R.uniform[0];
+            q.kr25 = q.kr25 + 4. * pi * R.uniform[1];
+            q.kr26 = q.kr26 + 4. * pi * R.uniform[2];
+        }
+    }
+    // rate coefficients at this temperature, :3568-3587
+    double logtem = R.logtem[c];
+    logtem = fmax(logtem, R.logtem0);
+    logtem = fmin(logtem, R.logtem9);
+    int ix = (int)((logtem - R.logtem0) / R.dlogtem) + 1;
+    ix = ix < 1 ? 1 : ix;
+    ix = ix > R.nratec - 1 ? R.nratec - 1 : ix;
+    const double t1 = R.logtem0 + (double)(ix - 1) * R.dlogtem, t2 = R.logtem0 + (double)ix * R.dlogtem, tdef = t2 - t1;
+    double kk[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const double *ka = R.k + (size_t)r * R.nratec;
+        kk[r] = ka[ix - 1] + (logtem - t1) * (ka[ix] - ka[ix - 1]) / tdef;
+    }
+    q.k1 = kk[0]; q.k2 = kk[1]; q.k3 = kk[2]; q.k4 = kk[3]; q.k5 = kk[4]; q.k6 = kk[5];
+
+    // bisection on the electron density, :3589-3633
+    double de1 = (double)1.e-30f, de2 = q.nh + 2. * q.nhe;
+    double res1 = chem_residual(q, de1, HeI);
+    double de = de2;
+    (void)chem_residual(q, de2, HeI);
+    double HeIprev = -1.;
+    unsigned steps = 0;
+    while (fabs(HeI - HeIprev) / q.nhe > 1.e-10 && steps < 4096u) {
+        HeIprev = HeI;
+        de = 0.5 * (de1 + de2);
+        const double res = chem_residual(q, de, HeI);
+        const bool opposite = (res > 0. && res1 < 0.) || (res < 0. && res1 > 0.); // :5044-5058
+        if (opposite) de2 = de;
+        else { de1 = de; res1 = res; }
+        ++steps;
+    }
+    const double X = q.k3 * de + q.kr26, Y = q.k4 * de;
+    HeII = HeI * X / Y;
+    const double HII = q.nh / (1. + q.k2 * de / (q.k1 * de + q.kr24));
+    HI = q.k2 * HII * de / (q.k1 * de + q.kr24);
+    // where the reference prints the species and stops, :3637-3654
+    const bool ok = (HI / q.nh >= 0. && HI / q.nh <= 1.) && (HeI / q.nhe >= 0. && HeI / q.nhe <= 1.) && steps < 4096u;
+    if (!ok) { atomicMin(R.first_bad, (unsigned long long)c); return; }
+    // the reference's (unused) convergence measure, :3671-3674
+    const double c1 = fabs(HI - HI0) * mh / (psi * rho), c2 = fabs(HeI - HeI0) * mhe / ((1. - psi) * rho),
+                 c3 = fabs(HeII - HeII0) * mhe / ((1. - psi) * rho);
+    const double change = fmax(c1, fmax(c2, c3));
+    atomicMax(R.max_change, (unsigned long long)__double_as_longlong(change)); // non-negative doubles order like their bits
+    atomicAdd(R.steps, (unsigned long long)steps);
+    R.HI_out[c] = HI; R.HeI_out[c] = HeI; R.HeII_out[c] = HeII;
+}
+
+int launch_rate_equations(const ChemRec &R, hipStream_t stream)
+{
+    if (R.ncell <= 0) return 0;
+    hipLaunchKernelGGL(rate_equations_kernel, dim3((unsigned)((R.ncell + 255) / 256)), dim3(256), 0, stream, R);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 // kappa[g][c] = HI[c]*beta[0][g] + HeI[c]*beta[1][g] + HeII[c]*beta[2][g]   (equiSources.f90:4977-4980)
 __global__ void __launch_bounds__(256) opacity_kernel(const double *__restrict__ HI, const double *__restrict__ HeI,
                                                       const double *__restrict__ HeII, const double *__restrict__ beta,

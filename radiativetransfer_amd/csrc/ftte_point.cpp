@@ -64,6 +64,7 @@ void PointState::drop_grid()
     for (auto &m : medium) drop(m);
     medium_cells = 0;
     medium_ready = false;
+    rho_given = false;
     drop(rates);
     rates_cells = 0;
     std::vector<int32_t>().swap(node_of_leaf);
@@ -220,6 +221,7 @@ int point_set_medium(PointState &P, hipStream_t stream, int64_t ncell, const dou
     P.medium_cells = ncell;
     P.dust = dust;
     P.medium_ready = true;
+    P.rho_given = field[3] != nullptr;
     return 0;
 }
 

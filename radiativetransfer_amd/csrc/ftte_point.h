@@ -28,6 +28,7 @@ struct PointState {
     int64_t medium_cells = 0;
     int dust = 0;
     bool medium_ready = false;
+    bool rho_given = false;   // ftte_set_medium received a density (the equilibrium update needs it)
     // [6][11^4] rate tables and their logarithms
     double *tables = nullptr, *logtab = nullptr;
     bool tables_ready = false;

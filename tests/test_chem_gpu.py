@@ -1,0 +1,141 @@
+"""Ionisation equilibrium on the GPU (solveRateEquations): libftte.so through the C ABI against the
+vectors the reference's own compiled routine produced, bit for bit -- the device update consists of IEEE additions,
+multiplications and divisions in the reference's order, and the logarithm of the temperature is taken on the host."""
+import numpy as np
+import pytest
+
+import _oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def stellar():
+    import radiativetransfer_amd as rt
+    st = rt.StellarTransfer()
+    yield st
+    st.close()
+
+
+def _load(st, g, tab):
+    st.set_grid(int(g["n"]), g["level"], float(g["box"]))
+    st.set_rate_coefficients(float(tab["logtem0"]), float(tab["logtem9"]), float(tab["dlogtem"]), tab["k"])
+    st.set_medium(g["HI"], g["HeI"], g["HeII"], g["rho"], None, 0)
+    st.set_temperature(g["tgas"])
+
+
+def test_transfer_driven_update_bitwise(stellar, golden):
+    g = golden("chem_uvb_refined")
+    _load(stellar, g, g)
+    change = stellar.solve_rate_equations(True, g["J"], g["ksi"], use_point_rates=False)
+    HI, HeI, HeII = stellar.medium()
+    ref = O.solve_rate_equations(int(g["n"]), g["level"], float(g["box"]), g["rho"], g["tgas"], g["HI"], g["HeI"], g["HeII"], None, True,
+                                 g["J"], g["ksi"], None, 0.0, float(g["logtem0"]), float(g["logtem9"]), float(g["dlogtem"]), g["k"])
+    assert ref[3] == 0
+    assert np.array_equal(HI, ref[0]) and np.array_equal(HeI, ref[1]) and np.array_equal(HeII, ref[2])
+    assert stellar.rate_equation_steps() == ref[4]
+    assert 0 < change <= 1.5 + 1e-9   # the synthetic state starts with up to 1.5 nH of neutral hydrogen in a cell
+
+
+def test_uniform_background_against_reference(stellar, golden):
+    tab, g = golden("chem_uvb_refined"), golden("chem_uniform_background")
+    _load(stellar, g, tab)
+    stellar.solve_rate_equations(False, None, None, g["uniform"], float(g["threshold"]))
+    HI, HeI, HeII = stellar.medium()
+    assert np.array_equal(HI, g["HI_out"]) and np.array_equal(HeI, g["HeI_out"]) and np.array_equal(HeII, g["HeII_out"])
+
+
+def test_point_rates_and_device_J_against_reference(stellar, golden):
+    """The reference's own case in full: J-driven rates plus point-source rates (handed to the device array as a host would
+    after summing them over ranks), J in device memory."""
+    import torch
+    g = golden("chem_uvb_refined")
+    _load(stellar, g, g)
+    rates = np.zeros((6, g["level"].size))
+    rates[:3] = g["krate"]
+    stellar.set_rates(rates)
+    assert np.array_equal(stellar.rates(), rates)
+    J = torch.from_numpy(np.ascontiguousarray(g["J"])).cuda()
+    torch.cuda.synchronize()
+    stellar.solve_rate_equations_device(J.data_ptr(), g["ksi"], use_point_rates=True)
+    HI, HeI, HeII = stellar.medium()
+    assert np.array_equal(HI, g["HI_out"]) and np.array_equal(HeI, g["HeI_out"]) and np.array_equal(HeII, g["HeII_out"])
+
+
+def test_where_the_reference_stops(stellar, golden):
+    from radiativetransfer_amd import FtteError
+    g = golden("chem_uvb_refined")
+    _load(stellar, g, g)
+    J = g["J"].copy()
+    rho = g["rho"].copy()
+    rho[7] = 0.0   # an empty cell: 0/0 in the species fractions, which the reference's range check catches
+    stellar.set_medium(g["HI"], g["HeI"], g["HeII"], rho, None, 0)
+    ref = O.solve_rate_equations(int(g["n"]), g["level"], float(g["box"]), rho, g["tgas"], g["HI"], g["HeI"], g["HeII"], None, True, J,
+                                 g["ksi"], None, 0.0, float(g["logtem0"]), float(g["logtem9"]), float(g["dlogtem"]), g["k"])
+    if ref[3] == 0:
+        pytest.skip("this input does not trip the reference's check")
+    with pytest.raises(FtteError) as e:
+        stellar.solve_rate_equations(True, J, g["ksi"])
+    assert e.value.status == "FTTE_ERR_RATES" and f"cell {ref[3] - 1} " in str(e.value)
+    HI, _, _ = stellar.medium()
+    assert np.array_equal(HI, g["HI"])   # state untouched
+    # call order
+    import radiativetransfer_amd as rt
+    with rt.StellarTransfer() as fresh:
+        fresh.set_grid(2, np.zeros(8, np.int32), 1e22)
+        z = np.full(8, 1e-6)
+        fresh.set_medium(z, z, z, None, None, 0)
+        for need in ("rate coefficients", "temperature", "density"):
+            with pytest.raises(FtteError) as e:
+                fresh.solve_rate_equations(False, None, None, np.zeros(3), 0.0)
+            assert e.value.status == "FTTE_ERR_STATE" and need in str(e.value)
+            if need == "rate coefficients":
+                fresh.set_rate_coefficients(float(g["logtem0"]), float(g["logtem9"]), float(g["dlogtem"]), g["k"])
+            elif need == "temperature":
+                fresh.set_temperature(np.full(8, 1e4))
+        fresh.set_medium(z, z * 0.05, z * 0.01, np.full(8, 3e-24), None, 0)
+        fresh.solve_rate_equations(False, None, None, np.zeros(3), 0.0)
+
+
+def test_closed_loop_on_the_device(stellar, golden):
+    """point sources -> rates, species -> opacities -> diffuse sweep -> J, (rates, J) -> new species, all resident on the
+    device; compared with the same loop through the oracle."""
+    import torch
+    g = golden("chem_uvb_refined")
+    tabs = golden("point16_homogeneous")["tables"]
+    n, level, box = int(g["n"]), g["level"], float(g["box"])
+    nc = level.size
+    st = stellar
+    _load(st, g, g)
+    st.set_rate_tables(tabs)
+    beta = np.array([[6.3e-18, 1.2e-18, 2.0e-19], [0.0, 7.4e-18, 1.5e-18], [0.0, 0.0, 1.6e-18]])  # [species][group]
+    ang = np.array([__import__("radiativetransfer_amd").pix2ang_nest(1, i) for i in range(12)])
+    phi, theta, w = ang[:, 0].copy(), ang[:, 1].copy(), np.full(12, 1.0 / 12)
+    uvb = np.array([2e-22, 1e-22, 3e-23])
+    src, ndot = np.array([5, nc // 2]), np.array([50.0, 20.0])
+    Jd = torch.empty((3, nc), dtype=torch.float64, device="cuda")
+    HI, HeI, HeII = g["HI"].copy(), g["HeI"].copy(), g["HeII"].copy()
+    for it in range(3):
+        # device
+        st.set_zero_rates()
+        st.point_sources(src, ndot)
+        st.compute_opacities_from_medium(beta)
+        st.transport_device(phi, theta, w, uvb, Jd.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        st.solve_rate_equations_device(Jd.data_ptr(), g["ksi"], use_point_rates=True)
+        # oracle, same steps (device arithmetic for the sweep so that J agrees to the bit)
+        rates, _ = O.point_sources(n, level, HI, HeI, HeII, g["rho"], np.zeros(nc), box, 0, src, ndot, tabs.reshape(6, -1))
+        kappa = O.compute_opacities(HI, HeI, HeII, beta)
+        J = O.sweep_tree(n, level, kappa, box, phi, theta, w, uvb, arith=1)
+        J = J[0] if isinstance(J, tuple) else J
+        assert np.array_equal(Jd.cpu().numpy(), J), it
+        dev_rates = st.rates()
+        HI, HeI, HeII, status, _ = O.solve_rate_equations(n, level, box, g["rho"], g["tgas"], HI, HeI, HeII, dev_rates[:3], True, J, g["ksi"],
+                                                          None, 0.0, float(g["logtem0"]), float(g["logtem9"]), float(g["dlogtem"]), g["k"])
+        assert status == 0
+        m = st.medium()
+        # the tracer's sums differ in the last bits from the oracle's (atomics), and the update was fed the device's
+        # own rates on both sides: species agree bit for bit; the rates themselves to the tracer's tolerance
+        assert np.array_equal(m[0], HI) and np.array_equal(m[1], HeI) and np.array_equal(m[2], HeII), it
+        scale = np.abs(rates).max(axis=1, keepdims=True)
+        assert np.all(np.abs(dev_rates - rates) <= 1e-9 * np.abs(rates) + 1e-13 * scale)
