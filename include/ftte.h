@@ -170,9 +170,13 @@ int ftte_locate_cell(ftte_ctx *ctx, int level, const int32_t *position, int64_t 
 int ftte_point_sources(ftte_ctx *ctx, int nsrc, const int64_t *src_cell, const double *src_ndot, int *highest_pixel_level);
 /* rates[6][ncell]: krate24, krate25, krate26, crate24, crate25, crate26 (zoneType, definitionsModule.f90:166) */
 int ftte_get_point_rates(ftte_ctx *ctx, double *rates);
+/* The same [6][ncell] in device memory: a copy in the interface's layout (the tracer accumulates into a packed array),
+ * valid until the rates change */
 int ftte_point_rates_device(ftte_ctx *ctx, double **rates_dev);
 /* Replace the device-resident rates, e.g. by the sum over the GPUs that traced different stars; same layout */
 int ftte_set_point_rates(ftte_ctx *ctx, const double *rates);
+/* cell crossings (ray segments drawn) of the last ftte_point_sources, all rays of all stars */
+long long ftte_point_ray_steps(const ftte_ctx *ctx);
 /* rmax(1:30), equiSources.f90:296-309 (formula, halved) */
 int ftte_rmax(double *rmax30);
 /* dustCrossSection(lambda [micron]), dustModule.f90:30-73, SMC curve; a_smc(7,5) Fortran order */

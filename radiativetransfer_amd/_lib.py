@@ -67,6 +67,7 @@ SIGNATURES = {
     "ftte_get_medium": (C.c_int, [_vp, _dp, _dp, _dp]),
     "ftte_compute_opacities": (C.c_int, [_vp, C.c_int, _dp]),
     "ftte_rate_equation_steps": (C.c_longlong, [_vp]),
+    "ftte_point_ray_steps": (C.c_longlong, [_vp]),
     "ftte_rmax": (C.c_int, [_dp]),
     "ftte_dust_cross_section": (C.c_double, [C.c_double, _dp]),
     "ftte_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),

@@ -312,6 +312,10 @@ class StellarTransfer(DiffuseTransfer):
                                               C.byref(highest)))
         return highest.value
 
+    def ray_steps(self) -> int:
+        """Cell crossings of the last point_sources call, all rays."""
+        return int(self._lib.ftte_point_ray_steps(self._ctx))
+
     def rates(self) -> np.ndarray:
         out = np.empty((6, max(self.ncell, 1)))
         self._ok(self._lib.ftte_get_point_rates(self._ctx, _dp(out)))

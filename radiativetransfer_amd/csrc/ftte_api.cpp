@@ -1043,7 +1043,9 @@ int ftte_get_point_rates(ftte_ctx *c, double *rates)
     if (!rates) return fail(c, FTTE_ERR_ARG, "ftte_get_point_rates: bad argument");
     if (!c->point.rates || c->point.rates_cells != c->ncell) return fail(c, FTTE_ERR_STATE, "no rates: call ftte_set_zero_rates / ftte_point_sources first");
     FTTE_HIP(c, hipSetDevice(c->device));
-    FTTE_HIP(c, hipMemcpyAsync(rates, c->point.rates, sizeof(double) * 6 * c->ncell, hipMemcpyDeviceToHost, c->stream));
+    double *planes = nullptr;
+    if ((rc = point_rate_planes(c->point, c->stream, &planes, &c->err))) return rc;
+    FTTE_HIP(c, hipMemcpyAsync(rates, planes, sizeof(double) * 6 * c->ncell, hipMemcpyDeviceToHost, c->stream));
     FTTE_HIP(c, hipStreamSynchronize(c->stream));
     return FTTE_OK;
 }
@@ -1054,10 +1056,7 @@ int ftte_set_point_rates(ftte_ctx *c, const double *rates)
     if (rc) return rc;
     if (!rates) return fail(c, FTTE_ERR_ARG, "ftte_set_point_rates: bad argument");
     FTTE_HIP(c, hipSetDevice(c->device));
-    if ((rc = point_zero_rates(c->point, c->stream, c->ncell, &c->err))) return rc;
-    FTTE_HIP(c, hipMemcpyAsync(c->point.rates, rates, sizeof(double) * 6 * (size_t)c->ncell, hipMemcpyHostToDevice, c->stream));
-    FTTE_HIP(c, hipStreamSynchronize(c->stream));
-    return FTTE_OK;
+    return point_set_rates(c->point, c->stream, c->ncell, rates, &c->err);
 }
 
 int ftte_point_rates_device(ftte_ctx *c, double **rates_dev)
@@ -1066,7 +1065,9 @@ int ftte_point_rates_device(ftte_ctx *c, double **rates_dev)
     if (rc) return rc;
     if (!rates_dev) return fail(c, FTTE_ERR_ARG, "ftte_point_rates_device: bad argument");
     if (!c->point.rates || c->point.rates_cells != c->ncell) return fail(c, FTTE_ERR_STATE, "no rates: call ftte_set_zero_rates / ftte_point_sources first");
-    *rates_dev = c->point.rates;
+    FTTE_HIP(c, hipSetDevice(c->device));
+    if ((rc = point_rate_planes(c->point, c->stream, rates_dev, &c->err))) return rc;
+    FTTE_HIP(c, hipStreamSynchronize(c->stream));
     return FTTE_OK;
 }
 
@@ -1167,6 +1168,7 @@ static int solve_rates(ftte_ctx *c, int run_uvb, const double *J, bool J_on_devi
     }
     for (int f = 0; f < 3; ++f)
         FTTE_HIP(c, hipMemcpyAsync(P.medium[f], c->chem_out + f * nc, sizeof(double) * nc, hipMemcpyDeviceToDevice, c->stream));
+    P.packed_ready = false; // the tracer's packed copy of the medium is stale now
     FTTE_HIP(c, hipStreamSynchronize(c->stream));
     double change;
     std::memcpy(&change, &out[1], sizeof change);
@@ -1228,6 +1230,8 @@ int ftte_compute_opacities(ftte_ctx *c, int nnu, const double *beta)
 }
 
 long long ftte_rate_equation_steps(const ftte_ctx *c) { return c ? c->chem_steps : 0; }
+
+long long ftte_point_ray_steps(const ftte_ctx *c) { return c ? c->point.ray_steps : 0; }
 
 int ftte_rmax(double *rmax30)
 {

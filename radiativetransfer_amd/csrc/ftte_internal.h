@@ -125,20 +125,23 @@ struct SplitRec {
     int32_t pad;
 };
 
+// What the tracer touches per cell crossing is packed so that each kind of datum is one 64-byte line (or less):
+// the rays of a wavefront are in 64 different places of the grid, and every separate array is another line from HBM.
+struct NodeRec { int32_t child0, leaf, parent, level; }; // a tree node: first child or -1, cell-array index or -1, parent or -1
+constexpr int kCellRec = 8; // doubles per cell in the packed medium {HI, HeI, HeII, rho, abun2, 0, 0, 0} and in the packed
+                            // rates {krate24, krate25, krate26, crate24, crate25, crate26, 0, 0}
+
 struct TraceRec {
-    // tree (AmrTree on the device)
-    const int32_t *parent, *child0, *leaf;
-    const int8_t *level;
+    const NodeRec *node;   // nullptr on a uniform grid: node == cell, level 0, no children
     int32_t n;
     int32_t dust;     // dustApproximation: 0 none, 1 ~HI, 2 ~total H
     int64_t ncell;
     double box;
-    // medium, cell-array order
-    const double *HI, *HeI, *HeII, *rho, *abun2;
-    const double *logtab;  // [6][11^4] natural logs of the rate tables
+    const double *medium;  // [ncell][kCellRec]
+    const double *logtab;  // [3][11^4][2] natural logs of the rate tables, (number, heating) pairs
     const double *pixdir;  // [kPixelCount][3] unit vectors of all pixels of levels 1..6
     double rmax[kMaxPixelLevel + 1];
-    double *rates;         // [6][ncell] krate24, krate25, krate26, crate24, crate25, crate26
+    double *rates;         // [ncell][kCellRec]
     // this launch: rays of `pixel_level`
     int32_t pixel_level;
     int32_t nrays;         // level 1: 12 * nsources; else 4 * number of split records
@@ -150,6 +153,7 @@ struct TraceRec {
     int32_t out_capacity;
     int32_t *highest_level;
     int32_t *error;
+    unsigned long long *steps; // cell crossings, all rays (instrumentation)
 };
 
 // ---- ionisation equilibrium (solveRateEquations, equiSources.f90:3459-3677) -------------------------------------------
@@ -159,7 +163,7 @@ struct ChemRec {
     const double *rho, *logtem;
     const double *HI, *HeI, *HeII;       // state on entry
     double *HI_out, *HeI_out, *HeII_out; // state on return
-    const double *krate;       // [6][ncell] point-source rates or nullptr
+    const double *krate;       // [ncell][kCellRec] packed point-source rates or nullptr
     const double *J;           // [3][ncell] or nullptr (uniform background)
     const double *k;           // [6][nratec] rate coefficients k1a..k6a
     int64_t ncell;

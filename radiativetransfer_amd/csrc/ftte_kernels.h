@@ -28,6 +28,8 @@ int launch_rate_table(const FreqBin *bins, int nbins, double *tables, double *lo
 int launch_rate_lookup(const double *logtab, int dust, int nsample, const double *tau, double *out, hipStream_t stream);
 int launch_log_table(const double *tables, double *logtab, hipStream_t stream);
 int launch_point_trace(const TraceRec &T, hipStream_t stream);
+int launch_pack_medium(const double *const field[5], double *packed, long ncell, hipStream_t stream);
+int launch_repack_rates(double *planes, double *packed, long ncell, bool to_packed, hipStream_t stream);
 
 // ionisation equilibrium of every leaf (solveRateEquations)
 int launch_rate_equations(const ChemRec &R, hipStream_t stream);

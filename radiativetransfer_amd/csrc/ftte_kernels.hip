@@ -606,6 +606,11 @@ int launch_amr_combine(const AmrLevelRec &A, double *J, bool zero_first, hipStre
 // sums over rays differ in the last bits from run to run).
 // ------------------------------------------------------------------------------------------------
 
+// The look-up interpolates the logarithms of the tables.  They are kept as pairs (number rate, heating rate) of one
+// reaction side by side, i1 fastest: the two i1 neighbours of both tables are 32 contiguous bytes.
+//   logtab[reaction][idust][i3][i2][i1][2]
+__device__ __forceinline__ size_t logtab_index(int reaction0, int flat) { return ((size_t)reaction0 * kTableSize + flat) * 2; }
+
 // stellarBetaTable's accumulation over frequency bins, one thread per depth tuple (stellarBetaTable.f90:217-285)
 __global__ void __launch_bounds__(256) rate_table_kernel(const FreqBin *__restrict__ bins, int nbins, double *__restrict__ tables,
                                                          double *__restrict__ logtab)
@@ -626,16 +631,29 @@ __global__ void __launch_bounds__(256) rate_table_kernel(const FreqBin *__restri
             if (B.excess[r] >= 0.0) { acc[r] = acc[r] + a; acc[3 + r] = acc[3 + r] + B.excess[r] * a; }
     }
 #pragma unroll
-    for (int r = 0; r < 6; ++r) { tables[r * kTableSize + t] = acc[r]; logtab[r * kTableSize + t] = log(acc[r]); }
+    for (int r = 0; r < 3; ++r) {
+        tables[r * kTableSize + t] = acc[r];
+        tables[(3 + r) * kTableSize + t] = acc[3 + r];
+        logtab[logtab_index(r, t)] = log(acc[r]);
+        logtab[logtab_index(r, t) + 1] = log(acc[3 + r]);
+    }
 }
 
 __global__ void __launch_bounds__(256) log_table_kernel(const double *__restrict__ tables, double *__restrict__ logtab)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < 6 * kTableSize) logtab[t] = log(tables[t]);
+    if (t >= 3 * kTableSize) return;
+    const int r = t / kTableSize, flat = t - r * kTableSize;
+    logtab[logtab_index(r, flat)] = log(tables[r * kTableSize + flat]);
+    logtab[logtab_index(r, flat) + 1] = log(tables[(3 + r) * kTableSize + flat]);
 }
 
-// getRatesHydrogenHelium, equiSources.f90:4157-4311, on the table of logarithms
+// getRatesHydrogenHelium, equiSources.f90:4157-4311, on the table of logarithms: number and heating rate of one reaction.
+// The reference forms, for the lower dust slab q = idust and the upper one,
+//   v_q = c1 ((1-c3)(1-c2) T(i1+1,i2,i3) + c3 (1-c2) T(i1+1,i2,i3+1) + c2 (1-c3) T(i1+1,i2+1,i3) + c3 c2 T(i1+1,i2+1,i3+1))
+//       + (1-c1) (the same four with i1)
+// and returns exp((1-cd) v_0 + cd v_1); the same operations in the same order here.  Without dust cd = 0 and the upper slab
+// contributes 0 * v_1 = 0 exactly: it is not read.
 __device__ __forceinline__ void lookup_rates(const double *__restrict__ logtab, int dust, int reaction, double tau1, double tau2,
                                              double tau3, double taud, double &number_rate, double &heating_rate)
 {
@@ -645,31 +663,43 @@ __device__ __forceinline__ void lookup_rates(const double *__restrict__ logtab, 
     int id = 0;
     double cd = 0.0;
     if (dust != 0) { id = (int)(taud / 10.0 * 10.0); cd = taud * 10.0 / 10.0 - (double)id; }
+    // at tau == 10 exactly the reference reads one past the table with weight 0; stay inside
+    const int s1 = i1 < 10 ? 2 : 0, s2 = i2 < 10 ? 11 : 0, s3 = i3 < 10 ? 121 : 0;
+    const double w00 = (1. - c3) * (1. - c2), w01 = c3 * (1. - c2), w10 = c2 * (1. - c3), w11 = c3 * c2;
+    const int nslab = (dust != 0 && id < 10) ? 2 : 1;
+    double vn[2] = {0.0, 0.0}, ve[2] = {0.0, 0.0};
 #pragma unroll
-    for (int which = 0; which < 2; ++which) {
-        const double *R = logtab + (size_t)((which ? 3 : 0) + reaction - 1) * kTableSize;
-        double v[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const double *P = R + (((size_t)(id + q) * 11 + i3) * 11 + i2) * 11 + i1;
-            // min(): the reference reads one past the table at tau == 10 exactly; stay inside
-            const int s1 = i1 < 10 ? 1 : 0, s2 = i2 < 10 ? 11 : 0, s3 = i3 < 10 ? 121 : 0;
-            v[q] = c1 * ((1. - c3) * (1. - c2) * P[s1] + c3 * (1. - c2) * P[s1 + s3] + c2 * (1. - c3) * P[s1 + s2] + c3 * c2 * P[s1 + s2 + s3]) +
-                   (1. - c1) * ((1. - c3) * (1. - c2) * P[0] + c3 * (1. - c2) * P[s3] + c2 * (1. - c3) * P[s2] + c3 * c2 * P[s2 + s3]);
-            if (id + q >= 10 && q == 0) { v[1] = v[0]; break; } // dust index 10: no slab above
+    for (int q = 0; q < 2; ++q) {
+        if (q < nslab) {
+            const double *P = logtab + logtab_index(reaction - 1, (((id + q) * 11 + i3) * 11 + i2) * 11 + i1);
+            // corner (i2, i3): {n(i1), e(i1), n(i1+1), e(i1+1)} are contiguous
+            const double *A = P, *B = P + 2 * s3, *Cc = P + 2 * s2, *D = P + 2 * (s2 + s3);
+            const double a0n = A[0], a0e = A[1], a1n = A[s1], a1e = A[s1 + 1];
+            const double b0n = B[0], b0e = B[1], b1n = B[s1], b1e = B[s1 + 1];
+            const double c0n = Cc[0], c0e = Cc[1], c1n = Cc[s1], c1e = Cc[s1 + 1];
+            const double d0n = D[0], d0e = D[1], d1n = D[s1], d1e = D[s1 + 1];
+            vn[q] = c1 * (w00 * a1n + w01 * b1n + w10 * c1n + w11 * d1n) + (1. - c1) * (w00 * a0n + w01 * b0n + w10 * c0n + w11 * d0n);
+            ve[q] = c1 * (w00 * a1e + w01 * b1e + w10 * c1e + w11 * d1e) + (1. - c1) * (w00 * a0e + w01 * b0e + w10 * c0e + w11 * d0e);
         }
-        const double out = exp((1. - cd) * v[0] + cd * v[1]);
-        if (which) heating_rate = out; else number_rate = out;
     }
+    if (dust == 0) { number_rate = exp(vn[0]); heating_rate = exp(ve[0]); return; }
+    if (nslab == 1) { vn[1] = vn[0]; ve[1] = ve[0]; } // dust index 10: no slab above, weight 0
+    number_rate = exp((1. - cd) * vn[0] + cd * vn[1]);
+    heating_rate = exp((1. - cd) * ve[0] + cd * ve[1]);
 }
 
 struct Neighbour { int node; double a, b; bool boundary; };
+
+__device__ __forceinline__ int node_child0(const TraceRec &T, int c) { return T.node ? T.node[c].child0 : -1; }
+__device__ __forceinline__ int node_level(const TraceRec &T, int c) { return T.node ? T.node[c].level : 0; }
+__device__ __forceinline__ int node_parent(const TraceRec &T, int c) { return T.node ? T.node[c].parent : -1; }
+__device__ __forceinline__ int node_leaf(const TraceRec &T, int c) { return T.node ? T.node[c].leaf : c; }
 
 // zoom??Neighbour, equiSources.f90:2827-2960: down into the leaf that holds (a,b) on the face the ray crosses.
 // axis: 0 the ray crosses an x face (coordinates y,z), 1 a y face (x,z), 2 a z face (x,y).
 __device__ __forceinline__ Neighbour zoom(const TraceRec &T, int c, double a, double b, int axis, int side)
 {
-    while (T.child0[c] >= 0) {
+    for (int first = node_child0(T, c); first >= 0; first = node_child0(T, c)) {
         const int ia = a < 0.5 ? 0 : 1, ib = b < 0.5 ? 0 : 1;
         a = ia ? 2. * a - 1. : 2. * a;
         b = ib ? 2. * b - 1. : 2. * b;
@@ -678,7 +708,7 @@ __device__ __forceinline__ Neighbour zoom(const TraceRec &T, int c, double a, do
         if (axis == 2) { i = ia; j = ib; k = ic; }
         else if (axis == 0) { i = ic; j = ia; k = ib; }
         else { i = ia; j = ic; k = ib; }
-        c = T.child0[c] + 4 * i + 2 * j + k;
+        c = first + 4 * i + 2 * j + k;
     }
     Neighbour N;
     N.node = c; N.a = a; N.b = b; N.boundary = false;
@@ -690,10 +720,11 @@ __device__ __forceinline__ Neighbour find_neighbour(const TraceRec &T, int c, do
 {
     const int pos = axis == 2 ? 2 : (axis == 0 ? 0 : 1);
     const int pa = axis == 2 ? 0 : (axis == 0 ? 1 : 0), pb = axis == 2 ? 1 : 2;
-    int lvl = T.level[c];
+    int lvl = node_level(T, c);
     while (lvl > 0) {
-        const int par = T.parent[c];
-        const int idx = c - T.child0[par];
+        const int par = node_parent(T, c);
+        const int first = node_child0(T, par);
+        const int idx = c - first;
         int ijk[3] = {(idx >> 2) & 1, (idx >> 1) & 1, idx & 1};
         if ((side == 0 && ijk[pos] == 0) || (side == 1 && ijk[pos] == 1)) {
             a = ijk[pa] == 0 ? 0.5 * a : 0.5 * a + 0.5;
@@ -702,7 +733,7 @@ __device__ __forceinline__ Neighbour find_neighbour(const TraceRec &T, int c, do
             --lvl;
         } else {
             ijk[pos] = side == 0 ? 0 : 1;
-            return zoom(T, T.child0[par] + 4 * ijk[0] + 2 * ijk[1] + ijk[2], a, b, axis, side);
+            return zoom(T, first + 4 * ijk[0] + 2 * ijk[1] + ijk[2], a, b, axis, side);
         }
     }
     const int n = T.n;
@@ -758,10 +789,10 @@ __global__ void __launch_bounds__(64) point_trace_kernel(const TraceRec T)
             pt[q] = base[q] * fn - (double)(float)ijk[q];
         }
         cell = (ijk[0] * n + ijk[1]) * n + ijk[2];
-        while (T.child0[cell] >= 0) {
+        for (int first = node_child0(T, cell); first >= 0; first = node_child0(T, cell)) {
             int h[3];
             for (int q = 0; q < 3; ++q) { h[q] = pt[q] < 0.5 ? 0 : 1; pt[q] = h[q] ? 2. * pt[q] - 1. : 2. * pt[q]; }
-            cell = T.child0[cell] + 4 * h[0] + 2 * h[1] + h[2];
+            cell = first + 4 * h[0] + 2 * h[1] + h[2];
         }
         radius = R.radius; d1 = R.depth[0]; d2 = R.depth[1]; d3 = R.depth[2]; dd = R.depth[3];
         ndot = R.ndot / 4.0;
@@ -771,11 +802,12 @@ __global__ void __launch_bounds__(64) point_trace_kernel(const TraceRec T)
     const double *dir = T.pixdir + 3 * (size_t)(level_off + pixel);
     const double prox = dir[0], proy = dir[1], proz = dir[2];
     const double rm = T.rmax[L];
-    const long nc = T.ncell;
     bool split = false;
+    unsigned crossed = 0;
     for (int step = 0; step < 1000000; ++step) {
+        ++crossed;
         // ---- drawSegment, :2412-2595
-        const int lvl = T.level[cell];
+        const int lvl = node_level(T, cell);
         const double scale = (double)(1 << lvl);
         const double t1 = proz > 0. ? (1. - pt[2]) / proz : -pt[2] / proz;
         const double t2 = prox > 0. ? (1. - pt[0]) / prox : -pt[0] / prox;
@@ -807,26 +839,35 @@ __global__ void __launch_bounds__(64) point_trace_kernel(const TraceRec T)
         // ---- optical depths of the piece and what it absorbs, :3176-3269
         const double cell_size = T.box / ((double)((float)(1 << lvl) * (float)n));
         const double path = cell_size * len;
-        const long c = T.leaf[cell];
-        const double tau1 = path * T.HI[c] * (double)6.3e-18f, tau2 = path * T.HeI[c] * (double)7.42e-18f,
-                     tau3 = path * T.HeII[c] * (double)1.58e-18f;
+        const long c = node_leaf(T, cell);
+        const double *M = T.medium + c * kCellRec; // HI, HeI, HeII, rho, abun2
+        const double hi = M[0];
+        const double tau1 = path * hi * (double)6.3e-18f, tau2 = path * M[1] * (double)7.42e-18f, tau3 = path * M[2] * (double)1.58e-18f;
         double taud = 0.0;
-        if (T.dust == 1) taud = path * T.HI[c] * (double)5.4116737e-22f * T.abun2[c] / (double)0.2f;
-        else if (T.dust == 2) taud = path * (double)0.76f * T.rho[c] / (double)1.6726231e-24f * (double)5.4116737e-22f * T.abun2[c] / (double)0.2f;
+        if (T.dust == 1) taud = path * hi * (double)5.4116737e-22f * M[4] / (double)0.2f;
+        else if (T.dust == 2) taud = path * (double)0.76f * M[3] / (double)1.6726231e-24f * (double)5.4116737e-22f * M[4] / (double)0.2f;
         if (fmin(fmin(d1 + tau1, d2 + tau2), fmin(d3 + tau3, dd + taud)) > 100.) { stop = true; split = false; }
+        // a species without opacity in this cell takes nothing from the ray: R(d) - R(d) = 0 (and the reference adds that 0)
         double a, b, ea, eb;
-        lookup_rates(T.logtab, T.dust, 1, d1, d2, d3, dd, a, ea);
-        lookup_rates(T.logtab, T.dust, 1, d1 + tau1, d2, d3, dd, b, eb);
-        unsafeAtomicAdd(&T.rates[0 * nc + c], ndot * (a - b));
-        unsafeAtomicAdd(&T.rates[3 * nc + c], ndot * (ea - eb));
-        lookup_rates(T.logtab, T.dust, 2, d1, d2, d3, dd, a, ea);
-        lookup_rates(T.logtab, T.dust, 2, d1, d2 + tau2, d3, dd, b, eb);
-        unsafeAtomicAdd(&T.rates[2 * nc + c], ndot * (a - b));
-        unsafeAtomicAdd(&T.rates[5 * nc + c], ndot * (ea - eb));
-        lookup_rates(T.logtab, T.dust, 3, d1, d2, d3, dd, a, ea);
-        lookup_rates(T.logtab, T.dust, 3, d1, d2, d3 + tau3, dd, b, eb);
-        unsafeAtomicAdd(&T.rates[1 * nc + c], ndot * (a - b));
-        unsafeAtomicAdd(&T.rates[4 * nc + c], ndot * (ea - eb));
+        double *K = T.rates + c * kCellRec; // krate24, krate25, krate26, crate24, crate25, crate26
+        if (tau1 != 0.0) {
+            lookup_rates(T.logtab, T.dust, 1, d1, d2, d3, dd, a, ea);
+            lookup_rates(T.logtab, T.dust, 1, d1 + tau1, d2, d3, dd, b, eb);
+            unsafeAtomicAdd(K + 0, ndot * (a - b));
+            unsafeAtomicAdd(K + 3, ndot * (ea - eb));
+        }
+        if (tau2 != 0.0) {
+            lookup_rates(T.logtab, T.dust, 2, d1, d2, d3, dd, a, ea);
+            lookup_rates(T.logtab, T.dust, 2, d1, d2 + tau2, d3, dd, b, eb);
+            unsafeAtomicAdd(K + 2, ndot * (a - b));
+            unsafeAtomicAdd(K + 5, ndot * (ea - eb));
+        }
+        if (tau3 != 0.0) {
+            lookup_rates(T.logtab, T.dust, 3, d1, d2, d3, dd, a, ea);
+            lookup_rates(T.logtab, T.dust, 3, d1, d2, d3 + tau3, dd, b, eb);
+            unsafeAtomicAdd(K + 1, ndot * (a - b));
+            unsafeAtomicAdd(K + 4, ndot * (ea - eb));
+        }
         d1 = d1 + tau1; d2 = d2 + tau2; d3 = d3 + tau3; dd = dd + taud;
         if (stop || split) break;
         // ---- into the neighbour, :2512-2558
@@ -838,15 +879,16 @@ __global__ void __launch_bounds__(64) point_trace_kernel(const TraceRec T)
         cell = N.node;
         if (step == 999999) atomicMax(T.error, 4);
     }
+    atomicAdd(T.steps, (unsigned long long)crossed);
     if (!split) return;
 
     // ---- hand the ray over to its four daughters: absoluteCoordinates, :3011-3047
     atomicMax(T.highest_level, L + 1);
     double p[3] = {pt[0], pt[1], pt[2]};
     int c = cell;
-    for (int lvl = T.level[c]; lvl > 0; --lvl) {
-        const int par = T.parent[c];
-        const int idx = c - T.child0[par];
+    for (int lvl = node_level(T, c); lvl > 0; --lvl) {
+        const int par = node_parent(T, c);
+        const int idx = c - node_child0(T, par);
         const int h[3] = {(idx >> 2) & 1, (idx >> 1) & 1, idx & 1};
         for (int q = 0; q < 3; ++q) p[q] = h[q] == 0 ? 0.5 * p[q] : 0.5 * p[q] + 0.5;
         c = par;
@@ -885,6 +927,55 @@ int launch_rate_lookup(const double *logtab, int dust, int nsample, const double
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// packed[c][0..4] = HI, HeI, HeII, rho, abun2 (one 64-byte line per cell)
+__global__ void __launch_bounds__(256) pack_medium_kernel(const double *__restrict__ HI, const double *__restrict__ HeI,
+                                                          const double *__restrict__ HeII, const double *__restrict__ rho,
+                                                          const double *__restrict__ abun2, double *__restrict__ packed, long ncell)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long c = t >> 3;
+    const int f = (int)(t & 7);
+    if (c >= ncell) return;
+    const double *src = f == 0 ? HI : f == 1 ? HeI : f == 2 ? HeII : f == 3 ? rho : f == 4 ? abun2 : nullptr;
+    packed[t] = src ? src[c] : 0.0;
+}
+
+// to_packed: packed[c][r] = planes[r][c] (r < 6), else planes[r][c] = packed[c][r]; tiles of 32 cells through LDS so that
+// both sides move whole lines
+__global__ void __launch_bounds__(256) repack_rates_kernel(double *__restrict__ planes, double *__restrict__ packed, long ncell,
+                                                           int to_packed)
+{
+    __shared__ double tile[8][33];
+    const long c0 = (long)blockIdx.x * 32;
+    const int a = threadIdx.x & 31, b = threadIdx.x >> 5; // 32 x 8
+    if (to_packed) {
+        tile[b][a] = (b < 6 && c0 + a < ncell) ? planes[(long)b * ncell + c0 + a] : 0.0;
+        __syncthreads();
+        const int cc = threadIdx.x >> 3, r = threadIdx.x & 7;
+        if (c0 + cc < ncell) packed[(c0 + cc) * kCellRec + r] = tile[r][cc];
+    } else {
+        const int cc = threadIdx.x >> 3, r = threadIdx.x & 7;
+        tile[r][cc] = c0 + cc < ncell ? packed[(c0 + cc) * kCellRec + r] : 0.0;
+        __syncthreads();
+        if (b < 6 && c0 + a < ncell) planes[(long)b * ncell + c0 + a] = tile[b][a];
+    }
+}
+
+int launch_pack_medium(const double *const field[5], double *packed, long ncell, hipStream_t stream)
+{
+    const long threads = ncell * kCellRec;
+    hipLaunchKernelGGL(pack_medium_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, field[0], field[1], field[2],
+                       field[3], field[4], packed, ncell);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_repack_rates(double *planes, double *packed, long ncell, bool to_packed, hipStream_t stream)
+{
+    hipLaunchKernelGGL(repack_rates_kernel, dim3((unsigned)((ncell + 31) / 32)), dim3(256), 0, stream, planes, packed, ncell,
+                       to_packed ? 1 : 0);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 int launch_rate_table(const FreqBin *bins, int nbins, double *tables, double *logtab, hipStream_t stream)
 {
     hipLaunchKernelGGL(rate_table_kernel, dim3((kTableSize + 255) / 256), dim3(256), 0, stream, bins, nbins, tables, logtab);
@@ -893,7 +984,7 @@ int launch_rate_table(const FreqBin *bins, int nbins, double *tables, double *lo
 
 int launch_log_table(const double *tables, double *logtab, hipStream_t stream)
 {
-    hipLaunchKernelGGL(log_table_kernel, dim3((6 * kTableSize + 255) / 256), dim3(256), 0, stream, tables, logtab);
+    hipLaunchKernelGGL(log_table_kernel, dim3((3 * kTableSize + 255) / 256), dim3(256), 0, stream, tables, logtab);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -935,9 +1026,9 @@ __global__ void __launch_bounds__(256) rate_equations_kernel(const ChemRec R)
     // rates per cell -> per absorber, :3520-3542
     const double size = R.box / (double)((float)(1 << R.level[c]) * (float)R.n);
     const double vol = size * size * size;
-    q.kr24 = (R.krate && HI > 0.) ? R.krate[c] / (vol * HI) : 0.;
-    q.kr25 = (R.krate && HeII > 0.) ? R.krate[R.ncell + c] / (vol * HeII) : 0.;
-    q.kr26 = (R.krate && HeI > 0.) ? R.krate[2 * R.ncell + c] / (vol * HeI) : 0.;
+    q.kr24 = (R.krate && HI > 0.) ? R.krate[c * kCellRec] / (vol * HI) : 0.;
+    q.kr25 = (R.krate && HeII > 0.) ? R.krate[c * kCellRec + 1] / (vol * HeII) : 0.;
+    q.kr26 = (R.krate && HeI > 0.) ? R.krate[c * kCellRec + 2] / (vol * HeI) : 0.;
     q.kr24 = fmax(q.kr24, 0.); q.kr25 = fmax(q.kr25, 0.); q.kr26 = fmax(q.kr26, 0.);
     if (R.run_uvb) { // :3545-3553
         const double t1 = 4. * pi * R.J[c], t2 = 4. * pi * R.J[R.ncell + c], t3 = 4. * pi * R.J[2 * R.ncell + c];

@@ -59,13 +59,15 @@ inline double hydrogenic(double sigma0, double threshold, double nu)
 
 void PointState::drop_grid()
 {
-    drop(parent); drop(child0); drop(leaf); drop(level);
+    drop(node);
     tree_ready = false;
     for (auto &m : medium) drop(m);
+    drop(packed);
+    packed_ready = false;
     medium_cells = 0;
     medium_ready = false;
     rho_given = false;
-    drop(rates);
+    drop(rates); drop(rate_planes);
     rates_cells = 0;
     std::vector<int32_t>().swap(node_of_leaf);
 }
@@ -206,9 +208,11 @@ int point_set_medium(PointState &P, hipStream_t stream, int64_t ncell, const dou
 {
     if (P.medium_cells != ncell) {
         for (auto &m : P.medium) drop(m);
+        drop(P.packed);
         P.medium_cells = 0;
         P.medium_ready = false;
     }
+    P.packed_ready = false;
     for (int f = 0; f < 5; ++f) {
         int rc;
         if ((rc = ensure(P.medium[f], (size_t)ncell, err))) return rc;
@@ -227,11 +231,31 @@ int point_set_medium(PointState &P, hipStream_t stream, int64_t ncell, const dou
 
 int point_zero_rates(PointState &P, hipStream_t stream, int64_t ncell, std::string *err)
 {
-    if (P.rates_cells != ncell) { drop(P.rates); P.rates_cells = 0; }
+    if (P.rates_cells != ncell) { drop(P.rates); drop(P.rate_planes); P.rates_cells = 0; }
     int rc;
-    if ((rc = ensure(P.rates, (size_t)6 * ncell, err))) return rc;
+    if ((rc = ensure(P.rates, (size_t)kCellRec * ncell, err))) return rc;
     P.rates_cells = ncell;
-    POINT_HIP(hipMemsetAsync(P.rates, 0, sizeof(double) * 6 * ncell, stream));
+    POINT_HIP(hipMemsetAsync(P.rates, 0, sizeof(double) * kCellRec * ncell, stream));
+    return 0;
+}
+
+int point_rate_planes(PointState &P, hipStream_t stream, double **planes, std::string *err)
+{
+    int rc;
+    if ((rc = ensure(P.rate_planes, (size_t)6 * P.rates_cells, err))) return rc;
+    if (launch_repack_rates(P.rate_planes, P.rates, (long)P.rates_cells, false, stream)) { *err = "layout kernel failed to launch"; return FTTE_ERR_NO_DEVICE; }
+    *planes = P.rate_planes;
+    return 0;
+}
+
+int point_set_rates(PointState &P, hipStream_t stream, int64_t ncell, const double *planes_host, std::string *err)
+{
+    int rc;
+    if ((rc = point_zero_rates(P, stream, ncell, err))) return rc;
+    if ((rc = ensure(P.rate_planes, (size_t)6 * ncell, err))) return rc;
+    POINT_HIP(hipMemcpyAsync(P.rate_planes, planes_host, sizeof(double) * 6 * ncell, hipMemcpyHostToDevice, stream));
+    if (launch_repack_rates(P.rate_planes, P.rates, (long)ncell, true, stream)) { *err = "layout kernel failed to launch"; return FTTE_ERR_NO_DEVICE; }
+    POINT_HIP(hipStreamSynchronize(stream));
     return 0;
 }
 
@@ -246,16 +270,20 @@ int point_trace(PointState &P, hipStream_t stream, const AmrTree &tree, double b
 
     const size_t nnode = tree.parent.size();
     if (!P.tree_ready) {
-        drop(P.parent); drop(P.child0); drop(P.leaf); drop(P.level);
-        if ((rc = ensure(P.parent, nnode, err)) || (rc = ensure(P.child0, nnode, err)) || (rc = ensure(P.leaf, nnode, err)) ||
-            (rc = ensure(P.level, nnode, err)))
-            return rc;
-        POINT_HIP(hipMemcpyAsync(P.parent, tree.parent.data(), sizeof(int32_t) * nnode, hipMemcpyHostToDevice, stream));
-        POINT_HIP(hipMemcpyAsync(P.child0, tree.child0.data(), sizeof(int32_t) * nnode, hipMemcpyHostToDevice, stream));
-        POINT_HIP(hipMemcpyAsync(P.leaf, tree.leaf.data(), sizeof(int32_t) * nnode, hipMemcpyHostToDevice, stream));
-        POINT_HIP(hipMemcpyAsync(P.level, tree.level.data(), sizeof(int8_t) * nnode, hipMemcpyHostToDevice, stream));
-        POINT_HIP(hipStreamSynchronize(stream));
+        drop(P.node);
+        if (tree.refined()) {
+            std::vector<NodeRec> nodes(nnode);
+            for (size_t v = 0; v < nnode; ++v) nodes[v] = NodeRec{tree.child0[v], tree.leaf[v], tree.parent[v], (int32_t)tree.level[v]};
+            if ((rc = ensure(P.node, nnode, err))) return rc;
+            POINT_HIP(hipMemcpyAsync(P.node, nodes.data(), sizeof(NodeRec) * nnode, hipMemcpyHostToDevice, stream));
+            POINT_HIP(hipStreamSynchronize(stream));
+        }
         P.tree_ready = true;
+    }
+    if (!P.packed_ready) {
+        if ((rc = ensure(P.packed, (size_t)kCellRec * tree.ncell, err))) return rc;
+        if (launch_pack_medium(P.medium, P.packed, (long)tree.ncell, stream)) { *err = "layout kernel failed to launch"; return FTTE_ERR_NO_DEVICE; }
+        P.packed_ready = true;
     }
     if (!P.pixdir) {
         // unit vectors of every pixel of levels 1..6.  The reference evaluates cos(phi)*cos(theta), sin(phi)*cos(theta),
@@ -279,7 +307,7 @@ int point_trace(PointState &P, hipStream_t stream, const AmrTree &tree, double b
         rmax_table(P.rmax);
     }
     if (!P.counters) {
-        if ((rc = ensure(P.counters, 4, err))) return rc;
+        if ((rc = ensure(P.counters, 8, err))) return rc;
     }
     const int batch_max = nsrc < kSplitBatch ? nsrc : kSplitBatch;
     const int32_t need = batch_max * 3072; // at most 12 * 4^4 rays of one source split into level 6
@@ -298,8 +326,8 @@ int point_trace(PointState &P, hipStream_t stream, const AmrTree &tree, double b
         P.src_capacity = batch_max;
     }
 
-    // cell-array index -> tree node (kept until the grid changes)
-    if (P.node_of_leaf.size() != (size_t)tree.ncell) {
+    // cell-array index -> tree node (kept until the grid changes; the identity on a uniform grid)
+    if (tree.refined() && P.node_of_leaf.size() != (size_t)tree.ncell) {
         P.node_of_leaf.assign((size_t)tree.ncell, -1);
         for (size_t v = 0; v < nnode; ++v)
             if (tree.leaf[v] >= 0) P.node_of_leaf[(size_t)tree.leaf[v]] = (int32_t)v;
@@ -307,20 +335,21 @@ int point_trace(PointState &P, hipStream_t stream, const AmrTree &tree, double b
     std::vector<int32_t> node_of(nsrc);
     for (int s = 0; s < nsrc; ++s) {
         if (src_cell[s] < 0 || src_cell[s] >= tree.ncell) { *err = "ftte_point_sources: source cell outside the cell array"; return FTTE_ERR_ARG; }
-        node_of[s] = P.node_of_leaf[(size_t)src_cell[s]];
+        node_of[s] = tree.refined() ? P.node_of_leaf[(size_t)src_cell[s]] : (int32_t)src_cell[s];
     }
 
     TraceRec T;
     std::memset(&T, 0, sizeof(T));
-    T.parent = P.parent; T.child0 = P.child0; T.leaf = P.leaf; T.level = P.level;
+    T.node = tree.refined() ? P.node : nullptr;
     T.n = tree.n; T.dust = P.dust; T.ncell = tree.ncell; T.box = box;
-    T.HI = P.medium[0]; T.HeI = P.medium[1]; T.HeII = P.medium[2]; T.rho = P.medium[3]; T.abun2 = P.medium[4];
+    T.medium = P.packed;
     T.logtab = P.logtab; T.pixdir = P.pixdir;
     T.rmax[0] = 0.0;
     for (int L = 1; L <= kMaxPixelLevel; ++L) T.rmax[L] = P.rmax[L - 1];
     T.rates = P.rates;
     T.src_node = P.src_node; T.src_ndot = P.src_ndot;
     T.out_count = P.counters; T.highest_level = P.counters + 1; T.error = P.counters + 2;
+    T.steps = reinterpret_cast<unsigned long long *>(P.counters + 4);
     T.out_capacity = P.queue_capacity;
 
     int32_t host_counters[4] = {0, 0, 0, 0};
@@ -340,7 +369,7 @@ int point_trace(PointState &P, hipStream_t stream, const AmrTree &tree, double b
             host_counters[0] = 0;
             host_counters[1] = highest;
             POINT_HIP(hipMemcpyAsync(P.counters, host_counters, sizeof(int32_t) * 2, hipMemcpyHostToDevice, stream));
-            if (L == 1 && s0 == 0) POINT_HIP(hipMemsetAsync(P.counters + 2, 0, sizeof(int32_t) * 2, stream));
+            if (L == 1 && s0 == 0) POINT_HIP(hipMemsetAsync(P.counters + 2, 0, sizeof(int32_t) * 6, stream));
             if (launch_point_trace(T, stream)) { *err = "tracer kernel failed to launch"; return FTTE_ERR_NO_DEVICE; }
             POINT_HIP(hipMemcpyAsync(host_counters, P.counters, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, stream));
             POINT_HIP(hipStreamSynchronize(stream));
@@ -355,6 +384,10 @@ int point_trace(PointState &P, hipStream_t stream, const AmrTree &tree, double b
             }
         }
     }
+    unsigned long long steps = 0;
+    POINT_HIP(hipMemcpyAsync(&steps, P.counters + 4, sizeof steps, hipMemcpyDeviceToHost, stream));
+    POINT_HIP(hipStreamSynchronize(stream));
+    P.ray_steps = (long long)steps;
     if (highest_pixel_level) *highest_pixel_level = highest;
     return 0;
 }

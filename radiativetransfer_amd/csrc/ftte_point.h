@@ -18,9 +18,8 @@ constexpr int kSplitBatch = 1024;    // sources traced together; bounds the spli
 
 // Everything the point-source path keeps on the device.  Owned by the context.
 struct PointState {
-    // the tree, uploaded on first use after ftte_set_grid
-    int32_t *parent = nullptr, *child0 = nullptr, *leaf = nullptr;
-    int8_t *level = nullptr;
+    // the tree, uploaded on first use after ftte_set_grid (nothing is uploaded for a uniform grid)
+    NodeRec *node = nullptr;
     bool tree_ready = false;
     std::vector<int32_t> node_of_leaf; // cell-array index -> node
     // HI, HeI, HeII, rho, abun2 in cell-array order
@@ -28,6 +27,8 @@ struct PointState {
     int64_t medium_cells = 0;
     int dust = 0;
     bool medium_ready = false;
+    double *packed = nullptr;   // [ncell][kCellRec] copy the tracer reads, rebuilt when the medium changes
+    bool packed_ready = false;
     bool rho_given = false;   // ftte_set_medium received a density (the equilibrium update needs it)
     // [6][11^4] rate tables and their logarithms
     double *tables = nullptr, *logtab = nullptr;
@@ -35,13 +36,15 @@ struct PointState {
     FreqBin *bins = nullptr;
     double *pixdir = nullptr; // [kPixelCount][3]
     double rmax[30];
-    // [6][ncell] krate24, krate25, krate26, crate24, crate25, crate26
+    // [ncell][kCellRec] krate24, krate25, krate26, crate24, crate25, crate26, 0, 0: what the tracer adds into
     double *rates = nullptr;
     int64_t rates_cells = 0;
+    double *rate_planes = nullptr; // [6][ncell]: the layout of the interface, filled on request
     // tracer scratch
     SplitRec *queue[2] = {nullptr, nullptr};
     int32_t queue_capacity = 0;
-    int32_t *counters = nullptr; // [0] queue length, [1] highest pixel level, [2] error
+    int32_t *counters = nullptr; // [0] queue length, [1] highest pixel level, [2] error, [4..5] 64-bit count of cell crossings
+    long long ray_steps = 0;     // of the last trace
     int32_t *src_node = nullptr;
     double *src_ndot = nullptr;
     int32_t src_capacity = 0;
@@ -70,6 +73,9 @@ int point_lookup(PointState &P, hipStream_t stream, int dust, int nsample, const
 int point_set_medium(PointState &P, hipStream_t stream, int64_t ncell, const double *const field[5], bool on_device, int dust,
                      std::string *err);
 int point_zero_rates(PointState &P, hipStream_t stream, int64_t ncell, std::string *err);
+// rates in the interface's layout [6][ncell], in device memory (valid until the next trace)
+int point_rate_planes(PointState &P, hipStream_t stream, double **planes, std::string *err);
+int point_set_rates(PointState &P, hipStream_t stream, int64_t ncell, const double *planes_host, std::string *err);
 int point_trace(PointState &P, hipStream_t stream, const AmrTree &tree, double box, int nsrc, const int64_t *src_cell,
                 const double *src_ndot, int *highest_pixel_level, std::string *err);
 
