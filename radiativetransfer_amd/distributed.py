@@ -35,3 +35,40 @@ def allreduce_J(J_tensor, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(J_tensor, op=dist.ReduceOp.SUM, group=group)
     return J_tensor
+
+
+def shard_groups(nnu: int, rank: int, world: int) -> Tuple[int, int]:
+    """Frequency groups [lo, hi) of this rank when the groups rather than the directions are split (with
+    as many GPUs as groups every J_nu is complete where it is computed and no reduction is needed; gather_J then only
+    assembles the groups)."""
+    return shard_bounds(nnu, rank, world)
+
+
+def gather_J(J_local, nnu: int, group=None):
+    """All-gather of per-rank group slices J_local[hi - lo][ncell] into J[nnu][ncell] on every rank (torch tensors)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return J_local
+    world = dist.get_world_size(group)
+    sizes = [shard_bounds(nnu, r, world) for r in range(world)]
+    most = max(hi - lo for lo, hi in sizes)
+    # all_gather wants equal shapes: pad every slice to the largest share, cut the padding off afterwards
+    mine = torch.zeros((most, J_local.shape[1]), dtype=J_local.dtype, device=J_local.device)
+    mine[:J_local.shape[0]] = J_local
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    return torch.cat([p[:hi - lo] for p, (lo, hi) in zip(parts, sizes)], dim=0)
+
+
+def shard_sources(cells, ndot, rank: int, world: int):
+    """This rank's share of the star list.  Point sources are independent; the rates they deposit add up
+    (equiSources.f90:3247-3260), so each rank traces its stars into its own rate array and allreduce_rates sums them."""
+    lo, hi = shard_bounds(len(cells), rank, world)
+    return np.asarray(cells)[lo:hi].copy(), np.asarray(ndot)[lo:hi].copy()
+
+
+def allreduce_rates(rates_tensor, group=None):
+    """In-place sum of rank-local point-source rates [6][ncell] over the process group; hand the result back to the
+    library with StellarTransfer.set_rates before the equilibrium update."""
+    return allreduce_J(rates_tensor, group)
