@@ -235,6 +235,16 @@ module ftte_binding
        real(c_double), intent(in) :: rates(*)      ! (ncell, 6)
      end function ftte_set_point_rates
 
+     integer(c_int) function ftte_uvb_beta_table(nfreq, freqdel, alpha, beta, ksi, gamma) bind(C, name='ftte_uvb_beta_table')
+       import :: c_int, c_double
+       integer(c_int), value :: nfreq
+       real(c_double), value :: freqdel
+       real(c_double), intent(in) :: alpha(3)
+       real(c_double), intent(out) :: beta(3,3)    ! (group, species HI/HeI/HeII): the (nnu, 3) matrix of ftte_set_species
+       real(c_double), intent(out) :: ksi(3,3)     ! (ksi24/25/26, group)
+       real(c_double), intent(out) :: gamma(3,3)   ! (gammaHI/HeI/HeII, group)
+     end function ftte_uvb_beta_table
+
   end interface
 
 contains

@@ -179,6 +179,13 @@ int ftte_set_point_rates(ftte_ctx *ctx, const double *rates);
 long long ftte_point_ray_steps(const ftte_ctx *ctx);
 /* rmax(1:30), equiSources.f90:296-309 (formula, halved) */
 int ftte_rmax(double *rmax30);
+/* uvbBetaTable(nfreq, freqdel, alpha), uvbBetaTable.f90:3-305 (host): the three frequency groups [nu1, nu2], [nu2, nu3],
+ * [nu3, inf) with power-law slopes alpha[3].  beta[3][3] = [species HI, HeI, HeII][group] (group%beta24, beta26, beta25:
+ * the matrix ftte_set_species / ftte_compute_opacities take; computeOpacities uses its lower triangle,
+ * equiSources.f90:4977-4980), ksi[3][3] = [group][ksi24, ksi25, ksi26] (what ftte_solve_rate_equations takes),
+ * gamma[3][3] = [group][gammaHI, gammaHeI, gammaHeII].  The reference calls it with nfbins = 400, frequencyBinWidth = 0.02
+ * (equiSources.f90:253). */
+int ftte_uvb_beta_table(int nfreq, double freqdel, const double *alpha, double *beta, double *ksi, double *gamma);
 /* dustCrossSection(lambda [micron]), dustModule.f90:30-73, SMC curve; a_smc(7,5) Fortran order */
 double ftte_dust_cross_section(double lambda_micron, const double *a_smc);
 

@@ -130,6 +130,8 @@ long fo_solve_rate_equations(int n, long ncell, const int32_t *level, double box
                              const double *ksi, const double *uniform, double threshold, int nratec, double logtem0,
                              double logtem9, double dlogtem, const double *k, long *iterations);
 
+void fo_uvb_beta_table(int nfreq, double freqdel, const double *alpha, double *beta, double *ksi, double *gamma);
+
 #ifdef __cplusplus
 }
 #endif

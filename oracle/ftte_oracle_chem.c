@@ -106,3 +106,53 @@ long fo_solve_rate_equations(int n, long ncell, const int32_t *level, double box
     if (iterations) *iterations = its;
     return 0;
 }
+
+/* uvbBetaTable, uvbBetaTable.f90:3-305.  out: beta[3 groups][3] (beta24, beta25, beta26), ksi[3][3] (ksi24, ksi25, ksi26),
+ * gamma[3][3] (gammaHI, gammaHeI, gammaHeII). */
+void fo_uvb_beta_table(int nfreq, double freqdel, const double *alpha, double *beta, double *ksi, double *gamma)
+{
+    const double nu1 = F(13.598), nu2 = F(24.587), nu3 = F(54.418), pi = F(3.141592654);
+    const double ev_to_erg = 1.60217646e-12, ev_to_hz = ev_to_erg / F(6.6260693e-27);
+    for (int q = 0; q < 9; ++q) beta[q] = ksi[q] = gamma[q] = 0.0;
+    double prev = 0.0;
+    for (int i = 0; i < nfreq; ++i) {
+        const double nu = pow(10.0, (double)i * freqdel);
+        double s24 = 0.0, s25 = 0.0, s26 = 0.0;
+        if (nu > nu1) {
+            const double dum = sqrt(nu / nu1 - 1);
+            const double r = nu1 / nu;
+            s24 = F(6.3e-18) * (r * r * r * r) * exp(4.0 - 4.0 * atan(dum) / dum) / (1 - exp(-2.0 * pi / dum));
+        }
+        if (nu > nu3) {
+            const double dum = sqrt(nu / nu3 - 1);
+            const double r = nu3 / nu;
+            s25 = F(1.58e-18) * (r * r * r * r) * exp(4.0 - 4.0 * atan(dum) / dum) / (1 - exp(-2.0 * pi / dum));
+        }
+        if (nu > nu2) s26 = F(7.42e-18) * (F(1.66) * pow(nu / nu2, (double)(-2.05f)) - F(0.66) * pow(nu / nu2, (double)(-3.05f)));
+        if (i >= 1) {
+            const double delta_nu = nu - prev;
+            const double lo[3] = {nu1, nu2, nu3};
+            const int in[3] = {nu >= nu1 && nu <= nu2, nu >= nu2 && nu <= nu3, nu >= nu3};
+            for (int q = 0; q < 3; ++q) {
+                if (!in[q]) continue;
+                const double dtmp = pow(nu / lo[q], -alpha[q]) * delta_nu;
+                const double over = dtmp * ev_to_hz / (nu * ev_to_erg);
+                beta[3 * q + 0] = beta[3 * q + 0] + dtmp * s24;
+                beta[3 * q + 1] = beta[3 * q + 1] + dtmp * s25;
+                beta[3 * q + 2] = beta[3 * q + 2] + dtmp * s26;
+                ksi[3 * q + 0] = ksi[3 * q + 0] + over * s24;
+                ksi[3 * q + 1] = ksi[3 * q + 1] + over * s25;
+                ksi[3 * q + 2] = ksi[3 * q + 2] + over * s26;
+                gamma[3 * q + 0] = gamma[3 * q + 0] + over * (nu - nu1) * ev_to_erg * s24;
+                if (q >= 1) gamma[3 * q + 1] = gamma[3 * q + 1] + over * (nu - nu2) * ev_to_erg * s26;
+                if (q == 2) gamma[3 * q + 2] = gamma[3 * q + 2] + over * (nu - nu3) * ev_to_erg * s25;
+            }
+        }
+        prev = nu;
+    }
+    const double shape[3] = {(1. - pow(nu2 / nu1, 1. - alpha[0])) / (alpha[0] - 1.), (1. - pow(nu3 / nu2, 1. - alpha[1])) / (alpha[1] - 1.),
+                             1. / (alpha[2] - 1.)};
+    const double lo[3] = {nu1, nu2, nu3};
+    for (int q = 0; q < 3; ++q)
+        for (int r = 0; r < 3; ++r) beta[3 * q + r] = beta[3 * q + r] / (shape[q] * lo[q]);
+}

@@ -1,0 +1,25 @@
+! uvb_harness.f90 -- TEST INFRASTRUCTURE ONLY.  Calls the reference's uvbBetaTable (uvbBetaTable.f90, compiled where it
+! lies) as the main program does (equiSources.f90:253) and writes the nine beta, ksi and gamma values it leaves in group1..3.
+! usage: uvb_harness <alpha1> <alpha2> <alpha3> <out.bin>
+! out.bin: real64 (beta24, beta25, beta26) x group1..3 ; (ksi24, ksi25, ksi26) x group1..3 ; (gammaHI, gammaHeI, gammaHeII) x group1..3
+program uvb_harness
+  use definitions
+  implicit none
+  real(kind=RealKind) :: alpha(3)
+  character(len=512) :: arg
+  integer :: q
+  do q = 1, 3
+     call get_command_argument(q, arg)
+     read(arg,*) alpha(q)
+  enddo
+  call get_command_argument(4, arg)
+  call uvbBetaTable(nfbins, frequencyBinWidth, alpha)
+  open(12, file=trim(arg), access='stream', form='unformatted', status='replace')
+  write(12) group1%beta24, group1%beta25, group1%beta26, group2%beta24, group2%beta25, group2%beta26, &
+       group3%beta24, group3%beta25, group3%beta26
+  write(12) group1%ksi24, group1%ksi25, group1%ksi26, group2%ksi24, group2%ksi25, group2%ksi26, &
+       group3%ksi24, group3%ksi25, group3%ksi26
+  write(12) group1%gammaHI, group1%gammaHeI, group1%gammaHeII, group2%gammaHI, group2%gammaHeI, group2%gammaHeII, &
+       group3%gammaHI, group3%gammaHeI, group3%gammaHeII
+  close(12)
+end program uvb_harness

@@ -16,7 +16,7 @@ import numpy as np
 from . import _lib
 from ._lib import FtteError, Pattern
 
-__all__ = ["DiffuseTransfer", "StellarTransfer", "rmax", "dust_cross_section", "FtteError", "Pattern", "pix2ang_nest", "healpix_directions", "fold_direction",
+__all__ = ["DiffuseTransfer", "StellarTransfer", "rmax", "dust_cross_section", "uvb_beta_table", "FtteError", "Pattern", "pix2ang_nest", "healpix_directions", "fold_direction",
            "rotate_indices", "set_pattern", "layer_patterns", "compute_cell_intensity"]
 
 
@@ -220,6 +220,17 @@ def rmax() -> np.ndarray:
     out = np.empty(30)
     _check(_lib.load().ftte_rmax(_dp(out)), "ftte_rmax")
     return out
+
+
+def uvb_beta_table(alpha, nfreq: int = 400, freqdel: Optional[float] = None):
+    """uvbBetaTable (uvbBetaTable.f90): returns (beta[3][3] = [species HI, HeI, HeII][group], ksi[3][3] = [group][24, 25, 26],
+    gamma[3][3] = [group][HI, HeI, HeII]) for the three groups' power-law slopes alpha[3].  Defaults: the reference's nfbins
+    and frequencyBinWidth (the default-real literal 0.02 widened, definitionsModule.f90:239-241)."""
+    alpha = _f64(alpha).reshape(3)
+    beta, ksi, gamma = np.empty((3, 3)), np.empty((3, 3)), np.empty((3, 3))
+    _check(_lib.load().ftte_uvb_beta_table(int(nfreq), float(np.float32(0.02)) if freqdel is None else float(freqdel), _dp(alpha),
+                                           _dp(beta), _dp(ksi), _dp(gamma)), "ftte_uvb_beta_table")
+    return beta, ksi, gamma
 
 
 def dust_cross_section(lambda_micron: float, a_smc) -> float:

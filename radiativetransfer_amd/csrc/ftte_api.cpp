@@ -1240,6 +1240,13 @@ int ftte_rmax(double *rmax30)
     return FTTE_OK;
 }
 
+int ftte_uvb_beta_table(int nfreq, double freqdel, const double *alpha, double *beta, double *ksi, double *gamma)
+{
+    if (nfreq < 2 || !(freqdel > 0.0) || !alpha || !beta || !ksi || !gamma) return FTTE_ERR_ARG;
+    uvb_beta_table(nfreq, freqdel, alpha, beta, ksi, gamma);
+    return FTTE_OK;
+}
+
 double ftte_dust_cross_section(double lambda_micron, const double *a_smc)
 {
     return dust_cross_section(lambda_micron, a_smc);

@@ -112,6 +112,47 @@ double stellar_population(const double *spec, int nmetal, int nspectrum, int nwa
     return sp;
 }
 
+void uvb_beta_table(int nfreq, double freqdel, const double *alpha, double *beta, double *ksi, double *gamma)
+{
+    // uvbBetaTable.f90:40-66: the frequency grid and the three cross-sections on it
+    std::vector<double> nu(nfreq), s24(nfreq), s25(nfreq), s26(nfreq);
+    for (int i = 0; i < nfreq; ++i) {
+        nu[i] = std::pow(10.0, (double)i * freqdel);
+        s24[i] = nu[i] > kHydrogen ? hydrogenic(W(6.3e-18), kHydrogen, nu[i]) : 0.0;
+        s25[i] = nu[i] > kHeII ? hydrogenic(W(1.58e-18), kHeII, nu[i]) : 0.0;
+        s26[i] = nu[i] > kHeI ? W(7.42e-18) * (W(1.66) * std::pow(nu[i] / kHeI, (double)(-2.05f)) -
+                                               W(0.66) * std::pow(nu[i] / kHeI, (double)(-3.05f)))
+                              : 0.0;
+    }
+    const double nu1 = kHydrogen, nu2 = kHeI, nu3 = kHeII;
+    const double lo[3] = {nu1, nu2, nu3}, hi[3] = {nu2, nu3, HUGE_VAL};
+    double b[3][3] = {}, k[3][3] = {}, g[3][3] = {}; // [group][24, 25, 26] / [group][HI, HeI, HeII]
+    for (int i = 1; i < nfreq; ++i) { // :171-252
+        const double freq = nu[i], delta_nu = nu[i] - nu[i - 1];
+        for (int q = 0; q < 3; ++q) {
+            if (!(freq >= lo[q] && freq <= hi[q])) continue;
+            const double dtmp = std::pow(freq / lo[q], -alpha[q]) * delta_nu;
+            const double over = dtmp * ev_to_hz() / (freq * ev_to_erg());
+            b[q][0] = b[q][0] + dtmp * s24[i]; b[q][1] = b[q][1] + dtmp * s25[i]; b[q][2] = b[q][2] + dtmp * s26[i];
+            k[q][0] = k[q][0] + over * s24[i]; k[q][1] = k[q][1] + over * s25[i]; k[q][2] = k[q][2] + over * s26[i];
+            g[q][0] = g[q][0] + over * (freq - nu1) * ev_to_erg() * s24[i];
+            if (q >= 1) g[q][1] = g[q][1] + over * (freq - nu2) * ev_to_erg() * s26[i];
+            if (q == 2) g[q][2] = g[q][2] + over * (freq - nu3) * ev_to_erg() * s25[i];
+        }
+    }
+    // :254-296: beta is normalised by the group's energy shape
+    const double shape[3] = {(1. - std::pow(nu2 / nu1, 1. - alpha[0])) / (alpha[0] - 1.),
+                             (1. - std::pow(nu3 / nu2, 1. - alpha[1])) / (alpha[1] - 1.), 1. / (alpha[2] - 1.)};
+    for (int q = 0; q < 3; ++q) {
+        const double energy_shape = shape[q] * lo[q];
+        // out: beta[species HI, HeI, HeII][group]; ksi[group][24, 25, 26]; gamma[group][HI, HeI, HeII]
+        beta[0 * 3 + q] = b[q][0] / energy_shape;
+        beta[1 * 3 + q] = b[q][2] / energy_shape;
+        beta[2 * 3 + q] = b[q][1] / energy_shape;
+        for (int r = 0; r < 3; ++r) { ksi[q * 3 + r] = k[q][r]; gamma[q * 3 + r] = g[q][r]; }
+    }
+}
+
 void rmax_table(double *rmax30)
 {
     for (int ir = 1; ir <= 30; ++ir) {

@@ -60,6 +60,9 @@ double dust_cross_section(double lambda_um, const double *a_smc);
 // stellarPopulation, stellarPopulationModule.f90:7-50.  spec is the Fortran array specificLuminosity(nmetal,nspectrum,nwave)
 double stellar_population(const double *spec, int nmetal, int nspectrum, int nwave, const double *wavelength, int iSpectrum,
                           double coefSpectrum, int iMetal, double coefMetal, double freq_ev);
+// uvbBetaTable(nfreq, freqdel, alpha), uvbBetaTable.f90:3-305: group-averaged cross-sections beta[species HI, HeI, HeII][group],
+// photo-rate coefficients ksi[group][24, 25, 26] and heating coefficients gamma[group][HI, HeI, HeII] of the three frequency groups
+void uvb_beta_table(int nfreq, double freqdel, const double *alpha, double *beta, double *ksi, double *gamma);
 // rmax(1:30), equiSources.f90:296-309
 void rmax_table(double *rmax30);
 

@@ -258,3 +258,14 @@ def solve_rate_equations(n, level, box, rho, tgas, HI, HeI, HeII, krate, run_uvb
                                    _dp(uniform), float(threshold), k.shape[1], float(logtem0), float(logtem9), float(dlogtem), _dp(k),
                                    C.byref(its))
     return HI, HeI, HeII, int(st), its.value
+
+
+def uvb_beta_table(alpha, nfreq=400, freqdel=float(np.float32(0.02))):
+    """fo_uvb_beta_table: (beta, ksi, gamma), each [group][3] in the reference's field order (24, 25, 26 / HI, HeI, HeII)."""
+    alpha = _f64(alpha)
+    out = [np.empty((3, 3)) for _ in range(3)]
+    dp = C.POINTER(C.c_double)
+    lib().fo_uvb_beta_table.restype = None
+    lib().fo_uvb_beta_table.argtypes = [C.c_int, C.c_double, dp, dp, dp, dp]
+    lib().fo_uvb_beta_table(nfreq, freqdel, _dp(alpha), *[_dp(a) for a in out])
+    return out

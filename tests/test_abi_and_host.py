@@ -141,3 +141,13 @@ def test_point_source_host_pieces_match_reference_vectors(rt, golden):
         freq = lower * math.exp(frac * (math.log(upper) - math.log(lower)))   # stellarBetaTable.f90:122
         lam = f32(2.99792458e10) / (freq * ev_to_hz) * f32(1.e8)
         assert rt.dust_cross_section(lam / f32(1.e4), a_smc) * f32(1.e-22) == g["outputSigma"][3][ie - 1]
+
+
+def test_uvb_beta_table_of_the_product_matches_reference_vectors(rt, golden):
+    """ftte_uvb_beta_table (host code of the product, row A9's table) against the reference's own uvbBetaTable output."""
+    g = golden("uvb_beta_table")
+    for a, beta, ksi, gamma in zip(g["alpha"], g["beta"], g["ksi"], g["gamma"]):
+        b, k, h = rt.uvb_beta_table(a)
+        # the library hands beta over as [species HI, HeI, HeII][group]; the reference's fields are (24, 25, 26) per group
+        assert np.array_equal(b[0], beta[:, 0]) and np.array_equal(b[1], beta[:, 2]) and np.array_equal(b[2], beta[:, 1])
+        assert np.array_equal(k, ksi) and np.array_equal(h, gamma)

@@ -43,3 +43,11 @@ def test_equilibrium_properties(golden):
     mfp1 = 1.0 / (HI * float(np.float32(6.3e-18)) + HeI * float(np.float32(7.42e-18)) + HeII * float(np.float32(1.58e-18)))
     same = (mfp0 >= float(g["threshold"])) == (mfp1 >= float(g["threshold"]))
     assert same.sum() > 100 and np.array_equal(shuffled[0][same], HI[same]) and np.array_equal(shuffled[1][same], HeI[same])
+
+
+def test_uvb_beta_table_bitwise(golden):
+    """Group cross-sections, photo-rate and heating coefficients (uvbBetaTable.f90) against the reference's own output."""
+    g = golden("uvb_beta_table")
+    for a, beta, ksi, gamma in zip(g["alpha"], g["beta"], g["ksi"], g["gamma"]):
+        mine = O.uvb_beta_table(a)
+        assert np.array_equal(mine[0], beta) and np.array_equal(mine[1], ksi) and np.array_equal(mine[2], gamma), a
