@@ -139,3 +139,41 @@ def test_closed_loop_on_the_device(stellar, golden):
         assert np.array_equal(m[0], HI) and np.array_equal(m[1], HeI) and np.array_equal(m[2], HeII), it
         scale = np.abs(rates).max(axis=1, keepdims=True)
         assert np.all(np.abs(dev_rates - rates) <= 1e-9 * np.abs(rates) + 1e-13 * scale)
+
+
+def test_baseline_size_properties(golden):
+    """256^3 cells (BASELINE's grid): the transfer-driven update depends on the state it starts from only through the
+    point-source rates, so without them a second application reproduces the first bit for bit; species stay within their
+    element's budget; and a sample of the cells equals the oracle."""
+    import radiativetransfer_amd as rt
+    from radiativetransfer_amd import synthetic
+    g = golden("chem_uvb_refined")
+    n = 256
+    nc = n ** 3
+    rho = 3.0e-26 * synthetic.lognormal_density(nc, seed=11, sigma_ln=0.8)
+    mp, mn, psi = float(np.float32(1.6726231e-24)), float(np.float32(1.67492728e-24)), float(np.float32(0.76))
+    nh, nhe = psi * rho / mp, (1 - psi) * rho / (2 * (mp + mn))
+    rng = np.random.default_rng(3)
+    tgas = 10 ** rng.uniform(3.5, 5.0, nc)
+    J = 10 ** rng.uniform(-23.5, -21.5, (3, nc))
+    box = 2.5e23
+    with rt.StellarTransfer() as st:
+        st.set_uniform_grid(n, box)
+        st.set_rate_coefficients(float(g["logtem0"]), float(g["logtem9"]), float(g["dlogtem"]), g["k"])
+        st.set_medium(1e-3 * nh, 1e-2 * nhe, 0.3 * nhe, rho, None, 0)
+        st.set_temperature(tgas)
+        st.solve_rate_equations(True, J, g["ksi"])
+        first = st.medium()
+        change = st.solve_rate_equations(True, J, g["ksi"])
+        second = st.medium()
+    assert change == 0.0
+    for a, b in zip(first, second):
+        assert np.array_equal(a, b)
+    HI, HeI, HeII = first
+    assert np.all((HI >= 0) & (HI <= nh)) and np.all((HeI >= 0) & (HeI <= nhe)) and np.all(HeII >= -1e-12 * nhe)
+    pick = rng.choice(nc, 5000, replace=False)
+    ref = O.solve_rate_equations(n, np.zeros(pick.size, np.int32), box, rho[pick], tgas[pick], 1e-3 * nh[pick], 1e-2 * nhe[pick],
+                                 0.3 * nhe[pick], None, True, J[:, pick], g["ksi"], None, 0.0, float(g["logtem0"]), float(g["logtem9"]),
+                                 float(g["dlogtem"]), g["k"])
+    assert ref[3] == 0
+    assert np.array_equal(HI[pick], ref[0]) and np.array_equal(HeI[pick], ref[1]) and np.array_equal(HeII[pick], ref[2])
