@@ -3,9 +3,9 @@
   * diffuse part: 8 frequency groups, 96 directions, the segment-forest path; plan-build time (host, once per tree +
     direction list) and the per-iteration rate;
   * point source (the Stromgren-sphere set-up): one star in the centre of the refined patch, homogeneous hydrogen;
-    stellarBetaTable on the device, the splitting tracer, and -- when oracle/_ref/point_harness has been built -- the
-    reference's own tracer timed on this box's host on the same case, with the rates compared.
-usage: bench_config4.py [n] [--no-diffuse] [--no-reference]"""
+    stellarBetaTable on the device and the splitting tracer.  (The reference's own tracer is timed on the same case by
+    tests/compare_with_reference.py, which may use the checker; this tool does not.)
+usage: bench_config4.py [n] [--no-diffuse] [--save case.npz]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -71,19 +71,6 @@ emitted = tab[0, 0, 0, 0, 0] * weight
 print(f"point source: stellarBetaTable {t_table * 1e3:.1f} ms (device), tracer {t_trace * 1e3:.2f} ms, highestPixelLevel {hp}, "
       f"absorbed/emitted (HI) = {k[0].sum() / emitted:.6f}", flush=True)
 
-if "--no-reference" not in sys.argv:
-    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-    import make_golden_point as M
-    if os.path.exists(M.HARNESS):
-        t0 = time.perf_counter()
-        ref = M.run_reference(n, level, HI, HeI, HeII, rho, abun2, box, 0, np.array([src]), np.array([weight]), pop, isp, im, csp, cm,
-                              np.zeros((1, 4)), npixlevel=1)
-        t_ref = time.perf_counter() - t0
-        scale = np.abs(ref["krate"]).max(axis=1, keepdims=True)
-        err = np.abs(k - ref["krate"]) / (np.abs(ref["krate"]) + 1e-4 * scale)
-        print(f"reference (1 host core): star loop {ref.get('trace_seconds', float('nan')):.2f} s (whole harness run {t_ref:.1f} s); "
-              f"device tracer is {ref.get('trace_seconds', float('nan')) / t_trace:.0f} x faster; "
-              f"worst |device - reference| / (|reference| + 1e-4 max) = {err.max():.2e}; tables worst rel "
-              f"{np.abs(tab / ref['tables'] - 1).max():.1e}", flush=True)
-    else:
-        print("oracle/_ref/point_harness not built: no reference timing")
+if "--save" in sys.argv:   # for tests/compare_with_reference.py, which times the reference on the same case
+    np.savez(sys.argv[sys.argv.index("--save") + 1], n=n, level=level, HI=HI, HeI=HeI, HeII=HeII, rho=rho, abun2=abun2, box=box, src=src,
+             weight=weight, isp=isp, csp=csp, im=im, cm=cm, rates=k, tables=tab, trace_ms=t_trace * 1e3)

@@ -1,16 +1,16 @@
 #!/usr/bin/env python3
 """The reference's outer iteration (equiSources.f90:1230-1843) for its three frequency groups with everything resident on the
-device: computeOpacities -> diffuse sweep (96 directions) -> solveRateEquations, 256^3 cells.  Prints the time of each stage,
-and the CPU rate of the equilibrium update (the oracle's C restatement, one core, on a sample) beside the device's."""
+device: computeOpacities -> diffuse sweep (96 directions) -> solveRateEquations, 256^3 cells.  Prints the time of each stage.
+(The CPU rate of the same update is measured by tests/compare_with_reference.py.)  usage: bench_loop.py [n] [--save case.npz]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
 import torch
 import radiativetransfer_amd as rt
 from radiativetransfer_amd import synthetic
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+n = int(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].startswith('--') else 256
 nc = n ** 3
 g = np.load(os.path.join(ROOT, "tests", "golden", "chem_uvb_refined.npz"))   # the reference's rate-coefficient tables
 box = 2.5e23
@@ -39,14 +39,7 @@ for it in range(5):
     print(f"iteration {it}: opacities {1e3 * (t1 - t0):6.2f} ms, sweep {1e3 * (t2 - t1):7.2f} ms ({nc * 3 * 96 / (t2 - t1):.3e} updates/s), "
           f"equilibrium {1e3 * (t3 - t2):6.2f} ms ({nc / (t3 - t2):.3e} cells/s, {st.rate_equation_steps() / nc:.1f} bisection steps per cell), "
           f"largest change of a species fraction {change:.3e}", flush=True)
-try:
-    import _oracle as O
+if "--save" in sys.argv:
     m = min(nc, 200000)
-    Jh = J[:, :m].cpu().numpy()
-    t0 = time.perf_counter()
-    O.solve_rate_equations(n, np.zeros(m, np.int32), box, rho[:m], tgas[:m], HI[:m], HeI[:m], HeII[:m], None, True, Jh, ksi, None, 0.0,
-                           float(g["logtem0"]), float(g["logtem9"]), float(g["dlogtem"]), g["k"])
-    dt = time.perf_counter() - t0
-    print(f"CPU (C restatement of solveRateEquations, one core, {m} cells): {m / dt:.3e} cells/s")
-except Exception as e:  # the checker is optional here
-    print("no CPU comparison:", e)
+    np.savez(sys.argv[sys.argv.index("--save") + 1], n=n, box=box, rho=rho[:m], tgas=tgas[:m], HI=HI[:m], HeI=HeI[:m], HeII=HeII[:m],
+             J=J[:, :m].cpu().numpy(), ksi=ksi, cells_per_s=nc / (t3 - t2))
