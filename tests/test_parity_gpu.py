@@ -266,6 +266,21 @@ def test_refined_ragged_tree(engine):
     assert not J0.any()
 
 
+@pytest.mark.parametrize("nnu", [1, 5, 7, 100])
+def test_refined_any_number_of_groups(engine, golden, nnu):
+    """Group counts that are not powers of two (the general thread mapping) and beyond 96 (no cell-major copy of kappa)."""
+    g = golden("amr8_block_level1")
+    n, level = int(g["n"]), g["level"]
+    rng = np.random.default_rng(nnu)
+    kappa = rng.lognormal(0, 1, (nnu, level.size)) * n * 0.3 * (2.0 ** level)[None, :]
+    uvb = 10 ** rng.uniform(-22, -21, nnu)
+    phi, theta, w = O.healpix_directions(1)
+    engine.set_grid(n, level, 1.0)
+    engine.set_opacity(kappa)
+    J = engine.transport(phi, theta, w, uvb)
+    assert np.array_equal(J, O.sweep_tree(n, level, kappa, 1.0, phi, theta, w, uvb, arith=O.ARITH_DEVICE))
+
+
 def test_forest_path_on_a_uniform_grid_equals_the_tiled_kernel(engine):
     n = 18
     kappa, uvb, box = synthetic.uniform_workload(n, 2, seed=3, tau_median=0.4)
