@@ -18,7 +18,9 @@ CSRC = os.path.join(ROOT, "radiativetransfer_amd", "csrc")
 @pytest.fixture(scope="module")
 def forest_check(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("host") / "forest_check")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-mfma", "-o", exe,
+    # host code only: AddressSanitizer and UBSan watch the planner while it is checked (the rounding-relevant flags stay)
+    subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-ffp-contract=off", "-mfma", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=all", "-o", exe,
                            os.path.join(ROOT, "tests", "host", "forest_check.cpp"),
                            os.path.join(CSRC, "ftte_amr.cpp"), os.path.join(CSRC, "ftte_geometry.cpp")])
 
