@@ -732,6 +732,12 @@ void fo_device_log(int64_t count, const double *x, double *out)
     for (int64_t i = 0; i < count; ++i) out[i] = ftte_log1p(&fo_device_consts, x[i] - 1.0);
 }
 
+/* ftte_segment_emit element-wise: I[i] is Iin on entry and Iout on return, mean[i] the cell's share */
+void fo_device_segment_emit(int64_t count, double *I, const double *tau, const double *eta, const double *src, double *mean)
+{
+    for (int64_t i = 0; i < count; ++i) mean[i] = ftte_segment_emit(&fo_device_consts, &I[i], tau[i], eta[i], src[i]);
+}
+
 void fo_device_cell_mean(int64_t count, const double *acc, int nseg, double w, double *out)
 {
     for (int64_t i = 0; i < count; ++i) out[i] = ftte_cell_mean(acc[i], nseg, w);

@@ -83,6 +83,8 @@ typedef struct {
     double c[10];   /* (exp(r)-1-r)/r^2 ~ c0 + c1 r + ... + c9 r^9, tools/fit_exp_poly.py */
     double sqrt_half; /* sqrt(1/2) */
     double lg[7];   /* (atanh(s)/s - 1)/s^2 ~ lg0 + lg1 z + ... + lg6 z^6, z = s^2, tools/fit_log_poly.py */
+    double s_max;   /* (sqrt(2)-1)/(sqrt(2)+1): below it the log-mean of two intensities needs no logarithm */
+    double mn[7];   /* (s/atanh(s) - 1)/s^2 ~ mn0 + mn1 z + ... + mn6 z^6, tools/fit_mean_poly.py */
 } ftte_consts;
 
 #define FTTE_CONSTS_INIT                                                                                              \
@@ -97,6 +99,11 @@ typedef struct {
         {                                                                                                             \
             0x1.5555555555558p-2, 0x1.9999999995273p-3, 0x1.2492492dfd879p-3, 0x1.c71c62d5e43dfp-4,                   \
                 0x1.7462b91bd6c45p-4, 0x1.39fdcce1da1aep-4, 0x1.2b5f6919aa514p-4                                      \
+        },                                                                                                            \
+            0x1.5f619980c4336p-3,                                                                                     \
+        {                                                                                                             \
+            -0x1.5555555555556p-2, -0x1.6c16c16c1511dp-4, -0x1.7d6d2c2f3c50dp-5, -0x1.eeb2c916bdc4dp-6,               \
+                -0x1.6522b1e23e2e9p-6, -0x1.123931a9bb85bp-6, -0x1.e26cad68d7a18p-7                                   \
         }                                                                                                             \
     }
 
@@ -179,7 +186,7 @@ FTTE_HD double ftte_log1p(const ftte_consts *K, double t)
  * (note the reference's extra 1/dpath: its eta is not an emissivity per unit length).  `src` adds the physical form
  * S*(1-exp(-tau)) = (src*tau)*g for a source function S per cell -- the build's own extension for source iterations
  * (DESIGN.md).  With emission log(Iin/Iout) != tau, so the path mean is the reference's log-mean itself
- * (transportRoutinesModule.f90:1044-1048), evaluated as (Iin-Iout)/log1p((Iin-Iout)/Iout): the same number, without
+ * (transportRoutinesModule.f90:1044-1048), evaluated from the difference Iin-Iout (below): the same number, without
  * the reference's loss of the difference when the quotient Iin/Iout is rounded (fatal near Iout = Iin, i.e. wherever
  * the radiation field is close to the source function). */
 FTTE_HD double ftte_segment_emit(const ftte_consts *K, double *I, double tau, double eta, double src)
@@ -190,9 +197,26 @@ FTTE_HD double ftte_segment_emit(const ftte_consts *K, double *I, double tau, do
     const double emis = FTTE_FMA(src, tau, eta);
     const double Iout = FTTE_FMA(emis, g, Iin * e);
     *I = Iout;
-    const double diff = Iin - Iout;
-    const double falling = diff / ftte_log1p(K, diff / Iout); /* Iout == 0: selected away below */
-    const double rising = 0.5 * (Iin + Iout);
+    const double diff = Iin - Iout, sum = Iin + Iout;
+    const double rising = 0.5 * sum;
+    /* (Iin-Iout)/log(Iin/Iout) = A s/atanh(s) with A = (Iin+Iout)/2, s = (Iin-Iout)/(Iin+Iout).  While Iin/Iout < sqrt(2)
+     * (s < s_max: wherever the field is near the source function, and in every thin segment) s/atanh(s) = 1 + z h(z),
+     * z = s^2, is a polynomial: one division, no logarithm. */
+    const double s = FTTE_DIV(diff, sum);
+    const double z = s * s;
+    double h = K->mn[6];
+    h = FTTE_FMA(h, z, K->mn[5]);
+    h = FTTE_FMA(h, z, K->mn[4]);
+    h = FTTE_FMA(h, z, K->mn[3]);
+    h = FTTE_FMA(h, z, K->mn[2]);
+    h = FTTE_FMA(h, z, K->mn[1]);
+    h = FTTE_FMA(h, z, K->mn[0]);
+    double falling = FTTE_FMA(rising * z, h, rising);
+    if (FTTE_ANY(s >= K->s_max)) { /* a steep drop somewhere in the wavefront: the general form for those lanes */
+        double steep = diff / ftte_log1p(K, diff / Iout); /* Iout == 0: selected away below */
+        FTTE_KEEP(steep);
+        falling = (s >= K->s_max) ? steep : falling;
+    }
     return (Iout < Iin) ? ((Iout == 0.0) ? 0.0 : falling) : rising;
 }
 

@@ -54,3 +54,33 @@ def test_log1p_accuracy():
         worst = max(worst, float(abs(mp.mpf(float(b)) / t - 1)))
     assert worst < 2.5 * EPS, worst
     assert O.device_log(np.array([1.0]))[0] == 0.0
+
+
+def test_log_mean_with_emission_accuracy():
+    """ftte_segment_emit's path mean (Iin-Iout)/log(Iin/Iout) from the intensities it produced itself: the logarithm-free
+    form below Iin/Iout = sqrt(2), the general one above, continuous across the switch, exact limits at the ends."""
+    rng = np.random.default_rng(8)
+    n = 6000
+    Iin = 10 ** rng.uniform(-24, -18, n)
+    S = Iin * 10 ** rng.uniform(-6, 1, n)                 # source function relative to the incoming intensity
+    tau = 10 ** rng.uniform(-9, 1.5, n)
+    # near equilibrium (the case the reference's own quotient form loses) and across the switch at Iin/Iout = sqrt(2)
+    S[:1500] = Iin[:1500] * (1 + rng.uniform(-1, 1, 1500) * 10 ** rng.uniform(-14, -2, 1500))
+    tau[1500:2500] = -np.log(1 / np.sqrt(2)) * (1 + rng.uniform(-1e-3, 1e-3, 1000))
+    S[1500:2500] = 0.0
+    Iout, mean = O.device_segment_emit(Iin, tau, 0.0, S)
+    mp.mp.dps = 50
+    worst = 0.0
+    for a, b, m in zip(Iin, Iout, mean):
+        a, b = mp.mpf(float(a)), mp.mpf(float(b))
+        true = (a - b) / mp.log(a / b) if b < a else (a + b) / 2
+        if a == b:
+            true = a
+        worst = max(worst, float(abs(mp.mpf(float(m)) / true - 1)))
+    assert worst < 3 * EPS, worst
+    # in equilibrium nothing changes, and the mean is the intensity itself
+    Iout, mean = O.device_segment_emit(np.array([3e-21]), np.array([0.7]), 0.0, np.array([3e-21]))
+    assert abs(Iout[0] / 3e-21 - 1) < 2 * EPS and abs(mean[0] / 3e-21 - 1) < 2 * EPS
+    # complete extinction without a source: zero out, zero mean (the reference's (Iin-0)/log(Iin/0))
+    Iout, mean = O.device_segment_emit(np.array([3e-21]), np.array([2000.0]), 0.0, np.array([0.0]))
+    assert Iout[0] == 0.0 and mean[0] == 0.0
