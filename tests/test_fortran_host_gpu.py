@@ -44,3 +44,57 @@ def test_fortran_point_source_host(golden, tmp_path):
     ref = g["krate"]
     scale = np.abs(ref).max(axis=1, keepdims=True)
     assert np.all(np.abs(rates - ref) <= 1e-9 * np.abs(ref) + 1e-13 * scale)
+
+
+DROPIN = os.path.join(ROOT, "tests", "fortran", "dropin_check")
+
+
+def test_dropin_uvb_transfer_on_the_reference_tree(golden, tmp_path):
+    """fortran/ftte_uvb_transfer.f90 -- the replacement of equiSources.f90:1383-1806 -- run as the reference driver would run
+    it: on a fully threaded tree of the reference's own zoneType cells (module `definitions`), with the reference's own
+    direction list (nAngularLevel = 3: 192 pixels, single-precision weight).  Jmean1..3 in the tree against what the
+    reference's own sweep left there (tests/golden/dropin_uvb_192dir.npz)."""
+    import numpy as np
+    import _oracle as O
+    if not os.path.exists(DROPIN):
+        pytest.skip("tests/fortran/dropin_check not built (needs oracle/_ref and a Fortran compiler at build time)")
+    g = golden("dropin_uvb_192dir")
+    n, level = int(g["n"]), g["level"]
+    case, out = tmp_path / "case.bin", tmp_path / "J.bin"
+    with open(case, "wb") as f:
+        f.write(np.array([n, level.size], "<i4").tobytes())
+        f.write(np.array([float(g["box"])] + list(g["uvb"]), "<f8").tobytes())
+        f.write(level.astype("<i4").tobytes())
+        f.write(np.ascontiguousarray(g["kappa"], "<f8").tobytes())          # kappa(ncell,3) in Fortran order
+    res = subprocess.run([DROPIN, "uvb", str(case), str(out)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "dropin_check OK" in res.stdout, res.stdout + res.stderr
+    J = np.fromfile(out, "<f8").reshape(3, level.size)
+    _, noise = O.sweep_tree(n, level, g["kappa"], float(g["box"]), g["phi"], g["theta"], g["w"], g["uvb"], with_noise=True)
+    eps = np.finfo(float).eps
+    assert np.all(np.abs(J - g["J"]) <= 8 * noise + 12 * 4 * n * eps * np.abs(g["J"]))
+    # and bit for bit what the library gives through the Python host for the same list
+    assert np.array_equal(J, O.sweep_tree(n, level, g["kappa"], float(g["box"]), g["phi"], g["theta"], g["w"], g["uvb"], arith=O.ARITH_DEVICE))
+
+
+def test_dropin_rate_equations_on_the_reference_tree(golden, tmp_path):
+    """fortran/ftte_rate_equations.f90 in place of the solveRateEquations calls of equiSources.f90:1824-1831, on the reference's
+    tree and module tables: HI, HeI, HeII equal to the reference's own routine bit for bit."""
+    import numpy as np
+    if not os.path.exists(DROPIN):
+        pytest.skip("tests/fortran/dropin_check not built (needs oracle/_ref and a Fortran compiler at build time)")
+    g = golden("chem_uvb_refined")
+    n, level = int(g["n"]), g["level"]
+    case, out = tmp_path / "case.bin", tmp_path / "species.bin"
+    with open(case, "wb") as f:
+        f.write(np.array([n, level.size, 1], "<i4").tobytes())
+        f.write(np.array([float(g["box"])], "<f8").tobytes())
+        f.write(level.astype("<i4").tobytes())
+        for a in (g["rho"], g["tgas"], g["HI"], g["HeI"], g["HeII"], g["krate"][0], g["krate"][1], g["krate"][2], g["J"][0], g["J"][1], g["J"][2]):
+            f.write(np.asarray(a, "<f8").tobytes())
+        f.write(np.asarray(g["ksi"], "<f8").reshape(3, 3).tobytes())        # [group][reaction] == Fortran ksiIn(reaction, group)
+        f.write(np.array([float(g["logtem0"]), float(g["logtem9"]), float(g["dlogtem"])], "<f8").tobytes())
+        f.write(np.ascontiguousarray(g["k"], "<f8").tobytes())
+    res = subprocess.run([DROPIN, "chem", str(case), str(out)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "dropin_check OK" in res.stdout, res.stdout + res.stderr
+    got = np.fromfile(out, "<f8").reshape(3, level.size)
+    assert np.array_equal(got[0], g["HI_out"]) and np.array_equal(got[1], g["HeI_out"]) and np.array_equal(got[2], g["HeII_out"])
