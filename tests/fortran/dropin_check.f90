@@ -8,11 +8,18 @@
 !                                              HI, HeI, HeII, krate24..26, Jmean1..3) ; real64 ksi(3,3) ; logtem0, logtem9, dlogtem ;
 !                                              k1a..k6a(nratec)
 !                                              out : real64 HI, HeI, HeII (ncell each) after ftteSolveRateEquations(n, runUVB)
+!   dropin_check stellar <case.bin> <out.bin>  case: int32 n, ncell, nsrc, dustApproximation ; real64 box ; int32 level ;
+!                                              real64 f(ncell,5) (HI, HeI, HeII, rho, abun2) ; per star int32 level, weight,
+!                                              position(33) ; real64 a_smc(7,5), wavelength(1221), specificLuminosity(5,37,1221),
+!                                              metallicity(5) ; int32 iSpectrum ; real64 coefSpectrum
+!                                              out : real64 krate24..26, crate24..26 (ncell each) after ftteRunStellarTransfer
 program dropin_check
 
   use definitions
   use ftte_uvb_transfer
   use ftte_rate_equations
+  use ftte_stellar_transfer
+  use dust
 
   implicit none
   integer :: n, ncell, ios, cursor, bi, bj, bk, runUVB
@@ -20,15 +27,40 @@ program dropin_check
   real(kind=RealKind), allocatable :: f(:,:), outv(:,:)
   real(kind=RealKind) :: box, uvbIn(3), ksiIn(3,3)
   character(len=512) :: what, caseName, outName
-  logical :: chem
+  logical :: chem, stellarMode
+  integer :: nsrc, is, iSpectrumIn, lvl, wgt, seq(33)
+  real(kind=RealKind) :: coefSpectrumIn
+  real(kind=RealKind), allocatable :: kout(:,:)
+  type(starType), allocatable, target :: stars(:)
 
   call get_command_argument(1, what)
   call get_command_argument(2, caseName)
   call get_command_argument(3, outName)
   chem = trim(what) == 'chem'
+  stellarMode = trim(what) == 'stellar'
   open(11, file=trim(caseName), access='stream', form='unformatted', status='old', iostat=ios)
   if (ios /= 0) stop 'dropin_check: cannot open case file'
-  if (chem) then
+  if (stellarMode) then
+     read(11) n, ncell, nsrc, dustApproximation
+     read(11) box
+     allocate(lev(ncell), f(ncell,11), outv(ncell,3), kout(ncell,6), stars(nsrc))
+     f = 0.
+     read(11) lev
+     read(11) f(:,1:5)
+     do is = 1, nsrc
+        read(11) lvl, wgt, seq
+        stars(is)%level = lvl
+        stars(is)%weight = wgt
+        allocate(stars(is)%position(3*lvl+3))
+        stars(is)%position = seq(1:3*lvl+3)
+     enddo
+     read(11) a_smc
+     read(11) wavelength
+     read(11) specificLuminosity
+     read(11) metallicity
+     read(11) iSpectrumIn
+     read(11) coefSpectrumIn
+  else if (chem) then
      read(11) n, ncell, runUVB
      read(11) box
      allocate(lev(ncell), f(ncell,11), outv(ncell,3))
@@ -70,7 +102,9 @@ program dropin_check
   enddo
   if (cursor /= ncell) stop 'dropin_check: level list does not describe a tree of ncell leaves'
 
-  if (chem) then
+  if (stellarMode) then
+     call ftteRunStellarTransfer(n, nsrc, stars, iSpectrumIn, coefSpectrumIn)
+  else if (chem) then
      call ftteSolveRateEquations(n, runUVB /= 0)
   else
      call ftteRunUVBTransfer(n)
@@ -85,7 +119,11 @@ program dropin_check
      enddo
   enddo
   open(12, file=trim(outName), access='stream', form='unformatted', status='replace')
-  write(12) outv
+  if (stellarMode) then
+     write(12) kout
+  else
+     write(12) outv
+  endif
   close(12)
   write(*,*) 'dropin_check OK'
 
@@ -101,7 +139,10 @@ contains
     c%level = int(level,1)
     if (lev(cursor) == level) then
        c%refined = .false.
-       if (chem) then
+       if (stellarMode) then
+          c%HI = f(cursor,1) ; c%HeI = f(cursor,2) ; c%HeII = f(cursor,3) ; c%rho = f(cursor,4) ; c%abun2 = f(cursor,5)
+          c%krate24 = 0. ; c%krate25 = 0. ; c%krate26 = 0. ; c%crate24 = 0. ; c%crate25 = 0. ; c%crate26 = 0.
+       else if (chem) then
           c%rho = f(cursor,1) ; c%tgas = f(cursor,2)
           c%HI = f(cursor,3) ; c%HeI = f(cursor,4) ; c%HeII = f(cursor,5)
           c%krate24 = f(cursor,6) ; c%krate25 = f(cursor,7) ; c%krate26 = f(cursor,8)
@@ -140,7 +181,10 @@ contains
        enddo
     else
        cursor = cursor + 1
-       if (chem) then
+       if (stellarMode) then
+          kout(cursor,1) = c%krate24 ; kout(cursor,2) = c%krate25 ; kout(cursor,3) = c%krate26
+          kout(cursor,4) = c%crate24 ; kout(cursor,5) = c%crate25 ; kout(cursor,6) = c%crate26
+       else if (chem) then
           outv(cursor,1) = c%HI ; outv(cursor,2) = c%HeI ; outv(cursor,3) = c%HeII
        else
           outv(cursor,1) = c%Jmean1 ; outv(cursor,2) = c%Jmean2 ; outv(cursor,3) = c%Jmean3

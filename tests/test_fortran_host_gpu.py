@@ -98,3 +98,62 @@ def test_dropin_rate_equations_on_the_reference_tree(golden, tmp_path):
     assert res.returncode == 0 and "dropin_check OK" in res.stdout, res.stdout + res.stderr
     got = np.fromfile(out, "<f8").reshape(3, level.size)
     assert np.array_equal(got[0], g["HI_out"]) and np.array_equal(got[1], g["HeI_out"]) and np.array_equal(got[2], g["HeII_out"])
+
+
+def test_dropin_stellar_transfer_on_the_reference_tree(golden, tmp_path):
+    """fortran/ftte_stellar_transfer.f90 in place of the star loop equiSources.f90:1260-1362: stars given as the reference
+    holds them (level + call sequence), population picked from the host cell's metallicity as :1281-1291 does, module
+    arrays a_smc / wavelength / specificLuminosity / metallicity; krate24..26, crate24..26 in the tree against the
+    reference's own tracer (tests/golden/point10_refined_dust.npz)."""
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden_point as M
+    if not os.path.exists(DROPIN):
+        pytest.skip("tests/fortran/dropin_check not built (needs oracle/_ref and a Fortran compiler at build time)")
+    g = golden("point10_refined_dust")
+    n, level = int(g["n"]), g["level"]
+    a_smc, wavelength, spec = M.synthetic_population()
+    # call sequences of the leaves, as readCellArray.f90:154-187 numbers them
+    seqs, cursor = [], 0
+
+    def grow(lvl, path):
+        nonlocal cursor
+        if level[cursor] == lvl:
+            seqs.append(path)
+            cursor += 1
+        else:
+            for a in (1, 2):
+                for b in (1, 2):
+                    for c in (1, 2):
+                        grow(lvl + 1, path + [a, b, c])
+    for i in range(1, n + 1):
+        for j in range(1, n + 1):
+            for k in range(1, n + 1):
+                grow(0, [i, j, k])
+    # a metallicity grid that makes the drop-in pick the golden's (iMetal, coefMetal) = (1, 0.1) for abun2 = 0.2
+    tmp = np.log10(0.2)
+    metallicity = np.array([tmp - 0.1, tmp + 0.9, tmp + 1.9, tmp + 2.9, tmp + 3.9])
+    case, out = tmp_path / "case.bin", tmp_path / "rates.bin"
+    with open(case, "wb") as f:
+        f.write(np.array([n, level.size, g["src_leaf"].size, int(g["dust"])], "<i4").tobytes())
+        f.write(np.array([float(g["box"])], "<f8").tobytes())
+        f.write(level.astype("<i4").tobytes())
+        for k in ("HI", "HeI", "HeII", "rho", "abun2"):
+            f.write(g[k].astype("<f8").tobytes())
+        for leaf, weight in zip(g["src_leaf"], g["src_weight"]):
+            seq = seqs[int(leaf)]
+            f.write(np.array([len(seq) // 3 - 1, int(weight)] + seq + [0] * (33 - len(seq)), "<i4").tobytes())
+        f.write(np.asfortranarray(a_smc).tobytes(order="F"))
+        f.write(np.asarray(wavelength, "<f8").tobytes())
+        f.write(np.asfortranarray(spec).tobytes(order="F"))
+        f.write(metallicity.astype("<f8").tobytes())
+        f.write(np.array([int(g["iSpectrum"])], "<i4").tobytes())
+        f.write(np.array([float(g["coefSpectrum"])], "<f8").tobytes())
+    res = subprocess.run([DROPIN, "stellar", str(case), str(out)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "dropin_check OK" in res.stdout, res.stdout + res.stderr
+    rates = np.fromfile(out, "<f8").reshape(6, level.size)
+    ref = g["krate"]
+    scale = np.abs(ref).max(axis=1, keepdims=True)
+    assert np.all(np.abs(rates - ref) <= 1e-9 * np.abs(ref) + 1e-13 * scale)
+    assert np.array_equal(rates == 0, ref == 0)
