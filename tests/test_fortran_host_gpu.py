@@ -157,3 +157,54 @@ def test_dropin_stellar_transfer_on_the_reference_tree(golden, tmp_path):
     scale = np.abs(ref).max(axis=1, keepdims=True)
     assert np.all(np.abs(rates - ref) <= 1e-9 * np.abs(ref) + 1e-13 * scale)
     assert np.array_equal(rates == 0, ref == 0)
+
+
+def test_fortran_host_runs_the_whole_iteration(golden, tmp_path):
+    """fortran/ftte_demo_loop: star loop -> opacities -> diffuse sweep -> equilibrium, three times, from a Fortran host;
+    the final species and J against the same loop through the oracle."""
+    import numpy as np
+    import _oracle as O
+    exe = os.path.join(ROOT, "fortran", "ftte_demo_loop")
+    if not os.path.exists(exe):
+        pytest.skip("fortran/ftte_demo_loop not built (no Fortran compiler at build time)")
+    g = golden("chem_uvb_refined")
+    tabs = golden("point16_homogeneous")["tables"]
+    n, level, box = int(g["n"]), g["level"], float(g["box"])
+    nc = level.size
+    alpha = np.array([1.8, 1.5, 1.2])
+    uvb = np.array([2e-22, 1e-22, 3e-23])
+    src, ndot = np.array([5, nc // 2], np.int64), np.array([50.0, 20.0])
+    niter, L = 3, 2
+    case, out = tmp_path / "case.bin", tmp_path / "out.bin"
+    with open(case, "wb") as f:
+        f.write(np.array([n, nc, src.size, niter, L, g["k"].shape[1]], "<i4").tobytes())
+        f.write(np.concatenate([[box], alpha, uvb]).astype("<f8").tobytes())
+        f.write(level.astype("<i4").tobytes())
+        for k in ("rho", "tgas", "HI", "HeI", "HeII"):
+            f.write(g[k].astype("<f8").tobytes())
+        f.write(src.astype("<i8").tobytes())
+        f.write(ndot.astype("<f8").tobytes())
+        f.write(tabs.astype("<f8").tobytes())
+        f.write(np.array([float(g["logtem0"]), float(g["logtem9"]), float(g["dlogtem"])], "<f8").tobytes())
+        f.write(np.ascontiguousarray(g["k"], "<f8").tobytes())      # k(nratec,6) in Fortran order == [6][nratec]
+    res = subprocess.run([exe, str(case), str(out)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "ftte_demo_loop OK" in res.stdout, res.stdout + res.stderr
+    raw = np.fromfile(out, "<f8")
+    species, J = raw[:3 * nc].reshape(3, nc), raw[3 * nc:].reshape(3, nc)
+    # the same loop through the oracle
+    beta_g, ksi, _ = O.uvb_beta_table(alpha)              # [group][24, 25, 26]
+    beta = np.array([beta_g[:, 0], beta_g[:, 2], beta_g[:, 1]])   # [species HI, HeI, HeII][group]
+    phi, theta, _ = O.healpix_directions(L)
+    w = np.full(phi.size, float(np.float32(1.0) / np.float32(phi.size)))
+    HI, HeI, HeII = g["HI"].copy(), g["HeI"].copy(), g["HeII"].copy()
+    for _ in range(niter):
+        rates, _ = O.point_sources(n, level, HI, HeI, HeII, g["rho"], g["rho"], box, 0, src, ndot, tabs.reshape(6, -1))
+        kappa = O.compute_opacities(HI, HeI, HeII, beta)
+        Jo = O.sweep_tree(n, level, kappa, box, phi, theta, w, uvb, arith=O.ARITH_DEVICE)
+        Jo = Jo[0] if isinstance(Jo, tuple) else Jo
+        HI, HeI, HeII, status, _ = O.solve_rate_equations(n, level, box, g["rho"], g["tgas"], HI, HeI, HeII, rates[:3], True, Jo, ksi, None, 0.0,
+                                                          float(g["logtem0"]), float(g["logtem9"]), float(g["dlogtem"]), g["k"])
+        assert status == 0
+    for mine, ref in zip(species, (HI, HeI, HeII)):
+        assert np.all(np.abs(mine - ref) <= 1e-8 * np.abs(ref) + 1e-30)
+    assert np.all(np.abs(J - Jo) <= 1e-9 * np.abs(Jo))
