@@ -34,6 +34,13 @@
 
 namespace ftte {
 
+// Pointers that went through uniform() have lost their address space as far as the compiler can tell, and a generic pointer
+// is read with flat_load, which also occupies the LDS path and counts on lgkmcnt: say that they are global memory.
+using gcbyte = const __attribute__((address_space(1))) char;
+using gbyte = __attribute__((address_space(1))) char;
+using gcdouble = const __attribute__((address_space(1))) double;
+using gdouble = __attribute__((address_space(1))) double;
+
 // value held by lane-1 (lane 0 receives its own value back; it is a halo lane and never uses it)
 __device__ __forceinline__ double from_lane_below(double x)
 {
@@ -90,8 +97,8 @@ __device__ __forceinline__ double segment(const ftte_consts &K, double &I, doubl
 //                     wavefront has a halo row, the others receive the two numbers per lane they need
 //                     through LDS (`xchg`, one s_barrier per layer that has such segments) and own row 0.
 template <int ROWS, int RC, bool EDGE, int STACK, int EMIT>
-__device__ __forceinline__ void layer_step(const ftte_consts &K, double (&I)[ROWS], const char *__restrict__ kplane,
-                                           const char *__restrict__ xplane, char *__restrict__ jplane, int cv0, int cu,
+__device__ __forceinline__ void layer_step(const ftte_consts &K, double (&I)[ROWS], gcbyte *__restrict__ kplane,
+                                           gcbyte *__restrict__ xplane, gbyte *__restrict__ jplane, int cv0, int cu,
                                            int n, int sv, bool mirror_u,
                                            double d0, double d1, double d2, double w, double uvb, bool first,
                                            bool lane_owned, int lane, int wid, double *xchg)
@@ -118,15 +125,15 @@ __device__ __forceinline__ void layer_step(const ftte_consts &K, double (&I)[ROW
 #pragma unroll
     for (int r = 0; r <= ROWS; ++r) {
         const int row = EDGE ? clampi(cv0 + r, 1, n) : cv0 + r;
-        const char *rp = kplane + row * row_bytes;
+        gcbyte *rp = kplane + row * row_bytes;
         const bool need0 = (r < ROWS) || (SHAPE == RC_TWO_V || SHAPE == RC_THREE_V);
         const bool need1 = HAS_U && ((SHAPE == RC_TWO_U) ? (r < ROWS) : (SHAPE == RC_THREE_U) ? true : (r >= 1));
-        if (need0) K0[r] = *reinterpret_cast<const double *>(rp + off0);
-        if (need1) K1[r] = *reinterpret_cast<const double *>(rp + off1);
+        if (need0) K0[r] = *(gcdouble *)(rp + off0);
+        if (need1) K1[r] = *(gcdouble *)(rp + off1);
         if (EMIT) {
-            const char *xp = xplane + row * row_bytes;
-            if (need0) X0[r] = *reinterpret_cast<const double *>(xp + off0);
-            if (need1) X1[r] = *reinterpret_cast<const double *>(xp + off1);
+            gcbyte *xp = xplane + row * row_bytes;
+            if (need0) X0[r] = *(gcdouble *)(xp + off0);
+            if (need1) X1[r] = *(gcdouble *)(xp + off1);
         }
     }
     constexpr int XM = EMIT ? ~0 : 0; // index mask: without emission the X arrays have one (unused) element
@@ -138,7 +145,7 @@ __device__ __forceinline__ void layer_step(const ftte_consts &K, double (&I)[ROW
         for (int r = R0; r < ROWS; ++r) {
             const int row = cv0 + r;
             if ((r > 0 || row0_owned) && (!EDGE || (row >= 1 && row <= n)))
-                Jacc[r] = *reinterpret_cast<const double *>(jplane + row * row_bytes + off0);
+                Jacc[r] = *(gcdouble *)(jplane + row * row_bytes + off0);
         }
     }
 
@@ -226,14 +233,14 @@ __device__ __forceinline__ void layer_step(const ftte_consts &K, double (&I)[ROW
         for (int r = R0; r < ROWS; ++r) {
             const int row = cv0 + r;
             if ((r > 0 || row0_owned) && (!EDGE || (row >= 1 && row <= n)))
-                *reinterpret_cast<double *>(jplane + row * row_bytes + off0) = Jacc[r];
+                *(gdouble *)(jplane + row * row_bytes + off0) = Jacc[r];
         }
     }
 }
 
 template <int ROWS, bool EDGE, int STACK, int EMIT>
-__device__ __forceinline__ void layer_dispatch(const ftte_consts &K, double (&I)[ROWS], int rc, const char *kplane,
-                                               const char *xplane, char *jplane, int cv0, int cu, int n, int sv,
+__device__ __forceinline__ void layer_dispatch(const ftte_consts &K, double (&I)[ROWS], int rc, gcbyte *kplane,
+                                               gcbyte *xplane, gbyte *jplane, int cv0, int cu, int n, int sv,
                                                bool mirror_u, double d0,
                                                double d1, double d2, double w, double uvb, bool first, bool lane_owned,
                                                int lane, int wid, double *xchg)
@@ -281,9 +288,9 @@ __global__ void __launch_bounds__(64 * STACK, WAVES) sweep_kernel(const LaunchRe
     const bool mirror_u = uniform(D.su) < 0;
     const bool first = uniform(D.first) != 0;
     const long org = uniform((long)D.org);
-    const char *kbase = reinterpret_cast<const char *>(uniform(D.kappa) + (long)nu * L.group_stride + org);
-    char *jbase = reinterpret_cast<char *>(uniform(D.J) + (long)nu * L.group_stride + org);
-    const char *xbase = EMIT ? reinterpret_cast<const char *>(uniform(D.emis) + (long)nu * L.group_stride + org) : nullptr;
+    gcbyte *kbase = (gcbyte *)(uniform(D.kappa) + (long)nu * L.group_stride + org);
+    gbyte *jbase = (gbyte *)(uniform(D.J) + (long)nu * L.group_stride + org);
+    gcbyte *xbase = EMIT ? (gcbyte *)(uniform(D.emis) + (long)nu * L.group_stride + org) : nullptr;
     const int u_lo = uniform(D.u_lo), v_lo = uniform(D.v_lo);
 
     // labels of this lane's rays: u label of the lane (lane 0: halo), v label of this wavefront's row 0
@@ -296,19 +303,19 @@ __global__ void __launch_bounds__(64 * STACK, WAVES) sweep_kernel(const LaunchRe
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) I[r] = uvb;
 
-    const LayerRec *layers = uniform(D.layers);
+    const __attribute__((address_space(1))) LayerRec *layers = (const __attribute__((address_space(1))) LayerRec *)uniform(D.layers);
     int parity = 0;
     for (int i = i_first; i <= i_last; ++i) {
-        const LayerRec *rp = layers + (i - 1);
+        const __attribute__((address_space(1))) LayerRec *rp = layers + (i - 1);
         const double d0 = uniform(rp->dpath[0]), d1 = uniform(rp->dpath[1]), d2 = uniform(rp->dpath[2]);
         const int rc = uniform(rp->info) & 7;
         const int drift = uniform(rp->drift);
         const int du = (int)(short)(drift & 0xffff), dv = drift >> 16;
         const int cu = ul + du;
         const int cv0 = vl0 + dv;
-        const char *kplane = kbase + 8l * i * si;
-        char *jplane = jbase + 8l * i * si;
-        const char *xplane = EMIT ? xbase + 8l * i * si : nullptr;
+        gcbyte *kplane = kbase + 8l * i * si;
+        gbyte *jplane = jbase + 8l * i * si;
+        gcbyte *xplane = EMIT ? xbase + 8l * i * si : nullptr;
         double *xchg = xchg_lds + parity * (STACK * 2 * 64);
         const bool has_v = rc != RC_ONE && rc != RC_TWO_U; // this layer passes segments from row to row
 
