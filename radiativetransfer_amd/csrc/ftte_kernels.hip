@@ -456,7 +456,7 @@ __global__ void __launch_bounds__(256) merge_kernel(const MergeRec M, double *__
             __syncthreads();
             for (int q = 0; q < 4; ++q) {
                 const int r = ty + 8 * q; // kc offset
-                if (k0 + r < n && j0 + tx < n) tile[r][tx] = s[((long)(k0 + r) * n + ic) * n + j0 + tx];
+                if (k0 + r < n && j0 + tx < n) tile[r][tx] = __builtin_nontemporal_load(&s[((long)(k0 + r) * n + ic) * n + j0 + tx]);
             }
             __syncthreads();
         }
@@ -465,8 +465,8 @@ __global__ void __launch_bounds__(256) merge_kernel(const MergeRec M, double *__
             const int jc = j0 + r, kc = k0 + tx;
             if (jc >= n || kc >= n) continue;
             double v;
-            if (M.layout[a] == 0) v = s[((long)ic * n + jc) * n + kc];
-            else if (M.layout[a] == 1) v = s[((long)jc * n + ic) * n + kc];
+            if (M.layout[a] == 0) v = __builtin_nontemporal_load(&s[((long)ic * n + jc) * n + kc]);
+            else if (M.layout[a] == 1) v = __builtin_nontemporal_load(&s[((long)jc * n + ic) * n + kc]);
             else v = tile[tx][r];
             sum[q] = have ? sum[q] + v : v;
         }
@@ -474,7 +474,7 @@ __global__ void __launch_bounds__(256) merge_kernel(const MergeRec M, double *__
     }
     for (int q = 0; q < 4; ++q) {
         const int jc = j0 + ty + 8 * q, kc = k0 + tx;
-        if (jc < n && kc < n) J[g * group_stride + ((long)ic * n + jc) * n + kc] = sum[q];
+        if (jc < n && kc < n) __builtin_nontemporal_store(sum[q], &J[g * group_stride + ((long)ic * n + jc) * n + kc]);
     }
 }
 
@@ -528,8 +528,8 @@ __global__ void __launch_bounds__(256) amr_level_kernel(const AmrLevelRec A)
         const double x = A.emis[kat];
         m = ftte_segment_emit(&A.math, &I, kap * R.dpath, A.emit == 1 ? x : 0.0, A.emit == 2 ? x : 0.0);
     }
-    D.Iout[at] = I;
-    D.mean[at] = m;
+    D.Iout[at] = I;                              // read again by the segments downstream
+    __builtin_nontemporal_store(m, &D.mean[at]); // read once, by the combine kernel
 }
 
 // J[g][leaf] += (w / nseg) * (mean_xy + mean_xz + mean_yz), one direction after the other in list order
@@ -545,11 +545,11 @@ __global__ void __launch_bounds__(256) amr_combine_kernel(const AmrLevelRec A, d
     double acc_J = zero_first ? 0.0 : J[(long)nu * A.ncell + cell];
     for (int d = 0; d < A.ndir; ++d) {
         const AmrDirRec &D = A.dir[d];
-        double acc = D.mean[(3 * cell) * nnu + nu];
+        double acc = __builtin_nontemporal_load(&D.mean[(3 * cell) * nnu + nu]);
         int nseg = 1;
         const int active = D.active[cell];
-        if (active & 1) { acc += D.mean[(3 * cell + 1) * nnu + nu]; ++nseg; }
-        if (active & 2) { acc += D.mean[(3 * cell + 2) * nnu + nu]; ++nseg; }
+        if (active & 1) { acc += __builtin_nontemporal_load(&D.mean[(3 * cell + 1) * nnu + nu]); ++nseg; }
+        if (active & 2) { acc += __builtin_nontemporal_load(&D.mean[(3 * cell + 2) * nnu + nu]); ++nseg; }
         acc_J += ftte_cell_mean(acc, nseg, D.w);
     }
     J[(long)nu * A.ncell + cell] = acc_J;
