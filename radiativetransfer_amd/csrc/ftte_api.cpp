@@ -34,6 +34,7 @@ struct DirPlan {
     int64_t org = 0;
     int si = 0, sv = 0, su = 0;
     int u_lo = 1, v_lo = 1, ntu = 0, ntv = 0;
+    int du_mid = 0, dv_mid = 0; // drift at the middle layer: where a tile's rays are halfway through the grid
     size_t layer_off = 0; // into the layer table
     int slot = 0;
 };
@@ -261,6 +262,8 @@ int build_plan(ftte_ctx *c, int rows, int stack, int ndir, const double *phi, co
         // rays present at the last layer start at label -drift (base cell 0, second piece in cell 1)
         D.u_lo = 1 - du_cum[n - 1];
         D.v_lo = 1 - dv_cum[n - 1];
+        D.du_mid = du_cum[n / 2];
+        D.dv_mid = dv_cum[n / 2];
         D.ntu = (n - D.u_lo + 1 + 62) / 63;
         D.ntv = (n - D.v_lo + 1 + tile_rows - 1) / tile_rows;
         D.slot = in_layout[D.layout]++ % slots;
@@ -275,6 +278,7 @@ int build_plan(ftte_ctx *c, int rows, int stack, int ndir, const double *phi, co
             LP.layout = layout;
             LP.first = (b == 0);
             LP.item_off = P.items.size();
+            std::vector<uint32_t> where; // per item of this launch: the tile's place in the plane halfway through the march
             for (size_t s = b; s < std::min(members.size(), b + (size_t)slots); ++s) {
                 const int d = members[s];
                 const DirPlan &D = P.dirs[d];
@@ -300,6 +304,8 @@ int build_plan(ftte_ctx *c, int rows, int stack, int ndir, const double *phi, co
                         it.slot = (int16_t)slot; it.tu = (int16_t)tu; it.tv = (int16_t)tv;
                         it.i_first = (int16_t)i_first; it.i_last = (int16_t)i_last; it.pad = 0;
                         P.items.push_back(it);
+                        const int pu = std::max(0, ul_min + D.du_mid + 64) / 64, pv = std::max(0, vl_min + D.dv_mid + 64) / std::max(tile_rows, 1);
+                        where.push_back(((uint32_t)pv << 16) | (uint32_t)(pu & 0xffff));
                     }
                 }
                 LP.updates += (int64_t)n * n * n;
@@ -308,9 +314,24 @@ int build_plan(ftte_ctx *c, int rows, int stack, int ndir, const double *phi, co
             // longest marches first, so that the short corner tiles fill the tail of the launch.  (Grouping the tiles
             // of one direction together instead -- hoping for L2 hits on shared halo rows -- was measured: no drop in
             // FETCH_SIZE, 6 % slower through worse load balance.)
-            std::stable_sort(P.items.begin() + LP.item_off, P.items.end(), [](const WorkItem &a, const WorkItem &b) {
-                return (a.i_last - a.i_first) > (b.i_last - b.i_first);
-            });
+            {
+                // longest marches first, so that the short corner tiles fill the tail of the launch; among equally long
+                // ones, tiles of the directions in flight that cross the same part of the grid side by side, so that they
+                // read the same part of a kappa plane at about the same time (+2 %; the place is taken halfway through the march.
+                // Grouping by direction instead: -6 %)
+                std::vector<uint32_t> idx(where.size());
+                for (size_t q = 0; q < idx.size(); ++q) idx[q] = (uint32_t)q;
+                const WorkItem *base = P.items.data() + LP.item_off;
+                std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) {
+                    const int lx = base[x].i_last - base[x].i_first, ly = base[y].i_last - base[y].i_first;
+                    if (lx != ly) return lx > ly;
+                    if (where[x] != where[y]) return where[x] < where[y];
+                    return base[x].slot < base[y].slot;
+                });
+                std::vector<WorkItem> sorted(idx.size());
+                for (size_t q = 0; q < idx.size(); ++q) sorted[q] = base[idx[q]];
+                std::copy(sorted.begin(), sorted.end(), P.items.begin() + LP.item_off);
+            }
             P.launches.push_back(LP);
         }
     }
