@@ -120,6 +120,10 @@ struct ftte_ctx {
     size_t amr_kappa_cap = 0, amr_emis_cap = 0;
     size_t amr_scratch_cap = 0; // elements per array
 
+    // partial merges run beside the sweeps of the next layout on their own (non-blocking) stream
+    hipStream_t merge_stream = nullptr;
+    hipEvent_t ev_layout_done = nullptr, ev_merge_done = nullptr;
+
     PointState point; // point sources: rate tables, medium, tracer scratch
 
     // ionisation equilibrium (solveRateEquations)
@@ -593,6 +597,9 @@ int ftte_destroy(ftte_ctx *c)
     if (c->amr_mean) (void)hipFree(c->amr_mean);
     if (c->amr_kappa) (void)hipFree(c->amr_kappa);
     if (c->amr_emis) (void)hipFree(c->amr_emis);
+    if (c->merge_stream) (void)hipStreamDestroy(c->merge_stream);
+    if (c->ev_layout_done) (void)hipEventDestroy(c->ev_layout_done);
+    if (c->ev_merge_done) (void)hipEventDestroy(c->ev_merge_done);
     c->point.release();
     c->drop_chem_grid();
     if (c->chem_k) (void)hipFree(c->chem_k);
@@ -825,6 +832,14 @@ int ftte_diffuse_sweep_device(ftte_ctx *c, int ndir, const double *phi, const do
     }
     c->timing_used = 0;
 
+    if (!c->merge_stream) {
+        FTTE_HIP(c, hipStreamCreateWithFlags(&c->merge_stream, hipStreamNonBlocking));
+        FTTE_HIP(c, hipEventCreateWithFlags(&c->ev_layout_done, hipEventDisableTiming));
+        FTTE_HIP(c, hipEventCreateWithFlags(&c->ev_merge_done, hipEventDisableTiming));
+    }
+    // the previous sweep's J may still be being merged into the same buffer by an earlier call on another stream
+    FTTE_HIP(c, hipStreamWaitEvent(c->merge_stream, c->ev_merge_done, 0));
+    bool merged_any = false;
     for (size_t li = 0; li < P.launches.size(); ++li) {
         const LaunchPlan &LP = P.launches[li];
         LaunchRec L;
@@ -861,16 +876,26 @@ int ftte_diffuse_sweep_device(ftte_ctx *c, int ndir, const double *phi, const do
         if (lrc) return fail(c, FTTE_ERR_NO_DEVICE, "sweep kernel launch failed");
         FTTE_HIP(c, hipEventRecord(T.stop, stream));
         c->timing_used = (int)li + 1;
-    }
 
-    // J = sum of the accumulators, layout 0 first, slots in order
-    const double *accs[3 * kMaxSlots];
-    int layouts[3 * kMaxSlots], count = 0;
-    for (int l = 0; l < 3; ++l)
-        for (int s = 0; s < kMaxSlots; ++s)
-            if (P.used[l][s]) { accs[count] = c->acc[l][s]; layouts[count++] = l; }
-    if (launch_merge(accs, layouts, count, J_dev, n, nnu, (long)c->ncell, stream))
-        return fail(c, FTTE_ERR_NO_DEVICE, "merge kernel launch failed");
+        // last launch of a layout: J (+)= its accumulators, slots in order, layout 0 first -- the same sequence of
+        // additions as one merge over all of them.  It runs on a second stream beside the sweeps of the next layout, which
+        // leave the memory system some room (the last layout's merge has nothing to hide behind).
+        if (li + 1 == P.launches.size() || P.launches[li + 1].layout != LP.layout) {
+            const double *accs[kMaxSlots];
+            int layouts[kMaxSlots], count = 0;
+            for (int s = 0; s < kMaxSlots; ++s)
+                if (P.used[LP.layout][s]) { accs[count] = c->acc[LP.layout][s]; layouts[count++] = LP.layout; }
+            FTTE_HIP(c, hipEventRecord(c->ev_layout_done, stream));
+            FTTE_HIP(c, hipStreamWaitEvent(c->merge_stream, c->ev_layout_done, 0));
+            if (launch_merge(accs, layouts, count, J_dev, n, nnu, (long)c->ncell, merged_any, c->merge_stream))
+                return fail(c, FTTE_ERR_NO_DEVICE, "merge kernel launch failed");
+            merged_any = true;
+        }
+    }
+    if (!merged_any) FTTE_HIP(c, hipMemsetAsync(J_dev, 0, sizeof(double) * (size_t)nnu * c->ncell, stream)); // no directions
+    FTTE_HIP(c, hipEventRecord(c->ev_merge_done, c->merge_stream));
+    FTTE_HIP(c, hipStreamWaitEvent(stream, c->ev_merge_done, 0));
+
     return FTTE_OK;
 }
 

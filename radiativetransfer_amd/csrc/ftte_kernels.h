@@ -14,7 +14,7 @@ int launch_sweep(const LaunchRec &L, int rows, int waves, int stack, int nnu, hi
 int launch_to_layout(int layout, const double *src, double *dst, int n, int nnu, long group_stride, hipStream_t stream);
 // J (cell-array order) = acc[0] + acc[1] + ... in list order; layout[a] in {0,1,2}
 int launch_merge(const double *const *acc, const int *layout, int count, double *J, int n, int nnu, long group_stride,
-                 hipStream_t stream);
+                 bool accumulate, hipStream_t stream);
 int launch_opacity(const double *HI, const double *HeI, const double *HeII, const double *beta, double *kappa, long ncell,
                    int nnu, hipStream_t stream);
 

@@ -440,7 +440,8 @@ struct MergeRec {
     int count;
 };
 
-__global__ void __launch_bounds__(256) merge_kernel(const MergeRec M, double *__restrict__ J, int n, long group_stride)
+// accumulate != 0: J += the accumulators (the additions continue the sequence of an earlier partial merge)
+__global__ void __launch_bounds__(256) merge_kernel(const MergeRec M, double *__restrict__ J, int n, long group_stride, int accumulate)
 {
     __shared__ double tile[32][33];
     const long g = blockIdx.z / n;
@@ -449,6 +450,13 @@ __global__ void __launch_bounds__(256) merge_kernel(const MergeRec M, double *__
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     double sum[4] = {0.0, 0.0, 0.0, 0.0};
     bool have = false;
+    if (accumulate) {
+        for (int q = 0; q < 4; ++q) {
+            const int jc = j0 + ty + 8 * q, kc = k0 + tx;
+            if (jc < n && kc < n) sum[q] = __builtin_nontemporal_load(&J[g * group_stride + ((long)ic * n + jc) * n + kc]);
+        }
+        have = true;
+    }
     for (int a = 0; a < M.count; ++a) {
         const double *s = M.acc[a] + g * group_stride;
         if (M.layout[a] == 2) {
@@ -479,14 +487,14 @@ __global__ void __launch_bounds__(256) merge_kernel(const MergeRec M, double *__
 }
 
 int launch_merge(const double *const *acc, const int *layout, int count, double *J, int n, int nnu, long group_stride,
-                 hipStream_t stream)
+                 bool accumulate, hipStream_t stream)
 {
     if (count > 3 * kMaxSlots) return -1;
     MergeRec M;
     M.count = count;
     for (int a = 0; a < count; ++a) { M.acc[a] = acc[a]; M.layout[a] = layout[a]; }
     const dim3 grid((n + 31) / 32, (n + 31) / 32, n * nnu);
-    hipLaunchKernelGGL(merge_kernel, grid, dim3(256), 0, stream, M, J, n, group_stride);
+    hipLaunchKernelGGL(merge_kernel, grid, dim3(256), 0, stream, M, J, n, group_stride, accumulate ? 1 : 0);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
