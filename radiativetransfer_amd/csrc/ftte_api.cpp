@@ -122,7 +122,7 @@ struct ftte_ctx {
 
     // partial merges run beside the sweeps of the next layout on their own (non-blocking) stream
     hipStream_t merge_stream = nullptr;
-    hipEvent_t ev_layout_done = nullptr, ev_merge_done = nullptr;
+    hipEvent_t ev_layout_done = nullptr, ev_merge_done = nullptr, ev_layouts_ready = nullptr;
 
     PointState point; // point sources: rate tables, medium, tracer scratch
 
@@ -600,6 +600,7 @@ int ftte_destroy(ftte_ctx *c)
     if (c->merge_stream) (void)hipStreamDestroy(c->merge_stream);
     if (c->ev_layout_done) (void)hipEventDestroy(c->ev_layout_done);
     if (c->ev_merge_done) (void)hipEventDestroy(c->ev_merge_done);
+    if (c->ev_layouts_ready) (void)hipEventDestroy(c->ev_layouts_ready);
     c->point.release();
     c->drop_chem_grid();
     if (c->chem_k) (void)hipFree(c->chem_k);
@@ -801,6 +802,17 @@ int ftte_diffuse_sweep_device(ftte_ctx *c, int ndir, const double *phi, const do
                 if (c->acc[l][s]) { FTTE_HIP(c, hipFree(c->acc[l][s])); c->acc[l][s] = nullptr; }
         c->acc_cap = per_acc;
     }
+    // a second (non-blocking) stream: the transposed copies of the opacity are made there while the directions that march
+    // along storage-i (layout 0, the array as it was handed over) are already being swept, and later the merges run there
+    if (!c->merge_stream) {
+        FTTE_HIP(c, hipStreamCreateWithFlags(&c->merge_stream, hipStreamNonBlocking));
+        FTTE_HIP(c, hipEventCreateWithFlags(&c->ev_layout_done, hipEventDisableTiming));
+        FTTE_HIP(c, hipEventCreateWithFlags(&c->ev_merge_done, hipEventDisableTiming));
+        FTTE_HIP(c, hipEventCreateWithFlags(&c->ev_layouts_ready, hipEventDisableTiming));
+    }
+    // everything queued on `stream` so far (and the previous sweep's merges) comes first
+    FTTE_HIP(c, hipEventRecord(c->ev_layout_done, stream));
+    FTTE_HIP(c, hipStreamWaitEvent(c->merge_stream, c->ev_layout_done, 0));
     for (int l = 0; l < 3; ++l) {
         bool any = false;
         for (int s = 0; s < kMaxSlots; ++s) {
@@ -811,17 +823,19 @@ int ftte_diffuse_sweep_device(ftte_ctx *c, int ndir, const double *phi, const do
         // opacity in the layout this march axis needs
         if (any && !c->kappa_ready[l]) {
             if (!c->kappa[l]) FTTE_HIP(c, hipMalloc((void **)&c->kappa[l], sizeof(double) * c->kappa_cap));
-            if (launch_to_layout(l, c->kappa[0], c->kappa[l], n, nnu, (long)c->ncell, stream))
+            if (launch_to_layout(l, c->kappa[0], c->kappa[l], n, nnu, (long)c->ncell, c->merge_stream))
                 return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
             c->kappa_ready[l] = true;
         }
         if (any && c->emit_mode && !c->emis_ready[l]) {
             if (!c->emis[l]) FTTE_HIP(c, hipMalloc((void **)&c->emis[l], sizeof(double) * c->kappa_cap));
-            if (launch_to_layout(l, c->emis[0], c->emis[l], n, nnu, (long)c->ncell, stream))
+            if (launch_to_layout(l, c->emis[0], c->emis[l], n, nnu, (long)c->ncell, c->merge_stream))
                 return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
             c->emis_ready[l] = true;
         }
     }
+    FTTE_HIP(c, hipEventRecord(c->ev_layouts_ready, c->merge_stream));
+    bool layouts_awaited = false;
 
     // events for the launch records
     while (c->timing.size() < P.launches.size()) {
@@ -832,13 +846,6 @@ int ftte_diffuse_sweep_device(ftte_ctx *c, int ndir, const double *phi, const do
     }
     c->timing_used = 0;
 
-    if (!c->merge_stream) {
-        FTTE_HIP(c, hipStreamCreateWithFlags(&c->merge_stream, hipStreamNonBlocking));
-        FTTE_HIP(c, hipEventCreateWithFlags(&c->ev_layout_done, hipEventDisableTiming));
-        FTTE_HIP(c, hipEventCreateWithFlags(&c->ev_merge_done, hipEventDisableTiming));
-    }
-    // the previous sweep's J may still be being merged into the same buffer by an earlier call on another stream
-    FTTE_HIP(c, hipStreamWaitEvent(c->merge_stream, c->ev_merge_done, 0));
     bool merged_any = false;
     for (size_t li = 0; li < P.launches.size(); ++li) {
         const LaunchPlan &LP = P.launches[li];
@@ -868,6 +875,10 @@ int ftte_diffuse_sweep_device(ftte_ctx *c, int ndir, const double *phi, const do
         L.math = kMath;
         LaunchTiming &T = c->timing[li];
         T.updates = LP.updates * nnu;
+        if (LP.layout != 0 && !layouts_awaited) { // the first launch that reads a transposed copy
+            FTTE_HIP(c, hipStreamWaitEvent(stream, c->ev_layouts_ready, 0));
+            layouts_awaited = true;
+        }
         FTTE_HIP(c, hipEventRecord(T.start, stream));
         const int lrc = launch_sweep(L, rows, c->waves, stack, nnu, stream);
         if (lrc == -1)
