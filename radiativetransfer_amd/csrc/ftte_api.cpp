@@ -43,6 +43,7 @@ struct LaunchPlan {
     int layout = 0;
     bool first = false;
     std::vector<int> dirs; // indices into Plan::dirs, position = slot
+    int acc_base = 0;      // slot s of this launch accumulates into acc[layout][acc_base + s]
     size_t item_off = 0;
     int nitems = 0;
     int64_t updates = 0;
@@ -92,7 +93,7 @@ struct ftte_ctx {
     double *acc[3][kMaxSlots] = {};
     size_t acc_cap = 0; // elements per accumulator
 
-    int rows = 8, slots = 6, waves = 4, stack = 1;
+    int rows = 8, slots = 8, waves = 4, stack = 1;
 
     Plan plan;
     LayerRec *d_layers = nullptr; size_t d_layers_cap = 0;
@@ -281,6 +282,10 @@ int build_plan(ftte_ctx *c, int rows, int stack, int ndir, const double *phi, co
             LaunchPlan LP;
             LP.layout = layout;
             LP.first = (b == 0);
+            // a short last batch takes the highest accumulators: the lower ones are final one launch earlier and can be
+            // merged while it runs, without changing the order in which the accumulators are added up
+            const int in_batch = (int)(std::min(members.size(), b + (size_t)slots) - b);
+            LP.acc_base = (b > 0 && in_batch < slots) ? slots - in_batch : 0;
             LP.item_off = P.items.size();
             std::vector<uint32_t> where; // per item of this launch: the tile's place in the plane halfway through the march
             for (size_t s = b; s < std::min(members.size(), b + (size_t)slots); ++s) {
@@ -288,7 +293,7 @@ int build_plan(ftte_ctx *c, int rows, int stack, int ndir, const double *phi, co
                 const DirPlan &D = P.dirs[d];
                 const int slot = (int)(s - b);
                 LP.dirs.push_back(d);
-                P.used[layout][slot] = true;
+                P.used[layout][LP.acc_base + slot] = true;
                 const LayerRec *Ls = &P.layers[D.layer_off];
                 for (int tv = 0; tv < D.ntv; ++tv) {
                     for (int tu = 0; tu < D.ntu; ++tu) {
@@ -856,7 +861,7 @@ int ftte_diffuse_sweep_device(ftte_ctx *c, int ndir, const double *phi, const do
             DirRec &R = L.dir[s];
             R.layers = c->d_layers + D.layer_off;
             R.kappa = c->kappa[LP.layout];
-            R.J = c->acc[LP.layout][s];
+            R.J = c->acc[LP.layout][LP.acc_base + s];
             R.emis = c->emit_mode ? c->emis[LP.layout] : nullptr;
             R.org = D.org;
             R.si = D.si; R.sv = D.sv; R.su = D.su;
@@ -888,19 +893,27 @@ int ftte_diffuse_sweep_device(ftte_ctx *c, int ndir, const double *phi, const do
         FTTE_HIP(c, hipEventRecord(T.stop, stream));
         c->timing_used = (int)li + 1;
 
-        // last launch of a layout: J (+)= its accumulators, slots in order, layout 0 first -- the same sequence of
-        // additions as one merge over all of them.  It runs on a second stream beside the sweeps of the next layout, which
-        // leave the memory system some room (the last layout's merge has nothing to hide behind).
-        if (li + 1 == P.launches.size() || P.launches[li + 1].layout != LP.layout) {
+        // J (+)= the accumulators of this layout, slots in order, layout 0 first -- the same sequence of additions as one
+        // merge over all of them -- on the second stream, beside the sweeps that follow: the accumulators that the
+        // layout's (short) last launch does not touch as soon as the launch before it is done, the rest after the last one.
+        // Only the tail of the last layout's merge has nothing to hide behind.
+        const bool last_of_layout = li + 1 == P.launches.size() || P.launches[li + 1].layout != LP.layout;
+        const bool before_last = !last_of_layout && (li + 2 == P.launches.size() || P.launches[li + 2].layout != LP.layout);
+        int lo = -1, hi = -1; // accumulator range [lo, hi) to merge now
+        if (before_last && P.launches[li + 1].acc_base > 0) { lo = 0; hi = P.launches[li + 1].acc_base; }
+        if (last_of_layout) { lo = LP.acc_base; hi = kMaxSlots; }
+        if (lo >= 0) {
             const double *accs[kMaxSlots];
             int layouts[kMaxSlots], count = 0;
-            for (int s = 0; s < kMaxSlots; ++s)
+            for (int s = lo; s < hi; ++s)
                 if (P.used[LP.layout][s]) { accs[count] = c->acc[LP.layout][s]; layouts[count++] = LP.layout; }
-            FTTE_HIP(c, hipEventRecord(c->ev_layout_done, stream));
-            FTTE_HIP(c, hipStreamWaitEvent(c->merge_stream, c->ev_layout_done, 0));
-            if (launch_merge(accs, layouts, count, J_dev, n, nnu, (long)c->ncell, merged_any, c->merge_stream))
-                return fail(c, FTTE_ERR_NO_DEVICE, "merge kernel launch failed");
-            merged_any = true;
+            if (count) {
+                FTTE_HIP(c, hipEventRecord(c->ev_layout_done, stream));
+                FTTE_HIP(c, hipStreamWaitEvent(c->merge_stream, c->ev_layout_done, 0));
+                if (launch_merge(accs, layouts, count, J_dev, n, nnu, (long)c->ncell, merged_any, c->merge_stream))
+                    return fail(c, FTTE_ERR_NO_DEVICE, "merge kernel launch failed");
+                merged_any = true;
+            }
         }
     }
     if (!merged_any) FTTE_HIP(c, hipMemsetAsync(J_dev, 0, sizeof(double) * (size_t)nnu * c->ncell, stream)); // no directions
