@@ -245,6 +245,16 @@ module ftte_binding
        real(c_double), intent(out) :: gamma(3,3)   ! (gammaHI/HeI/HeII, group)
      end function ftte_uvb_beta_table
 
+     integer(c_int) function ftte_assign_uvb_radiation(ctx, nnu, uvb, self_shielding_threshold, J) &
+          bind(C, name='ftte_assign_uvb_radiation')
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: nnu
+       real(c_double), intent(in) :: uvb(*)
+       real(c_double), value :: self_shielding_threshold
+       real(c_double), intent(out) :: J(*)         ! (ncell, nnu)
+     end function ftte_assign_uvb_radiation
+
   end interface
 
 contains

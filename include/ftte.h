@@ -221,6 +221,11 @@ int ftte_get_medium(ftte_ctx *ctx, double *HI, double *HeI, double *HeII);
 /* computeOpacities (equiSources.f90:4956-4983) on the device-resident medium: kappa[g] = HI beta[0][g] + HeI beta[1][g] +
  * HeII beta[2][g]; equivalent to ftte_set_species with the medium's arrays, without the host round trip */
 int ftte_compute_opacities(ftte_ctx *ctx, int nnu, const double *beta);
+/* assignUvbRadiation(currentCell), transportRoutinesModule.f90:1056-1093: the optically thin alternative to the sweep (not called
+ * in the reference's loop): J[g][cell] = uvb[g] where the Lyman-limit mean free path 1/(min(HI, psi rho/mh) 6.3e-18 + HeI 7.42e-18 +
+ * HeII 1.58e-18) of the device-resident medium is at least the threshold, else 0.  J[nnu][ncell]. */
+int ftte_assign_uvb_radiation(ftte_ctx *ctx, int nnu, const double *uvb, double self_shielding_threshold, double *J);
+int ftte_assign_uvb_radiation_device(ftte_ctx *ctx, int nnu, const double *uvb, double self_shielding_threshold, double *J_dev);
 /* bisection steps of the last ftte_solve_rate_equations*, summed over the cells */
 long long ftte_rate_equation_steps(const ftte_ctx *ctx);
 

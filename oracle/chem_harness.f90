@@ -14,9 +14,11 @@
 !   real64 ksiIn(3,3)  ((ksi24, ksi25, ksi26) of group1..3) ; real64 uniform(3) (4 pi (uniformQuasar quasar%ksi + ...)
 !   per reaction, entered through quasar%ksi with uniformQuasar = 1/(4 pi)) ; real64 selfShieldingThreshold
 ! out.bin: real64 logtem0, logtem9, dlogtem ; real64 k1a..k6a (nratec each) ; real64 HI, HeI, HeII (ncell each)
+!          (runUVB = 2: assignUvbRadiation instead, with uvb1..3 = uniform(1:3); the last three arrays are Jmean1..3)
 program chem_harness
 
   use definitions
+  use transportRoutinesModule
   use chemExtract
 
   implicit none
@@ -86,6 +88,17 @@ program chem_harness
   ! ---- equiSources.f90:1811-1819
   icosmic = 0
   ncosmic = ncell
+  if (runUVB == 2) then
+     ! the optically thin alternative to the sweep, transportRoutinesModule.f90:1056-1093 (inflow = the case's uniform(1:3))
+     uvb1 = uni(1) ; uvb2 = uni(2) ; uvb3 = uni(3)
+     do bi = 1, n
+        do bj = 1, n
+           do bk = 1, n
+              call assignUvbRadiation(baseGrid%cell(bi,bj,bk))
+           enddo
+        enddo
+     enddo
+  else
   do bi = 1, n
      do bj = 1, n
         do bk = 1, n
@@ -93,6 +106,7 @@ program chem_harness
         enddo
      enddo
   enddo
+  endif
 
   cursor = 0
   do bi = 1, n
@@ -162,9 +176,13 @@ contains
        enddo
     else
        cursor = cursor + 1
+       if (runUVB == 2) then
+          outv(cursor,1) = c%Jmean1 ; outv(cursor,2) = c%Jmean2 ; outv(cursor,3) = c%Jmean3
+       else
        outv(cursor,1) = c%HI
        outv(cursor,2) = c%HeI
        outv(cursor,3) = c%HeII
+       endif
     endif
   end subroutine harvest
 

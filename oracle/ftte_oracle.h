@@ -133,6 +133,9 @@ long fo_solve_rate_equations(int n, long ncell, const int32_t *level, double box
 
 void fo_uvb_beta_table(int nfreq, double freqdel, const double *alpha, double *beta, double *ksi, double *gamma);
 
+void fo_assign_uvb_radiation(long ncell, int nnu, const double *HI, const double *HeI, const double *HeII, const double *rho,
+                             const double *uvb, double threshold, double *J);
+
 #ifdef __cplusplus
 }
 #endif

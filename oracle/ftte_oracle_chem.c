@@ -156,3 +156,15 @@ void fo_uvb_beta_table(int nfreq, double freqdel, const double *alpha, double *b
     for (int q = 0; q < 3; ++q)
         for (int r = 0; r < 3; ++r) beta[3 * q + r] = beta[3 * q + r] / (shape[q] * lo[q]);
 }
+
+/* assignUvbRadiation, transportRoutinesModule.f90:1056-1093.  J: [nnu][ncell]. */
+void fo_assign_uvb_radiation(long ncell, int nnu, const double *HI, const double *HeI, const double *HeII, const double *rho,
+                             const double *uvb, double threshold, double *J)
+{
+    const double psi = F(0.76), mh = F(1.6726231e-24);
+    for (long c = 0; c < ncell; ++c) {
+        const double hi = fmin(HI[c], psi * rho[c] / mh);
+        const double mfp = 1. / (hi * F(6.3e-18) + HeI[c] * F(7.42e-18) + HeII[c] * F(1.58e-18));
+        for (int g = 0; g < nnu; ++g) J[(size_t)g * ncell + c] = (mfp >= threshold) ? uvb[g] : 0.0;
+    }
+}

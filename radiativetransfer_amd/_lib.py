@@ -66,6 +66,8 @@ SIGNATURES = {
     "ftte_solve_rate_equations_device": (C.c_int, [_vp, C.c_int, _vp, _dp, _dp, C.c_double, C.c_int, _dp]),
     "ftte_get_medium": (C.c_int, [_vp, _dp, _dp, _dp]),
     "ftte_compute_opacities": (C.c_int, [_vp, C.c_int, _dp]),
+    "ftte_assign_uvb_radiation": (C.c_int, [_vp, C.c_int, _dp, C.c_double, _dp]),
+    "ftte_assign_uvb_radiation_device": (C.c_int, [_vp, C.c_int, _dp, C.c_double, _vp]),
     "ftte_rate_equation_steps": (C.c_longlong, [_vp]),
     "ftte_point_ray_steps": (C.c_longlong, [_vp]),
     "ftte_rmax": (C.c_int, [_dp]),

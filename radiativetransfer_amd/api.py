@@ -394,5 +394,12 @@ class StellarTransfer(DiffuseTransfer):
         self._ok(self._lib.ftte_compute_opacities(self._ctx, beta.shape[1], _dp(beta)))
         self.nnu = beta.shape[1]
 
+    def assign_uvb_radiation(self, uvb, threshold: float) -> np.ndarray:
+        """assignUvbRadiation (transportRoutinesModule.f90:1056): J[nnu][ncell] = uvb where the medium is not self-shielded."""
+        uvb = _f64(uvb)
+        J = np.empty((uvb.size, max(self.ncell, 1)))
+        self._ok(self._lib.ftte_assign_uvb_radiation(self._ctx, uvb.size, _dp(uvb), float(threshold), _dp(J)))
+        return J
+
     def rate_equation_steps(self) -> int:
         return int(self._lib.ftte_rate_equation_steps(self._ctx))

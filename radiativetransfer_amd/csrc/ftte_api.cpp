@@ -1299,6 +1299,42 @@ int ftte_compute_opacities(ftte_ctx *c, int nnu, const double *beta)
     return FTTE_OK;
 }
 
+static int assign_uvb(ftte_ctx *c, int nnu, const double *uvb, double threshold, double *J, bool J_on_device, const char *who)
+{
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (nnu < 1 || !uvb || !J) return fail(c, FTTE_ERR_ARG, std::string(who) + ": bad argument");
+    PointState &P = c->point;
+    if (!P.medium_ready || P.medium_cells != c->ncell || !P.rho_given)
+        return fail(c, FTTE_ERR_STATE, std::string(who) + ": no medium with density (ftte_set_medium with rho)");
+    FTTE_HIP(c, hipSetDevice(c->device));
+    const size_t nc = (size_t)c->ncell;
+    double *duvb = nullptr, *dJ = J_on_device ? J : nullptr;
+    FTTE_HIP(c, hipMalloc((void **)&duvb, sizeof(double) * nnu));
+    hipError_t e = hipSuccess;
+    if (!J_on_device) e = hipMalloc((void **)&dJ, sizeof(double) * nc * nnu);
+    if (e == hipSuccess) e = hipMemcpyAsync(duvb, uvb, sizeof(double) * nnu, hipMemcpyHostToDevice, c->stream);
+    int lrc = 0;
+    if (e == hipSuccess) lrc = launch_thin_limit(P.medium[0], P.medium[1], P.medium[2], P.medium[3], duvb, threshold, dJ, (long)nc, nnu, c->stream);
+    if (e == hipSuccess && !J_on_device) e = hipMemcpyAsync(J, dJ, sizeof(double) * nc * nnu, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(duvb);
+    if (!J_on_device && dJ) (void)hipFree(dJ);
+    if (e != hipSuccess) return fail(c, FTTE_ERR_NO_DEVICE, std::string(who) + ": " + hipGetErrorString(e));
+    if (lrc) return fail(c, FTTE_ERR_NO_DEVICE, std::string(who) + ": kernel launch failed");
+    return FTTE_OK;
+}
+
+int ftte_assign_uvb_radiation(ftte_ctx *c, int nnu, const double *uvb, double self_shielding_threshold, double *J)
+{
+    return assign_uvb(c, nnu, uvb, self_shielding_threshold, J, false, "ftte_assign_uvb_radiation");
+}
+
+int ftte_assign_uvb_radiation_device(ftte_ctx *c, int nnu, const double *uvb, double self_shielding_threshold, double *J_dev)
+{
+    return assign_uvb(c, nnu, uvb, self_shielding_threshold, J_dev, true, "ftte_assign_uvb_radiation_device");
+}
+
 long long ftte_rate_equation_steps(const ftte_ctx *c) { return c ? c->chem_steps : 0; }
 
 long long ftte_point_ray_steps(const ftte_ctx *c) { return c ? c->point.ray_steps : 0; }

@@ -33,5 +33,7 @@ int launch_repack_rates(double *planes, double *packed, long ncell, bool to_pack
 
 // ionisation equilibrium of every leaf (solveRateEquations)
 int launch_rate_equations(const ChemRec &R, hipStream_t stream);
+int launch_thin_limit(const double *HI, const double *HeI, const double *HeII, const double *rho, const double *uvb, double threshold,
+                      double *J, long ncell, int nnu, hipStream_t stream);
 
 } // namespace ftte

@@ -1109,6 +1109,30 @@ __global__ void __launch_bounds__(256) rate_equations_kernel(const ChemRec R)
     R.HI_out[c] = HI; R.HeI_out[c] = HeI; R.HeII_out[c] = HeII;
 }
 
+// assignUvbRadiation, transportRoutinesModule.f90:1056-1093: the optically thin alternative to the sweep.  J_g = uvb_g where the
+// Lyman-limit mean free path of the cell is at least the self-shielding threshold, else 0.
+__global__ void __launch_bounds__(256) thin_limit_kernel(const double *__restrict__ HI, const double *__restrict__ HeI,
+                                                         const double *__restrict__ HeII, const double *__restrict__ rho,
+                                                         const double *__restrict__ uvb, double threshold, double *__restrict__ J,
+                                                         long ncell, int nnu)
+{
+    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncell) return;
+    const double psi = (double)0.76f, mh = (double)1.6726231e-24f;
+    const double hi = fmin(HI[c], psi * rho[c] / mh);
+    const double mfp = 1. / (hi * (double)6.3e-18f + HeI[c] * (double)7.42e-18f + HeII[c] * (double)1.58e-18f);
+    const bool lit = mfp >= threshold;
+    for (int g = 0; g < nnu; ++g) J[(long)g * ncell + c] = lit ? uvb[g] : 0.0;
+}
+
+int launch_thin_limit(const double *HI, const double *HeI, const double *HeII, const double *rho, const double *uvb, double threshold,
+                      double *J, long ncell, int nnu, hipStream_t stream)
+{
+    hipLaunchKernelGGL(thin_limit_kernel, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, stream, HI, HeI, HeII, rho, uvb, threshold, J,
+                       ncell, nnu);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 int launch_rate_equations(const ChemRec &R, hipStream_t stream)
 {
     if (R.ncell <= 0) return 0;

@@ -281,3 +281,13 @@ def uvb_beta_table(alpha, nfreq=400, freqdel=float(np.float32(0.02))):
     lib().fo_uvb_beta_table.argtypes = [C.c_int, C.c_double, dp, dp, dp, dp]
     lib().fo_uvb_beta_table(nfreq, freqdel, _dp(alpha), *[_dp(a) for a in out])
     return out
+
+
+def assign_uvb_radiation(HI, HeI, HeII, rho, uvb, threshold):
+    HI, HeI, HeII, rho, uvb = map(_f64, (HI, HeI, HeII, rho, uvb))
+    J = np.empty((uvb.size, HI.size))
+    dp = C.POINTER(C.c_double)
+    lib().fo_assign_uvb_radiation.restype = None
+    lib().fo_assign_uvb_radiation.argtypes = [C.c_long, C.c_int, dp, dp, dp, dp, dp, C.c_double, dp]
+    lib().fo_assign_uvb_radiation(HI.size, uvb.size, _dp(HI), _dp(HeI), _dp(HeII), _dp(rho), _dp(uvb), float(threshold), _dp(J))
+    return J

@@ -97,6 +97,11 @@ def main():
     o = run_reference(n2, level2, box, rho, tgas, HI, HeI, HeII, np.zeros((3, n2 ** 3)), J, False, ksi, uniform, threshold)
     save("chem_uniform_background", n=n2, level=level2, box=box, rho=rho, tgas=tgas, HI=HI, HeI=HeI, HeII=HeII, uniform=uniform,
          threshold=threshold, HI_out=o["HI"], HeI_out=o["HeI"], HeII_out=o["HeII"])
+    # assignUvbRadiation (transportRoutinesModule.f90:1056-1093): the optically thin alternative to the sweep, same cells
+    uvb = np.array([1.0e-21, 4.0e-22, 1.0e-22])
+    o = run_reference(n2, level2, box, rho, tgas, HI, HeI, HeII, np.zeros((3, n2 ** 3)), J, 2, ksi, uvb, threshold)
+    save("thin_limit_uvb", n=n2, level=level2, box=box, rho=rho, HI=HI, HeI=HeI, HeII=HeII, uvb=uvb, threshold=threshold,
+         J=np.stack([o["HI"], o["HeI"], o["HeII"]]))
 
 
 if __name__ == "__main__":

@@ -177,3 +177,13 @@ def test_baseline_size_properties(golden):
                                  float(g["dlogtem"]), g["k"])
     assert ref[3] == 0
     assert np.array_equal(HI[pick], ref[0]) and np.array_equal(HeI[pick], ref[1]) and np.array_equal(HeII[pick], ref[2])
+
+
+def test_assign_uvb_radiation_against_reference(stellar, golden):
+    g = golden("thin_limit_uvb")
+    stellar.set_grid(int(g["n"]), g["level"], float(g["box"]))
+    stellar.set_medium(g["HI"], g["HeI"], g["HeII"], g["rho"], None, 0)
+    J = stellar.assign_uvb_radiation(g["uvb"], float(g["threshold"]))
+    assert np.array_equal(J, g["J"])
+    J5 = stellar.assign_uvb_radiation(np.arange(1, 6) * 1e-22, float(g["threshold"]))   # any number of groups
+    assert J5.shape[0] == 5 and np.array_equal(J5[4] > 0, g["J"][0] > 0)

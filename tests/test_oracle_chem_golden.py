@@ -51,3 +51,9 @@ def test_uvb_beta_table_bitwise(golden):
     for a, beta, ksi, gamma in zip(g["alpha"], g["beta"], g["ksi"], g["gamma"]):
         mine = O.uvb_beta_table(a)
         assert np.array_equal(mine[0], beta) and np.array_equal(mine[1], ksi) and np.array_equal(mine[2], gamma), a
+
+
+def test_assign_uvb_radiation_bitwise(golden):
+    g = golden("thin_limit_uvb")
+    J = O.assign_uvb_radiation(g["HI"], g["HeI"], g["HeII"], g["rho"], g["uvb"], float(g["threshold"]))
+    assert np.array_equal(J, g["J"]) and 0 < (J[0] > 0).mean() < 1
