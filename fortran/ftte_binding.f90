@@ -255,6 +255,14 @@ module ftte_binding
        real(c_double), intent(out) :: J(*)         ! (ncell, nnu)
      end function ftte_assign_uvb_radiation
 
+     integer(c_int) function ftte_uniform_table(nfreq, freqdel, alpha_quasar, alpha_stellar, ksi, gamma) &
+          bind(C, name='ftte_uniform_table')
+       import :: c_int, c_double
+       integer(c_int), value :: nfreq
+       real(c_double), value :: freqdel, alpha_quasar, alpha_stellar
+       real(c_double), intent(out) :: ksi(3,2), gamma(3,2)   ! (24/25/26 or HI/HeI/HeII, quasar/stellar)
+     end function ftte_uniform_table
+
   end interface
 
 contains

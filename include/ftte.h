@@ -186,6 +186,10 @@ int ftte_rmax(double *rmax30);
  * gamma[3][3] = [group][gammaHI, gammaHeI, gammaHeII].  The reference calls it with nfbins = 400, frequencyBinWidth = 0.02
  * (equiSources.f90:253). */
 int ftte_uvb_beta_table(int nfreq, double freqdel, const double *alpha, double *beta, double *ksi, double *gamma);
+/* uniformTable(nfreq, freqdel, alphaQuasar, alphaStellar), uniformTable.f90:1-200 (host): the two power-law components of the
+ * uniform background.  ksi[2][3] = [quasar, stellar][ksi24, ksi25, ksi26], gamma[2][3] = [quasar, stellar][gammaHI, gammaHeI,
+ * gammaHeII]; uniformQuasar*ksi[0][x] + uniformStellar*ksi[1][x] is the `uniform` argument of ftte_solve_rate_equations. */
+int ftte_uniform_table(int nfreq, double freqdel, double alpha_quasar, double alpha_stellar, double *ksi, double *gamma);
 /* dustCrossSection(lambda [micron]), dustModule.f90:30-73, SMC curve; a_smc(7,5) Fortran order */
 double ftte_dust_cross_section(double lambda_micron, const double *a_smc);
 

@@ -136,6 +136,8 @@ void fo_uvb_beta_table(int nfreq, double freqdel, const double *alpha, double *b
 void fo_assign_uvb_radiation(long ncell, int nnu, const double *HI, const double *HeI, const double *HeII, const double *rho,
                              const double *uvb, double threshold, double *J);
 
+void fo_uniform_table(int nfreq, double freqdel, double alpha_quasar, double alpha_stellar, double *ksi, double *gamma);
+
 #ifdef __cplusplus
 }
 #endif

@@ -168,3 +168,42 @@ void fo_assign_uvb_radiation(long ncell, int nnu, const double *HI, const double
         for (int g = 0; g < nnu; ++g) J[(size_t)g * ncell + c] = (mfp >= threshold) ? uvb[g] : 0.0;
     }
 }
+
+/* uniformTable, uniformTable.f90:1-200.  ksi[2][3] (quasar, stellar) x (24, 25, 26); gamma[2][3] x (HI, HeI, HeII). */
+void fo_uniform_table(int nfreq, double freqdel, double alpha_quasar, double alpha_stellar, double *ksi, double *gamma)
+{
+    const double nu1 = F(13.598), nu2 = F(24.587), nu3 = F(54.418), pi = F(3.141592654);
+    const double ev_to_erg = 1.60217646e-12, ev_to_hz = ev_to_erg / F(6.6260693e-27);
+    const double alpha[2] = {alpha_quasar, alpha_stellar};
+    for (int q = 0; q < 6; ++q) ksi[q] = gamma[q] = 0.0;
+    double prev = 0.0;
+    for (int i = 0; i < nfreq; ++i) {
+        const double nu = pow(10.0, (double)i * freqdel);
+        double s24 = 0.0, s25 = 0.0, s26 = 0.0;
+        if (nu > nu1) {
+            const double dum = sqrt(nu / nu1 - 1), r = nu1 / nu;
+            s24 = F(6.3e-18) * (r * r * r * r) * exp(4.0 - 4.0 * atan(dum) / dum) / (1 - exp(-2.0 * pi / dum));
+        }
+        if (nu > nu3) {
+            const double dum = sqrt(nu / nu3 - 1), r = nu3 / nu;
+            s25 = F(1.58e-18) * (r * r * r * r) * exp(4.0 - 4.0 * atan(dum) / dum) / (1 - exp(-2.0 * pi / dum));
+        }
+        if (nu > nu2) s26 = F(7.42e-18) * (F(1.66) * pow(nu / nu2, (double)(-2.05f)) - F(0.66) * pow(nu / nu2, (double)(-3.05f)));
+        if (i >= 1) {
+            const double delta_nu = nu - prev;
+            for (int c = 0; c < 2; ++c) {
+                const double dtmp = pow(nu / nu1, -alpha[c]) * delta_nu;
+                const double over = dtmp * ev_to_hz / (nu * ev_to_erg);
+                if (nu >= nu1) {
+                    ksi[3 * c + 0] = ksi[3 * c + 0] + over * s24;
+                    ksi[3 * c + 1] = ksi[3 * c + 1] + over * s25;
+                    ksi[3 * c + 2] = ksi[3 * c + 2] + over * s26;
+                    gamma[3 * c + 0] = gamma[3 * c + 0] + over * (nu - nu1) * ev_to_erg * s24;
+                }
+                if (nu >= nu2) gamma[3 * c + 1] = gamma[3 * c + 1] + over * (nu - nu2) * ev_to_erg * s26;
+                if (nu >= nu3) gamma[3 * c + 2] = gamma[3 * c + 2] + over * (nu - nu3) * ev_to_erg * s25;
+            }
+        }
+        prev = nu;
+    }
+}

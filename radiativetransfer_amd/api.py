@@ -16,7 +16,7 @@ import numpy as np
 from . import _lib
 from ._lib import FtteError, Pattern
 
-__all__ = ["DiffuseTransfer", "StellarTransfer", "rmax", "dust_cross_section", "uvb_beta_table", "FtteError", "Pattern", "pix2ang_nest", "healpix_directions", "fold_direction",
+__all__ = ["DiffuseTransfer", "StellarTransfer", "rmax", "dust_cross_section", "uvb_beta_table", "uniform_table", "FtteError", "Pattern", "pix2ang_nest", "healpix_directions", "fold_direction",
            "rotate_indices", "set_pattern", "layer_patterns", "compute_cell_intensity"]
 
 
@@ -231,6 +231,14 @@ def uvb_beta_table(alpha, nfreq: int = 400, freqdel: Optional[float] = None):
     _check(_lib.load().ftte_uvb_beta_table(int(nfreq), float(np.float32(0.02)) if freqdel is None else float(freqdel), _dp(alpha),
                                            _dp(beta), _dp(ksi), _dp(gamma)), "ftte_uvb_beta_table")
     return beta, ksi, gamma
+
+
+def uniform_table(alpha_quasar: float, alpha_stellar: float, nfreq: int = 400, freqdel: Optional[float] = None):
+    """uniformTable (uniformTable.f90): (ksi[2][3], gamma[2][3]) of the quasar and the stellar power-law component."""
+    ksi, gamma = np.empty((2, 3)), np.empty((2, 3))
+    _check(_lib.load().ftte_uniform_table(int(nfreq), float(np.float32(0.02)) if freqdel is None else float(freqdel), float(alpha_quasar),
+                                          float(alpha_stellar), _dp(ksi), _dp(gamma)), "ftte_uniform_table")
+    return ksi, gamma
 
 
 def dust_cross_section(lambda_micron: float, a_smc) -> float:

@@ -1353,6 +1353,13 @@ int ftte_uvb_beta_table(int nfreq, double freqdel, const double *alpha, double *
     return FTTE_OK;
 }
 
+int ftte_uniform_table(int nfreq, double freqdel, double alpha_quasar, double alpha_stellar, double *ksi, double *gamma)
+{
+    if (nfreq < 2 || !(freqdel > 0.0) || !ksi || !gamma) return FTTE_ERR_ARG;
+    uniform_table(nfreq, freqdel, alpha_quasar, alpha_stellar, ksi, gamma);
+    return FTTE_OK;
+}
+
 double ftte_dust_cross_section(double lambda_micron, const double *a_smc)
 {
     return dust_cross_section(lambda_micron, a_smc);

@@ -153,6 +153,37 @@ void uvb_beta_table(int nfreq, double freqdel, const double *alpha, double *beta
     }
 }
 
+void uniform_table(int nfreq, double freqdel, double alpha_quasar, double alpha_stellar, double *ksi, double *gamma)
+{
+    const double nu1 = kHydrogen, nu2 = kHeI, nu3 = kHeII;
+    const double alpha[2] = {alpha_quasar, alpha_stellar};
+    for (int q = 0; q < 6; ++q) ksi[q] = gamma[q] = 0.0;
+    double prev = 0.0;
+    for (int i = 0; i < nfreq; ++i) {
+        const double nu = std::pow(10.0, (double)i * freqdel);
+        const double s24 = nu > kHydrogen ? hydrogenic(W(6.3e-18), kHydrogen, nu) : 0.0;
+        const double s25 = nu > kHeII ? hydrogenic(W(1.58e-18), kHeII, nu) : 0.0;
+        const double s26 = nu > kHeI ? W(7.42e-18) * (W(1.66) * std::pow(nu / kHeI, (double)(-2.05f)) - W(0.66) * std::pow(nu / kHeI, (double)(-3.05f)))
+                                     : 0.0;
+        if (i >= 1) { // uniformTable.f90:136-190
+            const double delta_nu = nu - prev;
+            for (int c = 0; c < 2; ++c) {
+                const double dtmp = std::pow(nu / nu1, -alpha[c]) * delta_nu;
+                const double over = dtmp * ev_to_hz() / (nu * ev_to_erg());
+                if (nu >= nu1) {
+                    ksi[3 * c + 0] = ksi[3 * c + 0] + over * s24;
+                    ksi[3 * c + 1] = ksi[3 * c + 1] + over * s25;
+                    ksi[3 * c + 2] = ksi[3 * c + 2] + over * s26;
+                    gamma[3 * c + 0] = gamma[3 * c + 0] + over * (nu - nu1) * ev_to_erg() * s24;
+                }
+                if (nu >= nu2) gamma[3 * c + 1] = gamma[3 * c + 1] + over * (nu - nu2) * ev_to_erg() * s26;
+                if (nu >= nu3) gamma[3 * c + 2] = gamma[3 * c + 2] + over * (nu - nu3) * ev_to_erg() * s25;
+            }
+        }
+        prev = nu;
+    }
+}
+
 void rmax_table(double *rmax30)
 {
     for (int ir = 1; ir <= 30; ++ir) {

@@ -63,6 +63,9 @@ double stellar_population(const double *spec, int nmetal, int nspectrum, int nwa
 // uvbBetaTable(nfreq, freqdel, alpha), uvbBetaTable.f90:3-305: group-averaged cross-sections beta[species HI, HeI, HeII][group],
 // photo-rate coefficients ksi[group][24, 25, 26] and heating coefficients gamma[group][HI, HeI, HeII] of the three frequency groups
 void uvb_beta_table(int nfreq, double freqdel, const double *alpha, double *beta, double *ksi, double *gamma);
+// uniformTable(nfreq, freqdel, alphaQuasar, alphaStellar), uniformTable.f90:1-200: ksi[component quasar, stellar][24, 25, 26] and
+// gamma[component][HI, HeI, HeII] of the two power-law components of the uniform background
+void uniform_table(int nfreq, double freqdel, double alpha_quasar, double alpha_stellar, double *ksi, double *gamma);
 // rmax(1:30), equiSources.f90:296-309
 void rmax_table(double *rmax30);
 

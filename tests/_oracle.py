@@ -291,3 +291,13 @@ def assign_uvb_radiation(HI, HeI, HeII, rho, uvb, threshold):
     lib().fo_assign_uvb_radiation.argtypes = [C.c_long, C.c_int, dp, dp, dp, dp, dp, C.c_double, dp]
     lib().fo_assign_uvb_radiation(HI.size, uvb.size, _dp(HI), _dp(HeI), _dp(HeII), _dp(rho), _dp(uvb), float(threshold), _dp(J))
     return J
+
+
+def uniform_table(alpha_quasar, alpha_stellar, nfreq=400, freqdel=float(np.float32(0.02))):
+    """fo_uniform_table: (ksi[2][3], gamma[2][3]) for the quasar and stellar components."""
+    ksi, gamma = np.empty((2, 3)), np.empty((2, 3))
+    dp = C.POINTER(C.c_double)
+    lib().fo_uniform_table.restype = None
+    lib().fo_uniform_table.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, dp, dp]
+    lib().fo_uniform_table(nfreq, freqdel, float(alpha_quasar), float(alpha_stellar), _dp(ksi), _dp(gamma))
+    return ksi, gamma

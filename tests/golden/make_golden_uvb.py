@@ -17,16 +17,19 @@ def main():
     if not os.path.exists(HARNESS):
         sys.exit("build oracle/_ref/uvb_harness first: make -C oracle ref")
     alphas = np.array([[1.8, 1.5, 1.2], [5.0, 5.0, 5.0], [0.5, 2.25, 1.75], [1.5, 1.5, 1.5]])
-    out = []
+    out, uni = [], []
     with tempfile.TemporaryDirectory() as tmp:
         for a in alphas:
             path = os.path.join(tmp, "o.bin")
             res = subprocess.run([HARNESS, repr(float(a[0])), repr(float(a[1])), repr(float(a[2])), path], capture_output=True, text=True)
             if res.returncode != 0:
                 raise RuntimeError(res.stdout + res.stderr)
-            out.append(np.fromfile(path, dtype="<f8").reshape(3, 3, 3))   # [beta|ksi|gamma][group][24,25,26 | HI,HeI,HeII]
-    out = np.array(out)
-    np.savez_compressed(os.path.join(HERE, "uvb_beta_table.npz"), alpha=alphas, beta=out[:, 0], ksi=out[:, 1], gamma=out[:, 2])
+            raw = np.fromfile(path, dtype="<f8")
+            out.append(raw[:27].reshape(3, 3, 3))   # [beta|ksi|gamma][group][24,25,26 | HI,HeI,HeII]
+            uni.append(raw[27:].reshape(2, 2, 3))   # uniformTable(alpha1, alpha2): [ksi|gamma][quasar, stellar][3]
+    out, uni = np.array(out), np.array(uni)
+    np.savez_compressed(os.path.join(HERE, "uvb_beta_table.npz"), alpha=alphas, beta=out[:, 0], ksi=out[:, 1], gamma=out[:, 2],
+                        uniform_ksi=uni[:, 0], uniform_gamma=uni[:, 1])
     print("uvb_beta_table:", out.shape)
 
 

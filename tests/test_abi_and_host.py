@@ -158,3 +158,6 @@ def test_uvb_beta_table_of_the_product_matches_reference_vectors(rt, golden):
         # the library hands beta over as [species HI, HeI, HeII][group]; the reference's fields are (24, 25, 26) per group
         assert np.array_equal(b[0], beta[:, 0]) and np.array_equal(b[1], beta[:, 2]) and np.array_equal(b[2], beta[:, 1])
         assert np.array_equal(k, ksi) and np.array_equal(h, gamma)
+    for a, ksi, gamma in zip(g["alpha"], g["uniform_ksi"], g["uniform_gamma"]):   # ftte_uniform_table vs uniformTable(alpha1, alpha2)
+        k, h = rt.uniform_table(a[0], a[1])
+        assert np.array_equal(k, ksi) and np.array_equal(h, gamma)

@@ -51,6 +51,9 @@ def test_uvb_beta_table_bitwise(golden):
     for a, beta, ksi, gamma in zip(g["alpha"], g["beta"], g["ksi"], g["gamma"]):
         mine = O.uvb_beta_table(a)
         assert np.array_equal(mine[0], beta) and np.array_equal(mine[1], ksi) and np.array_equal(mine[2], gamma), a
+    for a, ksi, gamma in zip(g["alpha"], g["uniform_ksi"], g["uniform_gamma"]):   # uniformTable(alpha1, alpha2)
+        mine = O.uniform_table(a[0], a[1])
+        assert np.array_equal(mine[0], ksi) and np.array_equal(mine[1], gamma), a
 
 
 def test_assign_uvb_radiation_bitwise(golden):
