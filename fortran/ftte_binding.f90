@@ -263,6 +263,15 @@ module ftte_binding
        real(c_double), intent(out) :: ksi(3,2), gamma(3,2)   ! (24/25/26 or HI/HeI/HeII, quasar/stellar)
      end function ftte_uniform_table
 
+     integer(c_int) function ftte_rate_coefficient_tables(nratec, temstart, temend, recombination_type, k, logtem0, logtem9, dlogtem) &
+          bind(C, name='ftte_rate_coefficient_tables')
+       import :: c_int, c_double
+       integer(c_int), value :: nratec, recombination_type
+       real(c_double), value :: temstart, temend
+       real(c_double), intent(out) :: k(*)         ! (nratec, 6): k1a..k6a
+       real(c_double), intent(out) :: logtem0, logtem9, dlogtem
+     end function ftte_rate_coefficient_tables
+
   end interface
 
 contains

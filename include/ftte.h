@@ -186,6 +186,13 @@ int ftte_rmax(double *rmax30);
  * gamma[3][3] = [group][gammaHI, gammaHeI, gammaHeII].  The reference calls it with nfbins = 400, frequencyBinWidth = 0.02
  * (equiSources.f90:253). */
 int ftte_uvb_beta_table(int nfreq, double freqdel, const double *alpha, double *beta, double *ksi, double *gamma);
+/* coll_rates(T, k1, ..., k19, recombinationType), coll_rates.f:42-150 (host): the six rate coefficients the equilibrium uses,
+ * k[6] = k1..k6 [cm^3/s]; recombination_type 1 = case A, 2 = case B (the reference's setting, definitionsModule.f90:48) */
+int ftte_coll_rates(double T, int recombination_type, double *k);
+/* k1a..k6a(nratec) as calc_rates.f:324-337 fills them, k[6][nratec], and logtem0, logtem9, dlogtem of equiSources.f90:174-176:
+ * what ftte_set_rate_coefficients takes (the reference: nratec = 5000, temstart = 1., temend = 1.e8) */
+int ftte_rate_coefficient_tables(int nratec, double temstart, double temend, int recombination_type, double *k, double *logtem0,
+                                 double *logtem9, double *dlogtem);
 /* uniformTable(nfreq, freqdel, alphaQuasar, alphaStellar), uniformTable.f90:1-200 (host): the two power-law components of the
  * uniform background.  ksi[2][3] = [quasar, stellar][ksi24, ksi25, ksi26], gamma[2][3] = [quasar, stellar][gammaHI, gammaHeI,
  * gammaHeII]; uniformQuasar*ksi[0][x] + uniformStellar*ksi[1][x] is the `uniform` argument of ftte_solve_rate_equations. */

@@ -138,6 +138,10 @@ void fo_assign_uvb_radiation(long ncell, int nnu, const double *HI, const double
 
 void fo_uniform_table(int nfreq, double freqdel, double alpha_quasar, double alpha_stellar, double *ksi, double *gamma);
 
+void fo_coll_rates(double T, int recombination_type, double *k);
+void fo_rate_coefficient_tables(int nratec, double temstart, double temend, int recombination_type, double *k, double *logtem0,
+                                double *logtem9, double *dlogtem);
+
 #ifdef __cplusplus
 }
 #endif

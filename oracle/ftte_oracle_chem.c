@@ -207,3 +207,64 @@ void fo_uniform_table(int nfreq, double freqdel, double alpha_quasar, double alp
         prev = nu;
     }
 }
+
+/* coll_rates (coll_rates.f:42-150): the six rate coefficients the equilibrium uses.  Fixed-form literals without a `d`
+ * exponent are single precision; integer powers are products taken from the left.  recombination_type 1 = case A, 2 = case B. */
+static double powi_left(double x, int n) { double r = x; for (int i = 1; i < n; ++i) r = r * x; return r; }
+
+void fo_coll_rates(double T, int recombination_type, double *k /* [6] */)
+{
+    const double T_eV = T / F(11605.);
+    const double L = log(T_eV);
+    if (T_eV > F(0.8)) {
+        k[0] = exp(F(-32.71396786375) + F(13.53655609057) * L - F(5.739328757388) * powi_left(L, 2) + F(1.563154982022) * powi_left(L, 3) -
+                   F(0.2877056004391) * powi_left(L, 4) + F(0.03482559773736999) * powi_left(L, 5) - F(0.00263197617559) * powi_left(L, 6) +
+                   F(0.0001119543953861) * powi_left(L, 7) - F(2.039149852002e-6) * powi_left(L, 8));
+        k[2] = exp(F(-44.09864886561001) + F(23.91596563469) * L - F(10.75323019821) * powi_left(L, 2) + F(3.058038757198) * powi_left(L, 3) -
+                   F(0.5685118909884001) * powi_left(L, 4) + F(0.06795391233790001) * powi_left(L, 5) -
+                   F(0.005009056101857001) * powi_left(L, 6) + F(0.0002067236157507) * powi_left(L, 7) -
+                   F(3.649161410833e-6) * powi_left(L, 8));
+        k[4] = exp(F(-68.71040990212001) + F(43.93347632635) * L - F(18.48066993568) * powi_left(L, 2) + F(4.701626486759002) * powi_left(L, 3) -
+                   F(0.7692466334492) * powi_left(L, 4) + F(0.08113042097303) * powi_left(L, 5) - F(0.005324020628287001) * powi_left(L, 6) +
+                   F(0.0001975705312221) * powi_left(L, 7) - F(3.165581065665e-6) * powi_left(L, 8));
+    } else {
+        k[0] = F(1.0e-20); k[2] = F(1.0e-20); k[4] = F(1.0e-20);
+    }
+    const double kb = 1.3806503e-16, ev = 1.60217646e-12;
+    if (recombination_type == 1) {
+        if (T_eV > F(0.8))
+            k[3] = F(1.54e-9) * (1. + F(0.3) / exp(F(8.099328789667) / T_eV)) / (exp(F(40.49664394833662) / T_eV) * pow(T_eV, F(1.5))) +
+                   F(3.92e-13) / pow(T_eV, F(0.6353));
+        else k[3] = F(3.92e-13) / pow(T_eV, F(0.6353));
+        if (T > F(5500.0))
+            k[1] = exp(F(-28.61303380689232) - F(0.7241125657826851) * L - F(0.02026044731984691) * powi_left(L, 2) -
+                       F(0.002380861877349834) * powi_left(L, 3) - F(0.0003212605213188796) * powi_left(L, 4) -
+                       F(0.00001421502914054107) * powi_left(L, 5) + F(4.989108920299513e-6) * powi_left(L, 6) +
+                       F(5.755614137575758e-7) * powi_left(L, 7) - F(1.856767039775261e-8) * powi_left(L, 8) -
+                       F(3.071135243196595e-9) * powi_left(L, 9));
+        else k[1] = k[3];
+        k[5] = F(3.36e-10) / sqrt(T) / pow(T / F(1.e3), F(0.2)) / (1. + pow(T / F(1.e6), F(0.7)));
+    } else {
+        double tmp = (double)(2.f * 24.587f) * ev / (kb * T);
+        k[3] = F(1.26e-14) * (sqrt(tmp) * sqrt(sqrt(tmp))); /* tmp**0.750 as the reference's compiler forms it */
+        tmp = (double)(2.f * 13.598f) * ev / (kb * T);
+        k[1] = F(2.753e-14) * pow(tmp, F(1.500)) / pow(1. + pow(tmp / F(2.740), F(0.407)), F(2.242));
+        tmp = (double)(2.f * 54.418f) * ev / (kb * T);
+        k[5] = (double)(2.f * 2.753e-14f) * pow(tmp, F(1.500)) / pow(1. + pow(tmp / F(2.740), F(0.407)), F(2.242));
+    }
+}
+
+/* the table loop of calc_rates.f:324-337 with the bounds of equiSources.f90:174-176: k[6][nratec] */
+void fo_rate_coefficient_tables(int nratec, double temstart, double temend, int recombination_type, double *k, double *logtem0,
+                                double *logtem9, double *dlogtem)
+{
+    *logtem0 = log(temstart);
+    *logtem9 = log(temend);
+    *dlogtem = (log(temend) - log(temstart)) / (double)(float)(nratec - 1);
+    for (int i = 1; i <= nratec; ++i) {
+        const double ttt = exp(log(temstart) + (double)(float)(i - 1) * *dlogtem);
+        double six[6];
+        fo_coll_rates(ttt, recombination_type, six);
+        for (int r = 0; r < 6; ++r) k[(size_t)r * nratec + (i - 1)] = six[r];
+    }
+}

@@ -5,4 +5,4 @@ include/ftte.h).  Importing it never compiles anything and never substitutes a C
 """
 from . import cellarray, synthetic  # noqa: F401
 from .api import (DiffuseTransfer, StellarTransfer, FtteError, Pattern, compute_cell_intensity, fold_direction,  # noqa: F401
-                  healpix_directions, layer_patterns, pix2ang_nest, rotate_indices, set_pattern, rmax, dust_cross_section, uvb_beta_table, uniform_table)
+                  healpix_directions, layer_patterns, pix2ang_nest, rotate_indices, set_pattern, rmax, dust_cross_section, uvb_beta_table, uniform_table, coll_rates, rate_coefficient_tables)

@@ -72,6 +72,8 @@ SIGNATURES = {
     "ftte_point_ray_steps": (C.c_longlong, [_vp]),
     "ftte_rmax": (C.c_int, [_dp]),
     "ftte_uvb_beta_table": (C.c_int, [C.c_int, C.c_double, _dp, _dp, _dp, _dp]),
+    "ftte_coll_rates": (C.c_int, [C.c_double, C.c_int, _dp]),
+    "ftte_rate_coefficient_tables": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_int, _dp, _dp, _dp, _dp]),
     "ftte_uniform_table": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_double, _dp, _dp]),
     "ftte_dust_cross_section": (C.c_double, [C.c_double, _dp]),
     "ftte_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),

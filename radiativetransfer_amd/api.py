@@ -16,7 +16,7 @@ import numpy as np
 from . import _lib
 from ._lib import FtteError, Pattern
 
-__all__ = ["DiffuseTransfer", "StellarTransfer", "rmax", "dust_cross_section", "uvb_beta_table", "uniform_table", "FtteError", "Pattern", "pix2ang_nest", "healpix_directions", "fold_direction",
+__all__ = ["DiffuseTransfer", "StellarTransfer", "rmax", "dust_cross_section", "uvb_beta_table", "uniform_table", "coll_rates", "rate_coefficient_tables", "FtteError", "Pattern", "pix2ang_nest", "healpix_directions", "fold_direction",
            "rotate_indices", "set_pattern", "layer_patterns", "compute_cell_intensity"]
 
 
@@ -231,6 +231,25 @@ def uvb_beta_table(alpha, nfreq: int = 400, freqdel: Optional[float] = None):
     _check(_lib.load().ftte_uvb_beta_table(int(nfreq), float(np.float32(0.02)) if freqdel is None else float(freqdel), _dp(alpha),
                                            _dp(beta), _dp(ksi), _dp(gamma)), "ftte_uvb_beta_table")
     return beta, ksi, gamma
+
+
+def coll_rates(T: float, recombination_type: int = 2) -> np.ndarray:
+    """coll_rates (coll_rates.f): k1..k6 at temperature T; recombination_type 1 = case A, 2 = case B."""
+    k = np.empty(6)
+    _check(_lib.load().ftte_coll_rates(float(T), int(recombination_type), _dp(k)), "ftte_coll_rates")
+    return k
+
+
+def rate_coefficient_tables(nratec: int = 5000, temstart: float = 1.0, temend: Optional[float] = None, recombination_type: int = 2):
+    """k1a..k6a as the reference's driver tabulates them (calc_rates.f:324-337): returns (k[6][nratec], logtem0, logtem9, dlogtem),
+    the arguments of StellarTransfer.set_rate_coefficients.  Defaults: the reference's nratec, temstart, temend = 1.e8 (a default-real
+    literal), case B."""
+    temend = float(np.float32(1.0e8)) if temend is None else float(temend)
+    k = np.empty((6, nratec))
+    a, b, c = C.c_double(), C.c_double(), C.c_double()
+    _check(_lib.load().ftte_rate_coefficient_tables(int(nratec), float(temstart), temend, int(recombination_type), _dp(k), C.byref(a),
+                                                    C.byref(b), C.byref(c)), "ftte_rate_coefficient_tables")
+    return k, a.value, b.value, c.value
 
 
 def uniform_table(alpha_quasar: float, alpha_stellar: float, nfreq: int = 400, freqdel: Optional[float] = None):

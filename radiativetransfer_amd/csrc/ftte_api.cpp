@@ -1353,6 +1353,23 @@ int ftte_uvb_beta_table(int nfreq, double freqdel, const double *alpha, double *
     return FTTE_OK;
 }
 
+int ftte_coll_rates(double T, int recombination_type, double *k)
+{
+    if (!(T > 0.0) || (recombination_type != 1 && recombination_type != 2) || !k) return FTTE_ERR_ARG;
+    coll_rates(T, recombination_type, k);
+    return FTTE_OK;
+}
+
+int ftte_rate_coefficient_tables(int nratec, double temstart, double temend, int recombination_type, double *k, double *logtem0,
+                                 double *logtem9, double *dlogtem)
+{
+    if (nratec < 2 || !(temstart > 0.0) || !(temend > temstart) || (recombination_type != 1 && recombination_type != 2) || !k || !logtem0 ||
+        !logtem9 || !dlogtem)
+        return FTTE_ERR_ARG;
+    rate_coefficient_tables(nratec, temstart, temend, recombination_type, k, logtem0, logtem9, dlogtem);
+    return FTTE_OK;
+}
+
 int ftte_uniform_table(int nfreq, double freqdel, double alpha_quasar, double alpha_stellar, double *ksi, double *gamma)
 {
     if (nfreq < 2 || !(freqdel > 0.0) || !ksi || !gamma) return FTTE_ERR_ARG;

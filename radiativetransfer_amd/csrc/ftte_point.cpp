@@ -184,6 +184,72 @@ void uniform_table(int nfreq, double freqdel, double alpha_quasar, double alpha_
     }
 }
 
+namespace {
+inline double powi_left(double x, int n)
+{
+    double r = x;
+    for (int i = 1; i < n; ++i) r = r * x;
+    return r;
+}
+} // namespace
+
+void coll_rates(double T, int recombination_type, double *k)
+{
+    // coll_rates.f:62-150 (fits of Abel et al. 1997 and Hui & Gnedin 1997); its literals are single precision
+    const double T_eV = T / W(11605.);
+    const double L = std::log(T_eV);
+    if (T_eV > W(0.8)) {
+        k[0] = std::exp(W(-32.71396786375) + W(13.53655609057) * L - W(5.739328757388) * powi_left(L, 2) + W(1.563154982022) * powi_left(L, 3) -
+                        W(0.2877056004391) * powi_left(L, 4) + W(0.03482559773736999) * powi_left(L, 5) - W(0.00263197617559) * powi_left(L, 6) +
+                        W(0.0001119543953861) * powi_left(L, 7) - W(2.039149852002e-6) * powi_left(L, 8));
+        k[2] = std::exp(W(-44.09864886561001) + W(23.91596563469) * L - W(10.75323019821) * powi_left(L, 2) + W(3.058038757198) * powi_left(L, 3) -
+                        W(0.5685118909884001) * powi_left(L, 4) + W(0.06795391233790001) * powi_left(L, 5) -
+                        W(0.005009056101857001) * powi_left(L, 6) + W(0.0002067236157507) * powi_left(L, 7) -
+                        W(3.649161410833e-6) * powi_left(L, 8));
+        k[4] = std::exp(W(-68.71040990212001) + W(43.93347632635) * L - W(18.48066993568) * powi_left(L, 2) + W(4.701626486759002) * powi_left(L, 3) -
+                        W(0.7692466334492) * powi_left(L, 4) + W(0.08113042097303) * powi_left(L, 5) - W(0.005324020628287001) * powi_left(L, 6) +
+                        W(0.0001975705312221) * powi_left(L, 7) - W(3.165581065665e-6) * powi_left(L, 8));
+    } else {
+        k[0] = k[2] = k[4] = W(1.0e-20);
+    }
+    const double kb = 1.3806503e-16, ev = 1.60217646e-12;
+    if (recombination_type == 1) { // case A
+        if (T_eV > W(0.8))
+            k[3] = W(1.54e-9) * (1. + W(0.3) / std::exp(W(8.099328789667) / T_eV)) / (std::exp(W(40.49664394833662) / T_eV) * std::pow(T_eV, W(1.5))) +
+                   W(3.92e-13) / std::pow(T_eV, W(0.6353));
+        else k[3] = W(3.92e-13) / std::pow(T_eV, W(0.6353));
+        if (T > W(5500.0))
+            k[1] = std::exp(W(-28.61303380689232) - W(0.7241125657826851) * L - W(0.02026044731984691) * powi_left(L, 2) -
+                            W(0.002380861877349834) * powi_left(L, 3) - W(0.0003212605213188796) * powi_left(L, 4) -
+                            W(0.00001421502914054107) * powi_left(L, 5) + W(4.989108920299513e-6) * powi_left(L, 6) +
+                            W(5.755614137575758e-7) * powi_left(L, 7) - W(1.856767039775261e-8) * powi_left(L, 8) -
+                            W(3.071135243196595e-9) * powi_left(L, 9));
+        else k[1] = k[3];
+        k[5] = W(3.36e-10) / std::sqrt(T) / std::pow(T / W(1.e3), W(0.2)) / (1. + std::pow(T / W(1.e6), W(0.7)));
+    } else { // case B
+        double tmp = (double)(2.f * 24.587f) * ev / (kb * T);
+        k[3] = W(1.26e-14) * (std::sqrt(tmp) * std::sqrt(std::sqrt(tmp))); // tmp**0.750 as the reference's compiler forms it
+        tmp = (double)(2.f * 13.598f) * ev / (kb * T);
+        k[1] = W(2.753e-14) * std::pow(tmp, W(1.500)) / std::pow(1. + std::pow(tmp / W(2.740), W(0.407)), W(2.242));
+        tmp = (double)(2.f * 54.418f) * ev / (kb * T);
+        k[5] = (double)(2.f * 2.753e-14f) * std::pow(tmp, W(1.500)) / std::pow(1. + std::pow(tmp / W(2.740), W(0.407)), W(2.242));
+    }
+}
+
+void rate_coefficient_tables(int nratec, double temstart, double temend, int recombination_type, double *k, double *logtem0,
+                             double *logtem9, double *dlogtem)
+{
+    *logtem0 = std::log(temstart);
+    *logtem9 = std::log(temend);
+    *dlogtem = (std::log(temend) - std::log(temstart)) / (double)(float)(nratec - 1);
+    for (int i = 1; i <= nratec; ++i) { // calc_rates.f:324-337
+        const double ttt = std::exp(std::log(temstart) + (double)(float)(i - 1) * *dlogtem);
+        double six[6];
+        coll_rates(ttt, recombination_type, six);
+        for (int r = 0; r < 6; ++r) k[(size_t)r * nratec + (i - 1)] = six[r];
+    }
+}
+
 void rmax_table(double *rmax30)
 {
     for (int ir = 1; ir <= 30; ++ir) {

@@ -66,6 +66,11 @@ void uvb_beta_table(int nfreq, double freqdel, const double *alpha, double *beta
 // uniformTable(nfreq, freqdel, alphaQuasar, alphaStellar), uniformTable.f90:1-200: ksi[component quasar, stellar][24, 25, 26] and
 // gamma[component][HI, HeI, HeII] of the two power-law components of the uniform background
 void uniform_table(int nfreq, double freqdel, double alpha_quasar, double alpha_stellar, double *ksi, double *gamma);
+// coll_rates (coll_rates.f:42-150): k1..k6 at temperature T; recombination_type 1 = case A, 2 = case B (definitionsModule.f90:48)
+void coll_rates(double T, int recombination_type, double *k);
+// k1a..k6a(nratec) as calc_rates.f:324-337 fills them, with the table bounds of equiSources.f90:174-176; k[6][nratec]
+void rate_coefficient_tables(int nratec, double temstart, double temend, int recombination_type, double *k, double *logtem0,
+                             double *logtem9, double *dlogtem);
 // rmax(1:30), equiSources.f90:296-309
 void rmax_table(double *rmax30);
 

@@ -301,3 +301,21 @@ def uniform_table(alpha_quasar, alpha_stellar, nfreq=400, freqdel=float(np.float
     lib().fo_uniform_table.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, dp, dp]
     lib().fo_uniform_table(nfreq, freqdel, float(alpha_quasar), float(alpha_stellar), _dp(ksi), _dp(gamma))
     return ksi, gamma
+
+
+def coll_rates(T, recombination_type):
+    k = np.empty(6)
+    lib().fo_coll_rates.restype = None
+    lib().fo_coll_rates.argtypes = [C.c_double, C.c_int, C.POINTER(C.c_double)]
+    lib().fo_coll_rates(float(T), int(recombination_type), _dp(k))
+    return k
+
+
+def rate_coefficient_tables(nratec, temstart, temend, recombination_type):
+    k = np.empty((6, nratec))
+    a, b, c = C.c_double(), C.c_double(), C.c_double()
+    dp = C.POINTER(C.c_double)
+    lib().fo_rate_coefficient_tables.restype = None
+    lib().fo_rate_coefficient_tables.argtypes = [C.c_int, C.c_double, C.c_double, C.c_int, dp, dp, dp, dp]
+    lib().fo_rate_coefficient_tables(nratec, float(temstart), float(temend), int(recombination_type), _dp(k), C.byref(a), C.byref(b), C.byref(c))
+    return k, a.value, b.value, c.value

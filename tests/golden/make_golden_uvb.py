@@ -26,10 +26,13 @@ def main():
                 raise RuntimeError(res.stdout + res.stderr)
             raw = np.fromfile(path, dtype="<f8")
             out.append(raw[:27].reshape(3, 3, 3))   # [beta|ksi|gamma][group][24,25,26 | HI,HeI,HeII]
-            uni.append(raw[27:].reshape(2, 2, 3))   # uniformTable(alpha1, alpha2): [ksi|gamma][quasar, stellar][3]
+            uni.append(raw[27:39].reshape(2, 2, 3))   # uniformTable(alpha1, alpha2): [ksi|gamma][quasar, stellar][3]
+            coll = raw[39:39 + 768].reshape(2, 64, 6)  # Fortran kout(6,64,2): [case A, case B][temperature][k1..k6]
+            coll_t = raw[39 + 768:]                     # the temperatures as the harness formed them
     out, uni = np.array(out), np.array(uni)
     np.savez_compressed(os.path.join(HERE, "uvb_beta_table.npz"), alpha=alphas, beta=out[:, 0], ksi=out[:, 1], gamma=out[:, 2],
-                        uniform_ksi=uni[:, 0], uniform_gamma=uni[:, 1])
+                        uniform_ksi=uni[:, 0], uniform_gamma=uni[:, 1], coll_temperature=coll_t,
+                        coll_rates=coll)
     print("uvb_beta_table:", out.shape)
 
 

@@ -161,3 +161,14 @@ def test_uvb_beta_table_of_the_product_matches_reference_vectors(rt, golden):
     for a, ksi, gamma in zip(g["alpha"], g["uniform_ksi"], g["uniform_gamma"]):   # ftte_uniform_table vs uniformTable(alpha1, alpha2)
         k, h = rt.uniform_table(a[0], a[1])
         assert np.array_equal(k, ksi) and np.array_equal(h, gamma)
+
+
+def test_coll_rates_of_the_product_match_reference_vectors(rt, golden):
+    """ftte_coll_rates / ftte_rate_coefficient_tables (host code of the product) against the reference's own coll_rates."""
+    g = golden("uvb_beta_table")
+    for rtype in (1, 2):
+        for T, ref in zip(g["coll_temperature"], g["coll_rates"][rtype - 1]):
+            assert np.array_equal(rt.coll_rates(T, rtype), ref), (rtype, T)
+    c = golden("chem_uvb_refined")
+    k, l0, l9, dl = rt.rate_coefficient_tables()
+    assert (l0, l9, dl) == (float(c["logtem0"]), float(c["logtem9"]), float(c["dlogtem"])) and np.array_equal(k, c["k"])

@@ -60,3 +60,16 @@ def test_assign_uvb_radiation_bitwise(golden):
     g = golden("thin_limit_uvb")
     J = O.assign_uvb_radiation(g["HI"], g["HeI"], g["HeII"], g["rho"], g["uvb"], float(g["threshold"]))
     assert np.array_equal(J, g["J"]) and 0 < (J[0] > 0).mean() < 1
+
+
+def test_coll_rates_and_tables_bitwise(golden):
+    """coll_rates.f (case A and case B recombination) at 64 temperatures, and the 5000-entry tables the reference's driver
+    builds from it (calc_rates.f:324-337 with equiSources.f90:174-176), against the reference's own compiled routine."""
+    g = golden("uvb_beta_table")
+    for rtype in (1, 2):
+        for T, ref in zip(g["coll_temperature"], g["coll_rates"][rtype - 1]):
+            assert np.array_equal(O.coll_rates(T, rtype), ref), (rtype, T)
+    c = golden("chem_uvb_refined")
+    k, l0, l9, dl = O.rate_coefficient_tables(c["k"].shape[1], 1.0, float(np.float32(1.0e8)), 2)
+    assert (l0, l9, dl) == (float(c["logtem0"]), float(c["logtem9"]), float(c["dlogtem"]))
+    assert np.array_equal(k, c["k"])
