@@ -24,6 +24,8 @@ program ftte_demo_loop
   integer(c_int64_t), allocatable :: src(:)
   real(c_double), allocatable :: gas(:,:), ndot(:), tables(:), k(:,:), J(:,:), phi(:), theta(:), w(:), species(:,:)
   real(c_double) :: box, alpha(3), uvb(3), logtem(3), beta(3,3), ksi(3,3), gam(3,3), uniform(3), change
+  real(c_double), allocatable :: kown(:,:)
+  real(c_double) :: logtemOwn(3)
   character(len=512) :: caseName, outName
   integer :: ios
 
@@ -57,6 +59,12 @@ program ftte_demo_loop
   call ftteCheck(c_null_ptr, ftte_create(ctx, 1, c_null_ptr), 'ftte_create')
   ! uvbBetaTable with the reference's nfbins and frequencyBinWidth (a default-real 0.02)
   call ftteCheck(ctx, ftte_uvb_beta_table(400, real(0.02, c_double), alpha, beta, ksi, gam), 'ftte_uvb_beta_table')
+  ! the rate-coefficient tables the reference's driver builds with calc_rates/coll_rates (case B, 1 K .. 1e8 K): when the case
+  ! file carries the reference's own, the library's must be the same numbers
+  allocate(kown(nratec,6))
+  call ftteCheck(ctx, ftte_rate_coefficient_tables(nratec, 1.d0, real(1.e8, c_double), 2, kown, logtemOwn(1), logtemOwn(2), &
+       logtemOwn(3)), 'ftte_rate_coefficient_tables')
+  if (any(kown /= k) .or. any(logtemOwn /= logtem)) stop 'ftte_demo_loop: rate-coefficient tables differ from the case file'
   call ftteCheck(ctx, ftte_set_grid(ctx, n, n, n, ncell, lev, box), 'ftte_set_grid')
   call ftteCheck(ctx, ftte_set_rate_tables(ctx, tables), 'ftte_set_rate_tables')
   call ftteCheck(ctx, ftte_set_rate_coefficients(ctx, nratec, logtem(1), logtem(2), logtem(3), k(:,1), k(:,2), k(:,3), k(:,4), &
