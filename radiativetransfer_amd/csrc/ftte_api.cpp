@@ -1170,7 +1170,17 @@ int ftte_set_temperature(ftte_ctx *c, const double *tgas)
     FTTE_HIP(c, hipSetDevice(c->device));
     // the logarithm is taken here, on the host, so that the device update consists of IEEE-exact operations only
     std::vector<double> logtem((size_t)c->ncell);
-    for (int64_t q = 0; q < c->ncell; ++q) logtem[(size_t)q] = std::log(tgas[q]);
+    {
+        const int nthreads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        const int64_t chunk = (c->ncell + nthreads - 1) / nthreads;
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; ++t)
+            pool.emplace_back([&, t] {
+                const int64_t lo = t * chunk, hi = std::min<int64_t>(c->ncell, lo + chunk);
+                for (int64_t q = lo; q < hi; ++q) logtem[(size_t)q] = std::log(tgas[q]);
+            });
+        for (auto &th : pool) th.join();
+    }
     if (!c->chem_logtem) FTTE_HIP(c, hipMalloc((void **)&c->chem_logtem, sizeof(double) * (size_t)c->ncell));
     FTTE_HIP(c, hipMemcpyAsync(c->chem_logtem, logtem.data(), sizeof(double) * (size_t)c->ncell, hipMemcpyHostToDevice, c->stream));
     FTTE_HIP(c, hipStreamSynchronize(c->stream));
