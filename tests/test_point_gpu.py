@@ -291,3 +291,44 @@ def test_argument_and_state_errors_of_the_table_calls(pop):
         total = st.stellar_beta_table(pop[0], pop[1], pop[2], 36, 1.0, 4, 1.0)   # the last admissible indices
         assert total > 0 and np.all(st.rate_tables() > 0)
         assert st.get_rates_hydrogen_helium(np.zeros((0, 4))).shape == (0, 3, 2)
+
+
+def test_limiting_media(stellar, golden):
+    """No absorbers: nothing is deposited and the rays run to the box.  An absorber so dense that the first half cell is
+    beyond the tables: every photon stays in the star's own cell.  A star in the corner cell: seven of its eight octants leave through the near faces."""
+    g = golden("point16_homogeneous")
+    tables = g["tables"].reshape(6, -1)
+    n = 16
+    nc = n ** 3
+    box = float(g["box"])
+    stellar.set_grid(n, np.zeros(nc, np.int32), box)
+    stellar.set_rate_tables(g["tables"])
+    zeros = np.zeros(nc)
+    src = (8 * n + 8) * n + 8
+    # transparent
+    stellar.set_medium(zeros, zeros, zeros, None, None, 0)
+    stellar.set_zero_rates()
+    hp = stellar.point_sources([src], [3.0])
+    _, hp_ref = O.point_sources(n, np.zeros(nc, np.int32), zeros, zeros, zeros, zeros, zeros, box, 0, [src], [3.0], tables)
+    assert hp == hp_ref == 6 and not stellar.rates().any()   # the rays towards the corners travel 13 cells: beyond rmax(5) = 10.2
+    # opaque in hydrogen only: tau1 of half a cell = 50
+    HI = np.full(nc, 100.0 / (float(np.float32(6.3e-18)) * box / n))
+    stellar.set_medium(HI, zeros, zeros, None, None, 0)
+    stellar.set_zero_rates()
+    hp = stellar.point_sources([src], [3.0])
+    k = stellar.rates()
+    assert abs(k[0, src] / (3.0 * tables[0, 0]) - 1) < 1e-14 and abs(k[3, src] / (3.0 * tables[3, 0]) - 1) < 1e-14
+    lit = np.flatnonzero(k[0])
+    assert lit.tolist() == [src] and not k[1].any() and not k[2].any()
+    # a corner star in a moderately thick box: conservation, and most photons leave through the three near faces
+    HI = np.full(nc, 0.3 / (float(np.float32(6.3e-18)) * box / n))
+    stellar.set_medium(HI, zeros, zeros, None, None, 0)
+    stellar.set_zero_rates()
+    stellar.point_sources([0], [1.0])
+    k = stellar.rates()
+    frac = k[0].sum() / tables[0, 0]
+    # the star sits in the middle of its cell: the seven octants that leave still cross up to 0.87 cells of it
+    assert 0.125 < frac < 0.3, frac
+    ref, _ = O.point_sources(n, np.zeros(nc, np.int32), HI, zeros, zeros, zeros, zeros, box, 0, [0], [1.0], tables)
+    _close(k, ref)
+    assert k[0, 0] > 0 and np.all(k[0] >= 0)
