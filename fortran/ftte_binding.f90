@@ -74,6 +74,25 @@ module ftte_binding
        real(c_double), intent(out) :: J(*)      ! (ncell, nnu)
      end function ftte_diffuse_sweep
 
+     ! pins a host array the caller keeps (kappa, J): moved by DMA without a staging copy while it stays registered
+     integer(c_int) function ftte_host_register(ctx, ptr, bytes) bind(C, name='ftte_host_register')
+       import :: c_ptr, c_int, c_size_t
+       type(c_ptr), value :: ctx, ptr
+       integer(c_size_t), value :: bytes
+     end function ftte_host_register
+
+     integer(c_int) function ftte_host_unregister(ctx, ptr) bind(C, name='ftte_host_unregister')
+       import :: c_ptr, c_int
+       type(c_ptr), value :: ctx, ptr
+     end function ftte_host_unregister
+
+     ! "grid_builds", "plan_builds", "forest_builds" (null-terminated): how often the host-side builds ran
+     integer(c_long_long) function ftte_counter(ctx, name) bind(C, name='ftte_counter')
+       import :: c_ptr, c_long_long, c_char
+       type(c_ptr), value :: ctx
+       character(kind=c_char), intent(in) :: name(*)
+     end function ftte_counter
+
      integer(c_int) function ftte_set_option(ctx, key, val) bind(C, name='ftte_set_option')
        import :: c_ptr, c_int, c_char
        type(c_ptr), value :: ctx

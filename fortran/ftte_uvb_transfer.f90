@@ -18,14 +18,18 @@ module ftte_uvb_transfer
 
   type(c_ptr), save, private :: ctx = c_null_ptr
   integer(c_int64_t), private :: cursor
+  ! The flattened cell array is kept from call to call (the reference's tree is static over a run) and pinned, so that
+  ! kappa and J cross PCIe by DMA straight from / into these arrays; the library for its part keeps the tree, the sweep
+  ! plan and the segment forests when ftte_set_grid sees the level list it already holds.
+  integer(c_int32_t), allocatable, target, save, private :: lev(:)
+  real(c_double), allocatable, target, save, private :: kap(:,:), Jflat(:,:)
 
 contains
 
   subroutine ftteRunUVBTransfer(nx)
     integer, intent(in) :: nx
     integer(c_int64_t) :: ncell
-    integer(c_int32_t), allocatable :: lev(:)
-    real(c_double), allocatable :: kap(:,:), Jflat(:,:), phi(:), theta(:), w(:)
+    real(c_double), allocatable :: phi(:), theta(:), w(:)
     real(c_double) :: uvb(3)
     integer :: i, j, k, ndir, nside
     integer(kind=8) :: iray
@@ -40,7 +44,18 @@ contains
           enddo
        enddo
     enddo
-    allocate(lev(ncell), kap(ncell,3), Jflat(ncell,3))
+    if (allocated(lev)) then
+       if (size(lev, kind=c_int64_t) /= ncell) then
+          call ftteCheck(ctx, ftte_host_unregister(ctx, c_loc(kap)), 'ftte_host_unregister')
+          call ftteCheck(ctx, ftte_host_unregister(ctx, c_loc(Jflat)), 'ftte_host_unregister')
+          deallocate(lev, kap, Jflat)
+       endif
+    endif
+    if (.not. allocated(lev)) then
+       allocate(lev(ncell), kap(ncell,3), Jflat(ncell,3))
+       call ftteCheck(ctx, ftte_host_register(ctx, c_loc(kap), int(24*ncell, c_size_t)), 'ftte_host_register')
+       call ftteCheck(ctx, ftte_host_register(ctx, c_loc(Jflat), int(24*ncell, c_size_t)), 'ftte_host_register')
+    endif
     cursor = 0
     do i = 1, nx
        do j = 1, nx

@@ -26,6 +26,7 @@
 #ifndef FTTE_H
 #define FTTE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -69,7 +70,9 @@ const char *ftte_last_error(const ftte_ctx *ctx);
  * (definitionsModule.f90:256).  nx == ny == nz is required, as in the reference.
  * level[ncell]: depth-first leaf list, 0 = base cell.  A list of all zeros (ncell = nx^3) is a
  * uniform grid and takes the tiled sweep kernel; a refined cell array takes the general
- * segment-forest path (setRaysRefined / findNeighbours / transport of the reference). */
+ * segment-forest path (setRaysRefined / findNeighbours / transport of the reference).
+ * The reference's tree is static over a run: a call with the list the context already holds returns at once and
+ * keeps the tree, the sweep plans and the device-resident medium (only box_cm is taken over). */
 int ftte_set_grid(ftte_ctx *ctx, int nx, int ny, int nz, int64_t ncell, const int32_t *level, double box_cm);
 
 /* Opacities kappa[nnu][ncell] in cell-array order (host memory), cm^-1.  Stands in for the
@@ -240,7 +243,20 @@ int ftte_assign_uvb_radiation_device(ftte_ctx *ctx, int nnu, const double *uvb, 
 /* bisection steps of the last ftte_solve_rate_equations*, summed over the cells */
 long long ftte_rate_equation_steps(const ftte_ctx *ctx);
 
+/* ---- host arrays ------------------------------------------------------------------------------
+ * The reference keeps its fields in host memory (the zoneType tree, definitionsModule.f90:163-180); the drop-ins
+ * flatten them into cell-array order and hand them over.  Pageable arrays cross PCIe through pinned staging blocks
+ * inside the library; an array registered here is pinned in place and moved by DMA directly, for as long as it stays
+ * registered (the caller unregisters it before freeing it).  bytes counts from ptr. */
+int ftte_host_register(ftte_ctx *ctx, void *ptr, size_t bytes);
+int ftte_host_unregister(ftte_ctx *ctx, void *ptr);
+
 /* ---- tuning and instrumentation ------------------------------------------------------------- */
+
+/* How often the expensive host-side builds have run on this context: "grid_builds" (tree rebuilt from a level list:
+ * ftte_set_grid with an unchanged list keeps the tree, the plans and the resident medium), "plan_builds" (tiled-sweep
+ * planner), "forest_builds" (per-direction segment forests of a refined cell array).  -1 for an unknown name. */
+long long ftte_counter(const ftte_ctx *ctx, const char *name);
 
 /* Tuning knobs: "rows" (rays per lane: 4, 8 or 16), "stack" (wavefronts per workgroup, stacked
  * along the row axis and exchanging their boundary row through LDS: 1, 2, 4 or 8), "slots"

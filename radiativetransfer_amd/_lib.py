@@ -76,6 +76,9 @@ SIGNATURES = {
     "ftte_rate_coefficient_tables": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_int, _dp, _dp, _dp, _dp]),
     "ftte_uniform_table": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_double, _dp, _dp]),
     "ftte_dust_cross_section": (C.c_double, [C.c_double, _dp]),
+    "ftte_host_register": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "ftte_host_unregister": (C.c_int, [_vp, _vp]),
+    "ftte_counter": (C.c_longlong, [_vp, C.c_char_p]),
     "ftte_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "ftte_launch_count": (C.c_int, [_vp]),
     "ftte_launch_info": (C.c_int, [_vp, C.c_int, _dp, C.POINTER(C.c_int64)]),

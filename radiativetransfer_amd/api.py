@@ -199,6 +199,25 @@ class DiffuseTransfer:
         self._ok(self._lib.ftte_diffuse_sweep_device(self._ctx, len(phi), _dp(phi), _dp(theta), _dp(weight), _dp(uvb),
                                                      C.c_void_p(j_device_ptr), C.c_void_p(stream)))
 
+    def transport_into(self, phi, theta, weight, uvb, J: np.ndarray) -> np.ndarray:
+        """Same as transport() into a caller-owned J[nnu][ncell] (e.g. one registered with host_register)."""
+        phi, theta, weight, uvb = map(_f64, (phi, theta, weight, uvb))
+        if J.dtype != np.float64 or not J.flags.c_contiguous or J.shape != (self.nnu, self.ncell):
+            raise ValueError("J must be a C-contiguous float64 array of shape [nnu][ncell]")
+        self._ok(self._lib.ftte_diffuse_sweep(self._ctx, len(phi), _dp(phi), _dp(theta), _dp(weight), _dp(uvb), _dp(J)))
+        return J
+
+    def host_register(self, a: np.ndarray):
+        """Pin a host array the caller keeps (kappa, J): the library then moves it by DMA without a staging copy."""
+        self._ok(self._lib.ftte_host_register(self._ctx, C.c_void_p(a.ctypes.data), a.nbytes))
+
+    def host_unregister(self, a: np.ndarray):
+        self._ok(self._lib.ftte_host_unregister(self._ctx, C.c_void_p(a.ctypes.data)))
+
+    def counter(self, name: str) -> int:
+        """grid_builds / plan_builds / forest_builds: how often the expensive host-side builds ran."""
+        return int(self._lib.ftte_counter(self._ctx, name.encode()))
+
     def launch_records(self):
         """[(ms, updates)] of the sweep-kernel launches of the last sweep (synchronise first)."""
         out = []

@@ -31,6 +31,18 @@ def hipcc() -> str:
     return exe
 
 
+def includes(path: str, seen=None) -> set:
+    """Quoted includes of a source file, followed recursively."""
+    import re
+    seen = set() if seen is None else seen
+    for m in re.finditer(r'^\s*#include\s+"([^"]+)"', open(path).read(), re.M):
+        h = os.path.normpath(os.path.join(os.path.dirname(path), m.group(1)))
+        if h not in seen and os.path.exists(h):
+            seen.add(h)
+            includes(h, seen)
+    return seen
+
+
 def stale() -> bool:
     if not os.path.exists(LIB):
         return True
@@ -42,14 +54,24 @@ def stale() -> bool:
 def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and not stale():
         return LIB
-    objs = []
+    # per-file: an object is rebuilt when its source, a header it includes, or this script is newer; files compile side by side
+    from concurrent.futures import ThreadPoolExecutor
+    objs, jobs = [], []
     for s in SOURCES:
+        src = os.path.join(CSRC, s)
         obj = os.path.join(CSRC, os.path.splitext(s)[0] + ".o")
-        cmd = [hipcc(), *FLAGS, "-x", "hip", "-c", os.path.join(CSRC, s), "-o", obj]
+        objs.append(obj)
+        deps = sorted(includes(src)) + [src, os.path.abspath(__file__)]
+        if force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in deps):
+            jobs.append([hipcc(), *FLAGS, "-x", "hip", "-c", src, "-o", obj])
+
+    def run(cmd):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-        objs.append(obj)
+
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        list(pool.map(run, jobs))
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
     if verbose:
         print(" ".join(cmd))

@@ -124,8 +124,24 @@ struct ftte_ctx {
     // partial merges run beside the sweeps of the next layout on their own (non-blocking) stream
     hipStream_t merge_stream = nullptr;
     hipEvent_t ev_layout_done = nullptr, ev_merge_done = nullptr, ev_layouts_ready = nullptr;
+    // end of the last sweep on whatever stream the caller gave it: the setters and the next sweep wait for it before they
+    // overwrite what that sweep reads
+    hipEvent_t ev_sweep_done = nullptr;
+    bool sweep_pending = false;
 
     PointState point; // point sources: rate tables, medium, tracer scratch
+
+    // host-array boundary (ftte_set_opacity / ftte_diffuse_sweep): J lives in a device buffer the context keeps, and
+    // pageable host arrays cross PCIe through two pinned staging blocks filled by a few host threads while the other
+    // block is in flight; arrays the caller has registered (ftte_host_register) are copied by the DMA engine directly
+    double *host_J_dev = nullptr; size_t host_J_cap = 0;
+    void *stage[2] = {nullptr, nullptr};
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    struct HostRange { const char *base; size_t bytes; };
+    std::vector<HostRange> registered;
+
+    // instrumentation (ftte_counter): how often the expensive host-side builds ran
+    long long n_grid_builds = 0, n_plan_builds = 0, n_forest_builds = 0;
 
     // ionisation equilibrium (solveRateEquations)
     std::vector<int8_t> leaf_level;  // per leaf, as handed to ftte_set_grid
@@ -184,6 +200,7 @@ int build_plan(ftte_ctx *c, int rows, int stack, int ndir, const double *phi, co
                        !std::memcmp(P.w.data(), w, sizeof(double) * ndir))))
         return FTTE_OK;
 
+    ++c->n_plan_builds;
     P = Plan();
     P.n = n; P.rows = rows; P.slots = slots; P.stack = stack; P.box = c->box;
     P.phi.assign(phi, phi + ndir); P.theta.assign(theta, theta + ndir); P.w.assign(w, w + ndir);
@@ -380,6 +397,24 @@ int check_ready(ftte_ctx *c, bool need_kappa)
     return FTTE_OK;
 }
 
+// the previous sweep may have been issued on a stream of the caller's: wait for its end before its inputs are rewritten
+int wait_sweep(ftte_ctx *c)
+{
+    if (c->sweep_pending) {
+        FTTE_HIP(c, hipEventSynchronize(c->ev_sweep_done));
+        c->sweep_pending = false;
+    }
+    return FTTE_OK;
+}
+
+int mark_sweep(ftte_ctx *c, hipStream_t stream)
+{
+    if (!c->ev_sweep_done) FTTE_HIP(c, hipEventCreateWithFlags(&c->ev_sweep_done, hipEventDisableTiming));
+    FTTE_HIP(c, hipEventRecord(c->ev_sweep_done, stream));
+    c->sweep_pending = true;
+    return FTTE_OK;
+}
+
 void free_forests(ftte_ctx *c)
 {
     for (auto &f : c->forests) {
@@ -397,6 +432,7 @@ int forest_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
     const int nnu = c->nnu;
     const int64_t ncell = c->ncell, nseg = 3 * ncell;
     int rc;
+    if ((rc = wait_sweep(c))) return rc;
 
     // ---- plan: fold, link, order; cached while the direction list, the tree and the box stay the same
     std::vector<double> key;
@@ -408,6 +444,7 @@ int forest_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
     if (key != c->forest_key || (int)c->forests.size() != ndir) {
         FTTE_HIP(c, hipStreamSynchronize(stream));
         free_forests(c);
+        ++c->n_forest_builds;
         std::vector<double> fphi(ndir), ftheta(ndir);
         std::vector<int> fzone(ndir);
         for (int d = 0; d < ndir; ++d) {
@@ -545,6 +582,98 @@ int forest_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
         FTTE_HIP(c, hipEventRecord(T.stop, stream));
         c->timing_used = b + 1;
     }
+    return mark_sweep(c, stream);
+}
+
+
+// ---- host arrays across PCIe ------------------------------------------------------------------------------------
+constexpr size_t kStageBytes = (size_t)64 << 20;
+
+bool is_registered(const ftte_ctx *c, const void *p, size_t bytes)
+{
+    const char *b = (const char *)p;
+    for (const auto &r : c->registered)
+        if (b >= r.base && b + bytes <= r.base + r.bytes) return true;
+    return false;
+}
+
+void parallel_copy(void *dst, const void *src, size_t bytes)
+{
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const size_t nthreads = std::min<size_t>(std::min(8u, hw), std::max<size_t>(1, bytes >> 22));
+    if (nthreads <= 1) { std::memcpy(dst, src, bytes); return; }
+    const size_t chunk = ((bytes + nthreads - 1) / nthreads + 63) & ~(size_t)63;
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < nthreads; ++t) {
+        const size_t lo = t * chunk;
+        if (lo >= bytes) break;
+        const size_t len = std::min(chunk, bytes - lo);
+        pool.emplace_back([=] { std::memcpy((char *)dst + lo, (const char *)src + lo, len); });
+    }
+    for (auto &th : pool) th.join();
+}
+
+int ensure_stage(ftte_ctx *c)
+{
+    for (int q = 0; q < 2; ++q) {
+        if (!c->stage[q]) FTTE_HIP(c, hipHostMalloc(&c->stage[q], kStageBytes, hipHostMallocDefault));
+        if (!c->stage_ev[q]) FTTE_HIP(c, hipEventCreateWithFlags(&c->stage_ev[q], hipEventDisableTiming));
+    }
+    return FTTE_OK;
+}
+
+// host -> device on c->stream; returns with the copy complete
+int upload(ftte_ctx *c, void *dst_dev, const void *src_host, size_t bytes)
+{
+    if (is_registered(c, src_host, bytes) || bytes < ((size_t)1 << 20)) {
+        FTTE_HIP(c, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream));
+        FTTE_HIP(c, hipStreamSynchronize(c->stream));
+        return FTTE_OK;
+    }
+    int rc = ensure_stage(c);
+    if (rc) return rc;
+    int q = 0;
+    bool busy[2] = {false, false};
+    for (size_t off = 0; off < bytes; off += kStageBytes, q ^= 1) {
+        const size_t len = std::min(kStageBytes, bytes - off);
+        if (busy[q]) FTTE_HIP(c, hipEventSynchronize(c->stage_ev[q]));
+        parallel_copy(c->stage[q], (const char *)src_host + off, len);
+        FTTE_HIP(c, hipMemcpyAsync((char *)dst_dev + off, c->stage[q], len, hipMemcpyHostToDevice, c->stream));
+        FTTE_HIP(c, hipEventRecord(c->stage_ev[q], c->stream));
+        busy[q] = true;
+    }
+    FTTE_HIP(c, hipStreamSynchronize(c->stream));
+    return FTTE_OK;
+}
+
+// device -> host on c->stream (after whatever is queued there); returns with the copy complete
+int download(ftte_ctx *c, void *dst_host, const void *src_dev, size_t bytes)
+{
+    if (is_registered(c, dst_host, bytes) || bytes < ((size_t)1 << 20)) {
+        FTTE_HIP(c, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+        FTTE_HIP(c, hipStreamSynchronize(c->stream));
+        return FTTE_OK;
+    }
+    int rc = ensure_stage(c);
+    if (rc) return rc;
+    // block q is filled by the DMA engine while the host threads empty block q^1
+    size_t off_prev = 0, len_prev = 0;
+    bool have_prev = false;
+    int q = 0;
+    for (size_t off = 0; off < bytes; off += kStageBytes, q ^= 1) {
+        const size_t len = std::min(kStageBytes, bytes - off);
+        FTTE_HIP(c, hipMemcpyAsync(c->stage[q], (const char *)src_dev + off, len, hipMemcpyDeviceToHost, c->stream));
+        FTTE_HIP(c, hipEventRecord(c->stage_ev[q], c->stream));
+        if (have_prev) {
+            FTTE_HIP(c, hipEventSynchronize(c->stage_ev[q ^ 1]));
+            parallel_copy((char *)dst_host + off_prev, c->stage[q ^ 1], len_prev);
+        }
+        off_prev = off; len_prev = len; have_prev = true;
+    }
+    if (have_prev) {
+        FTTE_HIP(c, hipEventSynchronize(c->stage_ev[q ^ 1]));
+        parallel_copy((char *)dst_host + off_prev, c->stage[q ^ 1], len_prev);
+    }
     return FTTE_OK;
 }
 
@@ -606,6 +735,13 @@ int ftte_destroy(ftte_ctx *c)
     if (c->ev_layout_done) (void)hipEventDestroy(c->ev_layout_done);
     if (c->ev_merge_done) (void)hipEventDestroy(c->ev_merge_done);
     if (c->ev_layouts_ready) (void)hipEventDestroy(c->ev_layouts_ready);
+    if (c->ev_sweep_done) (void)hipEventDestroy(c->ev_sweep_done);
+    if (c->host_J_dev) (void)hipFree(c->host_J_dev);
+    for (int q = 0; q < 2; ++q) {
+        if (c->stage[q]) (void)hipHostFree(c->stage[q]);
+        if (c->stage_ev[q]) (void)hipEventDestroy(c->stage_ev[q]);
+    }
+    for (auto &r : c->registered) (void)hipHostUnregister((void *)r.base);
     c->point.release();
     c->drop_chem_grid();
     if (c->chem_k) (void)hipFree(c->chem_k);
@@ -624,8 +760,20 @@ int ftte_set_grid(ftte_ctx *c, int nx, int ny, int nz, int64_t ncell, const int3
     if (nx < 1 || !level || ncell < 1 || !(box_cm > 0.0)) return fail(c, FTTE_ERR_ARG, "ftte_set_grid: bad argument");
     if (nx != ny || nx != nz) return fail(c, FTTE_ERR_NOT_CUBIC, "base grid needs to be of size n^3");
     if (nx > 32000) return fail(c, FTTE_ERR_UNSUPPORTED, "ftte_set_grid: n > 32000");
+    // The reference's tree is static over a run while its driver would hand the same list over on every outer iteration
+    // (the drop-ins do): an unchanged list keeps the tree, the sweep plan, the segment forests and the resident medium.
+    // Only the box may differ (the plans are keyed on it themselves).
+    if (c->grid_set && c->n == nx && c->ncell == ncell && (int64_t)c->leaf_level.size() == ncell) {
+        bool same = true;
+        const int8_t *have = c->leaf_level.data();
+        for (int64_t q = 0; q < ncell; ++q)
+            if ((int32_t)have[q] != level[q]) { same = false; break; }
+        if (same) { c->box = box_cm; return FTTE_OK; }
+    }
     // rebuild the tree exactly as createFullyThreadedStructure does (readCellArray.f90:154-187); this also
     // validates the list
+    ++c->n_grid_builds;
+    if (c->sweep_pending) { (void)hipSetDevice(c->device); (void)hipEventSynchronize(c->ev_sweep_done); c->sweep_pending = false; }
     AmrTree tree;
     const std::string terr = tree.build(nx, ncell, level);
     if (!terr.empty()) return fail(c, FTTE_ERR_LEVELS, terr);
@@ -667,10 +815,10 @@ int ftte_set_opacity(ftte_ctx *c, int nnu, const double *kappa)
     if (rc) return rc;
     if (nnu < 1 || !kappa) return fail(c, FTTE_ERR_ARG, "ftte_set_opacity: bad argument");
     FTTE_HIP(c, hipSetDevice(c->device));
+    if ((rc = wait_sweep(c))) return rc;
     FTTE_HIP(c, hipStreamSynchronize(c->stream));
     if ((rc = ensure_kappa(c, nnu))) return rc;
-    FTTE_HIP(c, hipMemcpyAsync(c->kappa[0], kappa, sizeof(double) * nnu * c->ncell, hipMemcpyHostToDevice, c->stream));
-    FTTE_HIP(c, hipStreamSynchronize(c->stream));
+    if ((rc = upload(c, c->kappa[0], kappa, sizeof(double) * nnu * c->ncell))) return rc;
     c->nnu = nnu;
     c->kappa_ready[0] = true; c->kappa_ready[1] = c->kappa_ready[2] = c->kappa_ready[3] = false;
     return FTTE_OK;
@@ -682,6 +830,7 @@ int ftte_set_opacity_device(ftte_ctx *c, int nnu, const double *kappa_dev)
     if (rc) return rc;
     if (nnu < 1 || !kappa_dev) return fail(c, FTTE_ERR_ARG, "ftte_set_opacity_device: bad argument");
     FTTE_HIP(c, hipSetDevice(c->device));
+    if ((rc = wait_sweep(c))) return rc;
     if ((rc = ensure_kappa(c, nnu))) return rc;
     FTTE_HIP(c, hipMemcpyAsync(c->kappa[0], kappa_dev, sizeof(double) * nnu * c->ncell, hipMemcpyDeviceToDevice, c->stream));
     FTTE_HIP(c, hipStreamSynchronize(c->stream)); // the sweep may run on another stream: the copy must have landed
@@ -696,6 +845,7 @@ int ftte_set_species(ftte_ctx *c, int nnu, const double *HI, const double *HeI, 
     if (rc) return rc;
     if (nnu < 1 || !HI || !HeI || !HeII || !beta) return fail(c, FTTE_ERR_ARG, "ftte_set_species: bad argument");
     FTTE_HIP(c, hipSetDevice(c->device));
+    if ((rc = wait_sweep(c))) return rc;
     FTTE_HIP(c, hipStreamSynchronize(c->stream));
     if ((rc = ensure_kappa(c, nnu))) return rc;
     double *tmp = nullptr;
@@ -723,6 +873,7 @@ static int set_emission(ftte_ctx *c, int mode, const double *values, bool on_dev
     int rc = check_ready(c, true);
     if (rc) return rc;
     FTTE_HIP(c, hipSetDevice(c->device));
+    if ((rc = wait_sweep(c))) return rc;
     if (!on_device) FTTE_HIP(c, hipStreamSynchronize(c->stream));
     if (!c->emis[0]) FTTE_HIP(c, hipMalloc((void **)&c->emis[0], sizeof(double) * c->kappa_cap));
     const size_t bytes = sizeof(double) * (size_t)c->nnu * c->ncell;
@@ -785,6 +936,7 @@ int ftte_diffuse_sweep_device(ftte_ctx *c, int ndir, const double *phi, const do
     Plan &P = c->plan;
 
     // everything below overwrites device tables the previous sweep may still be reading
+    if ((rc = wait_sweep(c))) return rc;
     FTTE_HIP(c, hipStreamSynchronize(stream));
     if (stream != c->stream) FTTE_HIP(c, hipStreamSynchronize(c->stream));
 
@@ -919,8 +1071,7 @@ int ftte_diffuse_sweep_device(ftte_ctx *c, int ndir, const double *phi, const do
     if (!merged_any) FTTE_HIP(c, hipMemsetAsync(J_dev, 0, sizeof(double) * (size_t)nnu * c->ncell, stream)); // no directions
     FTTE_HIP(c, hipEventRecord(c->ev_merge_done, c->merge_stream));
     FTTE_HIP(c, hipStreamWaitEvent(stream, c->ev_merge_done, 0));
-
-    return FTTE_OK;
+    return mark_sweep(c, stream);
 }
 
 int ftte_diffuse_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, const double *w, const double *uvb,
@@ -930,18 +1081,46 @@ int ftte_diffuse_sweep(ftte_ctx *c, int ndir, const double *phi, const double *t
     if (rc) return rc;
     if (!J) return fail(c, FTTE_ERR_ARG, "ftte_diffuse_sweep: J is NULL");
     FTTE_HIP(c, hipSetDevice(c->device));
-    double *J_dev = nullptr;
-    const size_t bytes = sizeof(double) * (size_t)c->nnu * c->ncell;
-    FTTE_HIP(c, hipMalloc((void **)&J_dev, bytes));
-    rc = ftte_diffuse_sweep_device(c, ndir, phi, theta, w, uvb, J_dev, nullptr);
-    hipError_t e = hipSuccess;
-    if (!rc) e = hipMemcpyAsync(J, J_dev, bytes, hipMemcpyDeviceToHost, c->stream);
-    hipError_t e2 = hipStreamSynchronize(c->stream);
-    (void)hipFree(J_dev);
-    if (rc) return rc;
-    if (e != hipSuccess || e2 != hipSuccess)
-        return fail(c, FTTE_ERR_NO_DEVICE, std::string("ftte_diffuse_sweep: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+    const size_t elems = (size_t)c->nnu * c->ncell;
+    if ((rc = ensure(c, &c->host_J_dev, &c->host_J_cap, elems))) return rc; // kept from call to call
+    if ((rc = ftte_diffuse_sweep_device(c, ndir, phi, theta, w, uvb, c->host_J_dev, nullptr))) return rc;
+    return download(c, J, c->host_J_dev, sizeof(double) * elems);
+}
+
+/* Pins a caller-owned host array for as long as it stays registered: ftte_set_opacity / ftte_diffuse_sweep then move
+ * it by DMA directly (no staging copy).  The caller unregisters it before freeing it. */
+int ftte_host_register(ftte_ctx *c, void *ptr, size_t bytes)
+{
+    if (!c) return FTTE_ERR_ARG;
+    if (!ptr || !bytes) return fail(c, FTTE_ERR_ARG, "ftte_host_register: bad argument");
+    if (is_registered(c, ptr, bytes)) return FTTE_OK;
+    FTTE_HIP(c, hipSetDevice(c->device));
+    FTTE_HIP(c, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    c->registered.push_back({(const char *)ptr, bytes});
     return FTTE_OK;
+}
+
+int ftte_host_unregister(ftte_ctx *c, void *ptr)
+{
+    if (!c) return FTTE_ERR_ARG;
+    for (size_t q = 0; q < c->registered.size(); ++q)
+        if (c->registered[q].base == (const char *)ptr) {
+            FTTE_HIP(c, hipSetDevice(c->device));
+            FTTE_HIP(c, hipStreamSynchronize(c->stream));
+            FTTE_HIP(c, hipHostUnregister(ptr));
+            c->registered.erase(c->registered.begin() + (long)q);
+            return FTTE_OK;
+        }
+    return fail(c, FTTE_ERR_ARG, "ftte_host_unregister: not a registered array");
+}
+
+long long ftte_counter(const ftte_ctx *c, const char *name)
+{
+    if (!c || !name) return -1;
+    if (!std::strcmp(name, "grid_builds")) return c->n_grid_builds;
+    if (!std::strcmp(name, "plan_builds")) return c->n_plan_builds;
+    if (!std::strcmp(name, "forest_builds")) return c->n_forest_builds;
+    return -1;
 }
 
 int ftte_launch_count(const ftte_ctx *c) { return c ? c->timing_used : 0; }
@@ -1292,6 +1471,7 @@ int ftte_compute_opacities(ftte_ctx *c, int nnu, const double *beta)
     if (nnu < 1 || !beta) return fail(c, FTTE_ERR_ARG, "ftte_compute_opacities: bad argument");
     if (!c->point.medium_ready || c->point.medium_cells != c->ncell) return fail(c, FTTE_ERR_STATE, "no medium: call ftte_set_medium first");
     FTTE_HIP(c, hipSetDevice(c->device));
+    if ((rc = wait_sweep(c))) return rc;
     FTTE_HIP(c, hipStreamSynchronize(c->stream));
     if ((rc = ensure_kappa(c, nnu))) return rc;
     double *dbeta = nullptr;

@@ -1,0 +1,84 @@
+"""The host-array boundary as the reference's driver would use it: the same cell array handed over on every outer
+iteration (the tree is static over a run, equiSources.f90:1230-1843 never rebuilds it), host arrays for kappa and J.
+
+  * ftte_set_grid with the level list the context already holds keeps the tree, the sweep plan and the segment forests
+    (counters of ftte_counter), and the results stay bit-identical;
+  * pageable arrays go through the library's pinned staging blocks, registered arrays by DMA directly: same bits.
+"""
+import numpy as np
+import pytest
+
+import _oracle as O
+import radiativetransfer_amd as rt
+from radiativetransfer_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def test_unchanged_level_list_keeps_tree_plan_and_forests(golden):
+    g = golden("amr8_block_level1")
+    n, level, box = int(g["n"]), g["level"], float(g["box"])
+    with rt.DiffuseTransfer() as e:
+        e.set_grid(n, level, box)
+        e.set_opacity(g["kappa"])
+        J1 = e.transport(g["phi"], g["theta"], g["w"], g["uvb"])
+        assert (e.counter("grid_builds"), e.counter("forest_builds")) == (1, 1)
+        for _ in range(3):  # the drop-in's call sequence, every outer iteration
+            e.set_grid(n, level, box)
+            e.set_opacity(g["kappa"])
+            J2 = e.transport(g["phi"], g["theta"], g["w"], g["uvb"])
+        assert (e.counter("grid_builds"), e.counter("forest_builds")) == (1, 1)
+        assert np.array_equal(J1, J2)
+        # a different box with the same tree: the tree stays, the forests (segment lengths) are rebuilt
+        e.set_grid(n, level, 2 * box)
+        J3 = e.transport(g["phi"], g["theta"], g["w"], g["uvb"])
+        assert (e.counter("grid_builds"), e.counter("forest_builds")) == (1, 2)
+        assert np.array_equal(J3, O.sweep_tree(n, level, g["kappa"], 2 * box, g["phi"], g["theta"], g["w"], g["uvb"],
+                                               arith=O.ARITH_DEVICE))
+        # a different list: everything is rebuilt
+        e.set_uniform_grid(n, box)
+        assert e.counter("grid_builds") == 2
+        assert e.counter("unknown") == -1
+
+
+def test_unchanged_uniform_grid_keeps_the_plan():
+    n = 20
+    kappa, uvb, box = synthetic.uniform_workload(n, 2, seed=5, tau_median=0.3)
+    phi, theta, w = O.healpix_directions(2)
+    with rt.DiffuseTransfer() as e:
+        e.set_uniform_grid(n, box)
+        e.set_opacity(kappa)
+        J1 = e.transport(phi, theta, w, uvb)
+        e.set_uniform_grid(n, box)
+        e.set_opacity(kappa)
+        J2 = e.transport(phi, theta, w, uvb)
+        assert (e.counter("grid_builds"), e.counter("plan_builds")) == (1, 1)
+        assert np.array_equal(J1, J2)
+        J3 = e.transport(phi[:7], theta[:7], w[:7], uvb)  # another direction list: a new plan, the same tree
+        assert (e.counter("grid_builds"), e.counter("plan_builds")) == (1, 2)
+        assert J3.shape == J1.shape
+
+
+def test_registered_and_pageable_host_arrays_give_the_same_bits():
+    """64^3 x 3 groups = 6.3 MB per array: beyond the 1 MiB below which the staging is skipped; 130^3 x 8 = 140 MB crosses
+    several 64 MiB staging blocks in both directions."""
+    for n, nnu in ((64, 3), (130, 8)):
+        kappa, uvb, box = synthetic.uniform_workload(n, nnu, seed=n, tau_median=0.2)
+        phi, theta, w = O.healpix_directions(1)
+        with rt.DiffuseTransfer() as e:
+            e.set_uniform_grid(n, box)
+            e.set_opacity(kappa)
+            J_pageable = e.transport(phi, theta, w, uvb)
+            kap_pinned = kappa.copy()
+            J_pinned = np.empty_like(J_pageable)
+            e.host_register(kap_pinned)
+            e.host_register(J_pinned)
+            e.set_opacity(kap_pinned)
+            e.transport_into(phi, theta, w, uvb, J_pinned)
+            assert np.array_equal(J_pageable, J_pinned)
+            e.host_unregister(J_pinned)
+            e.host_unregister(kap_pinned)
+            with pytest.raises(rt.FtteError):
+                e.host_unregister(J_pinned)
+        if n == 64:
+            assert np.array_equal(J_pageable, O.sweep_uniform(n, kappa, box, phi, theta, w, uvb, arith=O.ARITH_DEVICE))
