@@ -52,6 +52,13 @@ def parse():
     ap.add_argument("--rows", type=int, default=0, help="rays per lane (4/8/16); 0 = library default")
     ap.add_argument("--slots", type=int, default=0, help="directions in flight per launch; 0 = library default")
     ap.add_argument("--waves", type=int, default=0, help="waves per SIMD the kernel is compiled for; 0 = library default")
+    ap.add_argument("--engine", type=int, default=0, help="0 library default, 1 ray-following tiles, 2 cell-fixed bricks")
+    ap.add_argument("--chunk", type=int, default=0, help="bricks: layers per brick; 0 = library default")
+    ap.add_argument("--group", type=int, default=0, help="bricks: directions per group; 0 = library default")
+    ap.add_argument("--brick-waves", type=int, default=0, help="bricks: waves per SIMD the kernel is compiled for")
+    ap.add_argument("--team", type=int, default=-1, help="bricks: 1 one wavefront per direction (default), 0 one wavefront per group")
+    ap.add_argument("--share", type=int, default=-1, help="bricks: accumulator sharing 0/1/2")
+    ap.add_argument("--lanes", type=int, default=0, help="bricks: streams the frequency groups are spread over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=0, help="grid size of the CPU sample (default: --n)")
     return ap.parse_args()
@@ -145,6 +152,20 @@ def main():
         eng.set_option("slots", a.slots)
     if a.waves:
         eng.set_option("waves", a.waves)
+    if a.engine:
+        eng.set_option("engine", a.engine)
+    if a.chunk:
+        eng.set_option("chunk", a.chunk)
+    if a.group:
+        eng.set_option("group", a.group)
+    if a.brick_waves:
+        eng.set_option("brick_waves", a.brick_waves)
+    if a.team >= 0:
+        eng.set_option("team", a.team)
+    if a.share >= 0:
+        eng.set_option("share", a.share)
+    if a.lanes:
+        eng.set_option("lanes", a.lanes)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():

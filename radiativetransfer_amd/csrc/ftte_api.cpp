@@ -63,6 +63,26 @@ struct Plan {
     bool used[3][kMaxSlots] = {};
 };
 
+// The brick organisation of the same sweep (ftte_brick.hip): directions grouped by izone, bricks ordered into stages
+struct BrickPlan {
+    bool valid = false;
+    // key
+    int n = 0, chunk = 0, gmax = 0;
+    double box = 0;
+    std::vector<double> phi, theta, w;
+    // content
+    std::vector<DirPlan> dirs;
+    std::vector<LayerRec> layers;
+    struct Group { int izone = 0, layout = 0, acc = 0, offset = 0; std::vector<int> dirs; };
+    std::vector<Group> groups;
+    std::vector<BrickTask> tasks;      // stage after stage
+    std::vector<size_t> stage_off;     // [nstages + 1] into tasks
+    std::vector<int64_t> stage_updates; // cell.direction updates of a stage (per frequency group)
+    int ntu = 0, ntv = 0, nti = 0, up = 0, vp = 0, max_dirs = 0;
+    int64_t face_elems = 0, vface_off = 0, iface_off = 0;
+    int nacc[3] = {0, 0, 0};
+};
+
 struct LaunchTiming {
     hipEvent_t start = nullptr, stop = nullptr;
     int64_t updates = 0;
@@ -90,10 +110,23 @@ struct ftte_ctx {
     double *emis[3] = {nullptr, nullptr, nullptr};
     bool emis_ready[4] = {false, false, false, false};
 
-    double *acc[3][kMaxSlots] = {};
+    double *acc[3][kMaxAcc] = {};
     size_t acc_cap = 0; // elements per accumulator
 
     int rows = 8, slots = 8, waves = 4, stack = 1;
+
+    // which organisation sweeps a uniform grid: 0 = bricks unless emission is on (the tile kernel has the emission
+    // variants), 1 = tile kernel (sweep_kernel), 2 = bricks (brick_kernel)
+    int engine = 0, chunk = 16, group = 3, brick_waves = 4, share = 2, team = 0, lanes = 2; // measured best at 256^3 x 8 x 96
+    std::vector<hipStream_t> lane_stream;   // extra streams of the brick sweep (frequency groups are independent)
+    std::vector<hipEvent_t> lane_done;
+    hipEvent_t ev_fork = nullptr;
+    BrickPlan bplan;
+    bool bplan_uploaded = false;
+    LayerRec *d_blayers = nullptr; size_t d_blayers_cap = 0;
+    BrickGroup *d_bgroups = nullptr; size_t d_bgroups_cap = 0;
+    BrickTask *d_btasks = nullptr; size_t d_btasks_cap = 0;
+    double *d_faces = nullptr; size_t d_faces_cap = 0;
 
     Plan plan;
     LayerRec *d_layers = nullptr; size_t d_layers_cap = 0;
@@ -187,6 +220,91 @@ int fold_status(int rc)
 }
 
 // ---- planner ------------------------------------------------------------------------------------
+// One direction: fold it (equiSources.f90:1395-1454), build its per-layer patterns (:1495-1534, setPattern) and turn them
+// into what the kernels read: the memory frame of its izone and one LayerRec per layer.
+int plan_direction(ftte_ctx *c, int d, double phi_d, double theta_d, double w_d, int tile_rows, std::vector<ftte_pattern> &pat,
+                   std::vector<int> &du_cum, std::vector<int> &dv_cum, DirPlan &D, LayerRec *layers_of_d, size_t layer_off)
+{
+    const int n = c->n;
+    const double cell = c->box / (double)n; // cellSizeAbsoluteUnits, equiSources.f90:1570
+    const long nn = (long)n * n;
+    D.w = w_d;
+
+    int rc = fold_direction(phi_d, theta_d, &D.phi, &D.theta, &D.izone);
+    if (rc) {
+        char buf[160];
+        std::snprintf(buf, sizeof buf, "direction %d (phi=%.17g, theta=%.17g) cannot be folded: %s", d, phi_d, theta_d,
+                      rc == 1 ? "phi on a quadrant boundary" : rc == 2 ? "theta outside (-pi/2,0)u(0,pi/2)"
+                                                                       : "tie between dominant axes");
+        return fail(c, fold_status(rc), buf);
+    }
+    if (layer_patterns(n, D.phi, D.theta, pat.data())) {
+        char buf[128];
+        std::snprintf(buf, sizeof buf, "direction %d: ray pattern left the unit cell (setPattern consistency check)", d);
+        return fail(c, FTTE_ERR_PATTERN, buf);
+    }
+
+    // memory frame of this izone: which storage axis the march runs along decides the layout;
+    // within it u = the sweep axis that lands on the contiguous storage axis
+    ZoneMap zm;
+    zone_map(D.izone, &zm);
+    int march_c = 0;
+    for (int a = 0; a < 3; ++a) if (zm.src[a] == 0) march_c = a;
+    D.layout = march_c;
+    const int fast_c = (march_c == 2) ? 1 : 2;
+    const int mid_c = (march_c == 0) ? 1 : 0;
+    const bool u_is_k = zm.src[fast_c] == 2;
+    D.su = zm.mirror[fast_c] ? -1 : 1;
+    D.sv = zm.mirror[mid_c] ? -n : n;
+    D.si = (int)(zm.mirror[march_c] ? -nn : nn);
+    // the column enters as a position p = u (or n+1-u when mirrored) with stride +1: offset p - 1
+    D.org = -1 + (zm.mirror[mid_c] ? (long)n * n : -(long)n) +
+            (zm.mirror[march_c] ? (long)n * nn : -nn);
+
+    // layers: reference chain -> kernel-frame class, lengths in chain order, cumulative drift
+    D.layer_off = layer_off;
+    int du = 0, dv = 0;
+    for (int i = 0; i < n; ++i) {
+        const ftte_pattern &p = pat[i];
+        LayerRec &R = layers_of_d[i];
+        R.dpath[0] = cell * p.xy_len;
+        R.dpath[1] = R.dpath[2] = 0.0;
+        int rc_class = RC_ONE, step_k = 0, step_j = 0;
+        if (p.xz_active && p.yz_active) {
+            step_k = step_j = 1;
+            if (p.xy_top == 3) { // xy -> yz -> xz (the xz piece reaches the top)
+                R.dpath[1] = cell * p.yz_len; R.dpath[2] = cell * p.xz_len;
+                rc_class = u_is_k ? RC_THREE_U_SWAP : RC_THREE_V_SWAP; // mean adds xy, xz, yz: 3rd piece before 2nd
+            } else {             // xy -> xz -> yz
+                R.dpath[1] = cell * p.xz_len; R.dpath[2] = cell * p.yz_len;
+                rc_class = u_is_k ? RC_THREE_V : RC_THREE_U;
+            }
+        } else if (p.yz_active) { // xy -> yz: one cell further along sweep-k
+            step_k = 1;
+            R.dpath[1] = cell * p.yz_len;
+            rc_class = u_is_k ? RC_TWO_U : RC_TWO_V;
+        } else if (p.xz_active) { // xy -> xz: one cell further along sweep-j
+            step_j = 1;
+            R.dpath[1] = cell * p.xz_len;
+            rc_class = u_is_k ? RC_TWO_V : RC_TWO_U;
+        }
+        R.info = rc_class;
+        R.drift = (du & 0xffff) | (dv << 16);
+        du_cum[i] = du; dv_cum[i] = dv;
+        du += u_is_k ? step_k : step_j;
+        dv += u_is_k ? step_j : step_k;
+    }
+    // rays present at the last layer start at label -drift (base cell 0, second piece in cell 1)
+    D.u_lo = 1 - du_cum[n - 1];
+    D.v_lo = 1 - dv_cum[n - 1];
+    D.du_mid = du_cum[n / 2];
+    D.dv_mid = dv_cum[n / 2];
+    D.ntu = (n - D.u_lo + 1 + 62) / 63;
+    D.ntv = (n - D.v_lo + 1 + tile_rows - 1) / tile_rows;
+
+    return FTTE_OK;
+}
+
 // Turns the direction list into what the kernel consumes.  O(ndir * (n + tiles)) host work,
 // cached in the context for as long as the directions, the grid and the tuning stay the same.
 int build_plan(ftte_ctx *c, int rows, int stack, int ndir, const double *phi, const double *theta, const double *w)
@@ -208,86 +326,14 @@ int build_plan(ftte_ctx *c, int rows, int stack, int ndir, const double *phi, co
     P.layers.resize((size_t)ndir * n);
     c->plan_uploaded = false;
 
-    const double cell = c->box / (double)n; // cellSizeAbsoluteUnits, equiSources.f90:1570
     std::vector<ftte_pattern> pat(n);
     std::vector<int> du_cum(n + 1), dv_cum(n + 1);
     int in_layout[3] = {0, 0, 0};
-    const long nn = (long)n * n;
 
     for (int d = 0; d < ndir; ++d) {
         DirPlan &D = P.dirs[d];
-        D.w = w[d];
-        int rc = fold_direction(phi[d], theta[d], &D.phi, &D.theta, &D.izone);
-        if (rc) {
-            char buf[160];
-            std::snprintf(buf, sizeof buf, "direction %d (phi=%.17g, theta=%.17g) cannot be folded: %s", d, phi[d], theta[d],
-                          rc == 1 ? "phi on a quadrant boundary" : rc == 2 ? "theta outside (-pi/2,0)u(0,pi/2)"
-                                                                           : "tie between dominant axes");
-            return fail(c, fold_status(rc), buf);
-        }
-        if (layer_patterns(n, D.phi, D.theta, pat.data())) {
-            char buf[128];
-            std::snprintf(buf, sizeof buf, "direction %d: ray pattern left the unit cell (setPattern consistency check)", d);
-            return fail(c, FTTE_ERR_PATTERN, buf);
-        }
-
-        // memory frame of this izone: which storage axis the march runs along decides the layout;
-        // within it u = the sweep axis that lands on the contiguous storage axis
-        ZoneMap zm;
-        zone_map(D.izone, &zm);
-        int march_c = 0;
-        for (int a = 0; a < 3; ++a) if (zm.src[a] == 0) march_c = a;
-        D.layout = march_c;
-        const int fast_c = (march_c == 2) ? 1 : 2;
-        const int mid_c = (march_c == 0) ? 1 : 0;
-        const bool u_is_k = zm.src[fast_c] == 2;
-        D.su = zm.mirror[fast_c] ? -1 : 1;
-        D.sv = zm.mirror[mid_c] ? -n : n;
-        D.si = (int)(zm.mirror[march_c] ? -nn : nn);
-        // the column enters as a position p = u (or n+1-u when mirrored) with stride +1: offset p - 1
-        D.org = -1 + (zm.mirror[mid_c] ? (long)n * n : -(long)n) +
-                (zm.mirror[march_c] ? (long)n * nn : -nn);
-
-        // layers: reference chain -> kernel-frame class, lengths in chain order, cumulative drift
-        D.layer_off = (size_t)d * n;
-        int du = 0, dv = 0;
-        for (int i = 0; i < n; ++i) {
-            const ftte_pattern &p = pat[i];
-            LayerRec &R = P.layers[D.layer_off + i];
-            R.dpath[0] = cell * p.xy_len;
-            R.dpath[1] = R.dpath[2] = 0.0;
-            int rc_class = RC_ONE, step_k = 0, step_j = 0;
-            if (p.xz_active && p.yz_active) {
-                step_k = step_j = 1;
-                if (p.xy_top == 3) { // xy -> yz -> xz (the xz piece reaches the top)
-                    R.dpath[1] = cell * p.yz_len; R.dpath[2] = cell * p.xz_len;
-                    rc_class = u_is_k ? RC_THREE_U_SWAP : RC_THREE_V_SWAP; // mean adds xy, xz, yz: 3rd piece before 2nd
-                } else {             // xy -> xz -> yz
-                    R.dpath[1] = cell * p.xz_len; R.dpath[2] = cell * p.yz_len;
-                    rc_class = u_is_k ? RC_THREE_V : RC_THREE_U;
-                }
-            } else if (p.yz_active) { // xy -> yz: one cell further along sweep-k
-                step_k = 1;
-                R.dpath[1] = cell * p.yz_len;
-                rc_class = u_is_k ? RC_TWO_U : RC_TWO_V;
-            } else if (p.xz_active) { // xy -> xz: one cell further along sweep-j
-                step_j = 1;
-                R.dpath[1] = cell * p.xz_len;
-                rc_class = u_is_k ? RC_TWO_V : RC_TWO_U;
-            }
-            R.info = rc_class;
-            R.drift = (du & 0xffff) | (dv << 16);
-            du_cum[i] = du; dv_cum[i] = dv;
-            du += u_is_k ? step_k : step_j;
-            dv += u_is_k ? step_j : step_k;
-        }
-        // rays present at the last layer start at label -drift (base cell 0, second piece in cell 1)
-        D.u_lo = 1 - du_cum[n - 1];
-        D.v_lo = 1 - dv_cum[n - 1];
-        D.du_mid = du_cum[n / 2];
-        D.dv_mid = dv_cum[n / 2];
-        D.ntu = (n - D.u_lo + 1 + 62) / 63;
-        D.ntv = (n - D.v_lo + 1 + tile_rows - 1) / tile_rows;
+        const int rc = plan_direction(c, d, phi[d], theta[d], w[d], tile_rows, pat, du_cum, dv_cum, D, &P.layers[(size_t)d * n], (size_t)d * n);
+        if (rc) return rc;
         D.slot = in_layout[D.layout]++ % slots;
     }
 
@@ -359,6 +405,160 @@ int build_plan(ftte_ctx *c, int rows, int stack, int ndir, const double *phi, co
                 std::copy(sorted.begin(), sorted.end(), P.items.begin() + LP.item_off);
             }
             P.launches.push_back(LP);
+        }
+    }
+    P.valid = true;
+    return FTTE_OK;
+}
+
+// Bricks: group the directions by izone (input order within an izone, at most `group` per group), cut the grid into
+// bricks of 64 x kBrickRows x chunk cells, and order the bricks of every group into stages tu + tv + ti: a brick's three
+// upstream neighbours lie one stage earlier, its consumers exactly one stage later (which is what lets the face buffers be
+// rings over two chunks).  Pure host work, cached like the tile plan.
+int build_brick_plan(ftte_ctx *c, int ndir, const double *phi, const double *theta, const double *w)
+{
+    BrickPlan &P = c->bplan;
+    const int n = c->n, chunk = std::min(c->chunk, n), gmax = c->group;
+    if (P.valid && P.n == n && P.chunk == chunk && P.gmax == gmax && P.box == c->box && (int)P.phi.size() == ndir &&
+        (ndir == 0 || (!std::memcmp(P.phi.data(), phi, sizeof(double) * ndir) &&
+                       !std::memcmp(P.theta.data(), theta, sizeof(double) * ndir) &&
+                       !std::memcmp(P.w.data(), w, sizeof(double) * ndir))))
+        return FTTE_OK;
+
+    ++c->n_plan_builds;
+    P = BrickPlan();
+    P.n = n; P.chunk = chunk; P.gmax = gmax; P.box = c->box;
+    P.phi.assign(phi, phi + ndir); P.theta.assign(theta, theta + ndir); P.w.assign(w, w + ndir);
+    P.dirs.resize(ndir);
+    P.layers.resize((size_t)ndir * n);
+    c->bplan_uploaded = false;
+
+    std::vector<ftte_pattern> pat(n);
+    std::vector<int> du_cum(n + 1), dv_cum(n + 1);
+    for (int d = 0; d < ndir; ++d) {
+        const int rc = plan_direction(c, d, phi[d], theta[d], w[d], 7, pat, du_cum, dv_cum, P.dirs[d], &P.layers[(size_t)d * n], (size_t)d * n);
+        if (rc) return rc;
+    }
+    P.ntu = (n + 63) / 64; P.ntv = (n + kBrickRows - 1) / kBrickRows; P.nti = (n + chunk - 1) / chunk;
+    P.up = 64 * P.ntu; P.vp = kBrickRows * P.ntv;
+    P.vface_off = (int64_t)P.ntu * 2 * chunk * P.vp;
+    P.iface_off = P.vface_off + (int64_t)P.ntv * 2 * chunk * P.up;
+    P.face_elems = P.iface_off + (int64_t)2 * P.vp * P.up;
+
+    if (P.nti >= kBrickAccumulate) return fail(c, FTTE_ERR_UNSUPPORTED, "brick engine: more than 16383 chunks along the march axis: raise option \"chunk\"");
+
+    // Groups: layout after layout (the order in which the merge adds the accumulators), izone after izone, at most gmax
+    // directions each.  Accumulators: a group stores its J contribution once per cell, and every accumulator costs the merge
+    // one more read of the grid, so groups share an accumulator where they provably never meet in a brick in the same launch
+    // (the later one then reads, adds and stores, BrickTask):
+    //   * the passes of one izone sweep the bricks in the same order: started in different launches they never meet;
+    //   * two izones of one layout differ by reflections of the brick order along some axes; with t -> N-1-t along an axis
+    //     of even brick count N the difference of their stage numbers in a brick changes by an odd amount, so if an odd number
+    //     of such axes is reflected the difference is odd in every brick, and start launches that differ by an even number
+    //     never bring them together.  Needs bricks that coincide under reflection: n a multiple of 64, 8 and the chunk.
+    const bool aligned = n % 64 == 0 && n % kBrickRows == 0 && n % chunk == 0;
+    const int nbricks[3] = {P.ntu, P.ntv, P.nti};
+    for (int layout = 0; layout < 3; ++layout) {
+        struct Zone { int izone, parity; std::vector<std::vector<int>> passes; };
+        std::vector<Zone> zones;
+        for (int izone = 1; izone <= 24; ++izone) {
+            std::vector<int> members;
+            for (int d = 0; d < ndir; ++d)
+                if (P.dirs[d].izone == izone && P.dirs[d].layout == layout) members.push_back(d);
+            if (members.empty()) continue;
+            Zone Z;
+            Z.izone = izone;
+            const DirPlan &D0 = P.dirs[members[0]];
+            const bool mirror[3] = {D0.su < 0, D0.sv < 0, D0.si < 0};
+            Z.parity = 0;
+            for (int a = 0; a < 3; ++a) if (mirror[a] && nbricks[a] % 2 == 0) Z.parity ^= 1;
+            // as few passes as gmax allows, of equal size where possible (5 directions, gmax 4: 3 + 2, not 4 + 1)
+            const size_t npass = (members.size() + (size_t)gmax - 1) / (size_t)gmax;
+            for (size_t b = 0, q = 0; q < npass; ++q) {
+                const size_t len = members.size() / npass + (q < members.size() % npass ? 1 : 0);
+                Z.passes.emplace_back(members.begin() + (long)b, members.begin() + (long)(b + len));
+                b += len;
+            }
+            zones.push_back(Z);
+        }
+        // pair the izones of opposite parity (share = 2); share = 1: only the passes of one izone share; 0: nobody shares
+        std::vector<int> partner(zones.size(), -1);
+        if (aligned && c->share >= 2)
+            for (size_t x = 0; x < zones.size(); ++x) {
+                if (partner[x] >= 0) continue;
+                for (size_t y = x + 1; y < zones.size(); ++y)
+                    if (partner[y] < 0 && zones[y].parity != zones[x].parity) { partner[x] = (int)y; partner[y] = (int)x; break; }
+            }
+        std::vector<int> acc_of(zones.size(), -1);
+        for (size_t x = 0; x < zones.size(); ++x) {
+            const bool paired = partner[x] >= 0;
+            if (c->share >= 1) {
+                if (acc_of[x] < 0) {
+                    acc_of[x] = P.nacc[layout]++;
+                    if (paired) acc_of[(size_t)partner[x]] = acc_of[x];
+                }
+            }
+            for (size_t p = 0; p < zones[x].passes.size(); ++p) {
+                BrickPlan::Group G;
+                G.izone = zones[x].izone; G.layout = layout;
+                G.acc = c->share >= 1 ? acc_of[x] : P.nacc[layout]++;
+                G.offset = c->share >= 1 ? (int)p * (paired ? 2 : 1) : 0;
+                G.dirs = zones[x].passes[p];
+                P.max_dirs = std::max(P.max_dirs, (int)G.dirs.size());
+                P.groups.push_back(G);
+            }
+        }
+    }
+    for (int layout = 0; layout < 3; ++layout)
+        if (P.nacc[layout] > kMaxAcc) return fail(c, FTTE_ERR_UNSUPPORTED, "too many direction groups for one memory layout: raise option \"group\"");
+
+    int max_offset = 0;
+    for (const auto &G : P.groups) max_offset = std::max(max_offset, G.offset);
+    const int nstages = P.groups.empty() ? 0 : P.ntu + P.ntv + P.nti - 2 + max_offset;
+    P.stage_off.assign((size_t)nstages + 1, 0);
+    P.stage_updates.assign((size_t)nstages, 0);
+    if (!P.groups.empty()) {
+        // launch in which each accumulator's cells are first written, per physical brick: whoever comes later accumulates
+        const size_t nb = (size_t)P.ntu * P.ntv * P.nti;
+        std::vector<std::vector<int>> first(3 * (size_t)kMaxAcc);
+        auto brick_of = [&](const BrickPlan::Group &G, int tu, int tv, int ti) {
+            const DirPlan &D0 = P.dirs[G.dirs[0]];
+            const int bu = D0.su < 0 ? P.ntu - 1 - tu : tu, bv = D0.sv < 0 ? P.ntv - 1 - tv : tv, bi = D0.si < 0 ? P.nti - 1 - ti : ti;
+            return ((size_t)bi * P.ntv + bv) * P.ntu + bu;
+        };
+        for (const auto &G : P.groups) {
+            std::vector<int> &F = first[(size_t)G.layout * kMaxAcc + G.acc];
+            if (F.empty()) F.assign(nb, 1 << 30);
+            for (int ti = 0; ti < P.nti; ++ti)
+                for (int tv = 0; tv < P.ntv; ++tv)
+                    for (int tu = 0; tu < P.ntu; ++tu) {
+                        int &f = F[brick_of(G, tu, tv, ti)];
+                        f = std::min(f, tu + tv + ti + G.offset);
+                    }
+        }
+        for (int pass = 0; pass < 2; ++pass) { // count, then fill
+            std::vector<size_t> fill(P.stage_off.begin(), P.stage_off.end() - 1);
+            for (size_t g = 0; g < P.groups.size(); ++g) {
+                const BrickPlan::Group &G = P.groups[g];
+                const std::vector<int> &F = first[(size_t)G.layout * kMaxAcc + G.acc];
+                for (int ti = 0; ti < P.nti; ++ti)
+                    for (int tv = 0; tv < P.ntv; ++tv)
+                        for (int tu = 0; tu < P.ntu; ++tu) {
+                            const int st = tu + tv + ti + G.offset;
+                            if (!pass) { ++P.stage_off[(size_t)st + 1]; continue; }
+                            BrickTask T;
+                            T.group = (int16_t)g; T.tu = (int16_t)tu; T.tv = (int16_t)tv;
+                            T.ti = (int16_t)(ti | (st > F[brick_of(G, tu, tv, ti)] ? kBrickAccumulate : 0));
+                            P.tasks[fill[(size_t)st]++] = T;
+                            const int64_t cu = std::min(64, n - 64 * tu), cv = std::min(kBrickRows, n - kBrickRows * tv),
+                                          ci = std::min(chunk, n - chunk * ti);
+                            P.stage_updates[(size_t)st] += cu * cv * ci * (int64_t)G.dirs.size();
+                        }
+            }
+            if (!pass) {
+                for (int st = 0; st < nstages; ++st) P.stage_off[(size_t)st + 1] += P.stage_off[(size_t)st];
+                P.tasks.resize(P.stage_off[(size_t)nstages]);
+            }
         }
     }
     P.valid = true;
@@ -586,6 +786,154 @@ int forest_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
 }
 
 
+// The sweep of a uniform grid by cell-fixed bricks (ftte_brick.hip): one launch per stage, then one merge of the groups'
+// accumulators (layout after layout, group after group: a fixed order) into J.
+int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, const double *w, const double *uvb, double *J_dev,
+                hipStream_t stream)
+{
+    int rc;
+    if ((rc = build_brick_plan(c, ndir, phi, theta, w))) return rc;
+    BrickPlan &P = c->bplan;
+    const int n = c->n, nnu = c->nnu;
+    const size_t per_acc = (size_t)nnu * c->ncell;
+
+    // everything below overwrites device tables the previous sweep may still be reading
+    if ((rc = wait_sweep(c))) return rc;
+    FTTE_HIP(c, hipStreamSynchronize(stream));
+    if (stream != c->stream) FTTE_HIP(c, hipStreamSynchronize(c->stream));
+
+    if (c->acc_cap < per_acc) {
+        for (int l = 0; l < 3; ++l)
+            for (int s = 0; s < kMaxAcc; ++s)
+                if (c->acc[l][s]) { FTTE_HIP(c, hipFree(c->acc[l][s])); c->acc[l][s] = nullptr; }
+        c->acc_cap = per_acc;
+    }
+    const size_t face_need = (size_t)ndir * nnu * (size_t)P.face_elems;
+    if ((rc = ensure(c, &c->d_faces, &c->d_faces_cap, face_need))) return rc;
+    if (!c->merge_stream) {
+        FTTE_HIP(c, hipStreamCreateWithFlags(&c->merge_stream, hipStreamNonBlocking));
+        FTTE_HIP(c, hipEventCreateWithFlags(&c->ev_layout_done, hipEventDisableTiming));
+        FTTE_HIP(c, hipEventCreateWithFlags(&c->ev_merge_done, hipEventDisableTiming));
+        FTTE_HIP(c, hipEventCreateWithFlags(&c->ev_layouts_ready, hipEventDisableTiming));
+    }
+    // accumulators and the opacity in the layouts the groups march through
+    bool transposed = false;
+    for (int l = 0; l < 3; ++l) {
+        for (int s = 0; s < P.nacc[l]; ++s)
+            if (!c->acc[l][s]) FTTE_HIP(c, hipMalloc((void **)&c->acc[l][s], sizeof(double) * c->acc_cap));
+        if (P.nacc[l] && !c->kappa_ready[l]) {
+            if (!c->kappa[l]) FTTE_HIP(c, hipMalloc((void **)&c->kappa[l], sizeof(double) * c->kappa_cap));
+            if (launch_to_layout(l, c->kappa[0], c->kappa[l], n, nnu, (long)c->ncell, stream))
+                return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
+            c->kappa_ready[l] = true;
+            transposed = true;
+        }
+    }
+    (void)transposed;
+
+    if (!c->bplan_uploaded || c->d_faces_cap != face_need) {
+        if ((rc = ensure(c, &c->d_blayers, &c->d_blayers_cap, P.layers.size()))) return rc;
+        if ((rc = ensure(c, &c->d_btasks, &c->d_btasks_cap, P.tasks.size()))) return rc;
+        if ((rc = ensure(c, &c->d_bgroups, &c->d_bgroups_cap, P.groups.size()))) return rc;
+        if (!P.layers.empty())
+            FTTE_HIP(c, hipMemcpy(c->d_blayers, P.layers.data(), sizeof(LayerRec) * P.layers.size(), hipMemcpyHostToDevice));
+        if (!P.tasks.empty())
+            FTTE_HIP(c, hipMemcpy(c->d_btasks, P.tasks.data(), sizeof(BrickTask) * P.tasks.size(), hipMemcpyHostToDevice));
+        c->bplan_uploaded = true;
+    }
+    // the group records carry pointers that depend on nnu (face blocks) and on the buffers: rebuilt per sweep (a few KB)
+    {
+        std::vector<BrickGroup> G(P.groups.size());
+        std::memset(G.data(), 0, sizeof(BrickGroup) * G.size());
+        for (size_t g = 0; g < P.groups.size(); ++g) {
+            const BrickPlan::Group &H = P.groups[g];
+            const DirPlan &D0 = P.dirs[H.dirs[0]];
+            G[g].kappa = c->kappa[H.layout];
+            G[g].J = c->acc[H.layout][H.acc];
+            G[g].org = D0.org; G[g].si = D0.si; G[g].sv = D0.sv; G[g].su = D0.su;
+            G[g].ndir = (int)H.dirs.size();
+            for (size_t q = 0; q < H.dirs.size(); ++q) {
+                const int d = H.dirs[q];
+                G[g].dir[q].layers = c->d_blayers + P.dirs[d].layer_off;
+                G[g].dir[q].faces = c->d_faces + (size_t)d * nnu * (size_t)P.face_elems;
+                G[g].dir[q].w = P.dirs[d].w;
+            }
+        }
+        if (!G.empty()) FTTE_HIP(c, hipMemcpy(c->d_bgroups, G.data(), sizeof(BrickGroup) * G.size(), hipMemcpyHostToDevice));
+    }
+    if ((rc = ensure(c, &c->d_uvb, &c->d_uvb_cap, (size_t)nnu))) return rc;
+    FTTE_HIP(c, hipMemcpy(c->d_uvb, uvb, sizeof(double) * nnu, hipMemcpyHostToDevice));
+
+    // The frequency groups never touch each other's data (own slices of the accumulators and of the face rings), and a
+    // stage is a launch that drains before the next one starts: the stage sequence is therefore issued once per "lane"
+    // (a subset of the frequency groups) on streams of their own, so that the tail of one lane's stage overlaps the next
+    // stage of another.  Lane 0 is the caller's stream.  One pair of events brackets the whole phase: with kernels of
+    // several streams in flight together the time of a single launch says little.
+    const size_t nstages = P.stage_updates.size();
+    const int nlanes = std::max(1, std::min(c->lanes, nnu));
+    while ((int)c->lane_stream.size() < nlanes - 1) {
+        hipStream_t q; hipEvent_t e;
+        FTTE_HIP(c, hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+        FTTE_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->lane_stream.push_back(q); c->lane_done.push_back(e);
+    }
+    if (!c->ev_fork) FTTE_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    while (c->timing.size() < 1) {
+        LaunchTiming t;
+        FTTE_HIP(c, hipEventCreate(&t.start));
+        FTTE_HIP(c, hipEventCreate(&t.stop));
+        c->timing.push_back(t);
+    }
+    c->timing_used = 0;
+
+    static const ftte_consts kMath = FTTE_CONSTS_INIT;
+    if (!P.groups.empty()) {
+        LaunchTiming &T = c->timing[0];
+        T.updates = 0;
+        for (size_t st = 0; st < nstages; ++st) T.updates += P.stage_updates[st] * nnu;
+        FTTE_HIP(c, hipEventRecord(T.start, stream));
+        FTTE_HIP(c, hipEventRecord(c->ev_fork, stream));
+        for (int lane = 0; lane < nlanes; ++lane) {
+            hipStream_t q = lane == 0 ? stream : c->lane_stream[(size_t)lane - 1];
+            if (lane) FTTE_HIP(c, hipStreamWaitEvent(q, c->ev_fork, 0));
+            const int nu0 = (int)((int64_t)nnu * lane / nlanes), nu1 = (int)((int64_t)nnu * (lane + 1) / nlanes);
+            for (size_t st = 0; st < nstages; ++st) {
+                BrickLaunch L;
+                std::memset(&L, 0, sizeof L);
+                L.groups = c->d_bgroups;
+                L.tasks = c->d_btasks + P.stage_off[st];
+                L.uvb = c->d_uvb;
+                L.group_stride = c->ncell;
+                L.face_stride = P.face_elems;
+                L.vface_off = P.vface_off; L.iface_off = P.iface_off;
+                L.n = n; L.ntasks = (int)(P.stage_off[st + 1] - P.stage_off[st]); L.nnu = nu1 - nu0; L.nu0 = nu0; L.chunk = P.chunk;
+                L.up = P.up; L.vp = P.vp;
+                L.math = kMath;
+                const int lrc = c->team ? launch_brick_team(L, P.max_dirs, c->brick_waves, q) : launch_brick(L, P.max_dirs, c->brick_waves, q);
+                if (lrc) return fail(c, lrc == -1 ? FTTE_ERR_ARG : FTTE_ERR_NO_DEVICE, "brick kernel launch failed");
+            }
+            if (lane) {
+                FTTE_HIP(c, hipEventRecord(c->lane_done[(size_t)lane - 1], q));
+                FTTE_HIP(c, hipStreamWaitEvent(stream, c->lane_done[(size_t)lane - 1], 0));
+            }
+        }
+        FTTE_HIP(c, hipEventRecord(T.stop, stream));
+        c->timing_used = 1;
+    }
+    // J = the groups' accumulators, layout after layout
+    {
+        const double *accs[3 * kMaxAcc];
+        int layouts[3 * kMaxAcc], count = 0;
+        for (int l = 0; l < 3; ++l)
+            for (int s = 0; s < P.nacc[l]; ++s) { accs[count] = c->acc[l][s]; layouts[count++] = l; }
+        if (count) {
+            if (launch_merge(accs, layouts, count, J_dev, n, nnu, (long)c->ncell, false, stream))
+                return fail(c, FTTE_ERR_NO_DEVICE, "merge kernel launch failed");
+        } else FTTE_HIP(c, hipMemsetAsync(J_dev, 0, sizeof(double) * (size_t)nnu * c->ncell, stream)); // no directions
+    }
+    return mark_sweep(c, stream);
+}
+
 // ---- host arrays across PCIe ------------------------------------------------------------------------------------
 constexpr size_t kStageBytes = (size_t)64 << 20;
 
@@ -721,8 +1069,12 @@ int ftte_destroy(ftte_ctx *c)
     for (int l = 0; l < 3; ++l) {
         if (c->kappa[l]) (void)hipFree(c->kappa[l]);
         if (c->emis[l]) (void)hipFree(c->emis[l]);
-        for (int s = 0; s < kMaxSlots; ++s) if (c->acc[l][s]) (void)hipFree(c->acc[l][s]);
+        for (int s = 0; s < kMaxAcc; ++s) if (c->acc[l][s]) (void)hipFree(c->acc[l][s]);
     }
+    if (c->d_blayers) (void)hipFree(c->d_blayers);
+    if (c->d_bgroups) (void)hipFree(c->d_bgroups);
+    if (c->d_btasks) (void)hipFree(c->d_btasks);
+    if (c->d_faces) (void)hipFree(c->d_faces);
     if (c->d_layers) (void)hipFree(c->d_layers);
     if (c->d_items) (void)hipFree(c->d_items);
     if (c->d_uvb) (void)hipFree(c->d_uvb);
@@ -736,6 +1088,9 @@ int ftte_destroy(ftte_ctx *c)
     if (c->ev_merge_done) (void)hipEventDestroy(c->ev_merge_done);
     if (c->ev_layouts_ready) (void)hipEventDestroy(c->ev_layouts_ready);
     if (c->ev_sweep_done) (void)hipEventDestroy(c->ev_sweep_done);
+    for (auto &q : c->lane_stream) (void)hipStreamDestroy(q);
+    for (auto &e : c->lane_done) (void)hipEventDestroy(e);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->host_J_dev) (void)hipFree(c->host_J_dev);
     for (int q = 0; q < 2; ++q) {
         if (c->stage[q]) (void)hipHostFree(c->stage[q]);
@@ -785,7 +1140,7 @@ int ftte_set_grid(ftte_ctx *c, int nx, int ny, int nz, int64_t ncell, const int3
         for (int l = 0; l < 3; ++l) {
             if (c->kappa[l]) { (void)hipFree(c->kappa[l]); c->kappa[l] = nullptr; }
             if (c->emis[l]) { (void)hipFree(c->emis[l]); c->emis[l] = nullptr; }
-            for (int s = 0; s < kMaxSlots; ++s) if (c->acc[l][s]) { (void)hipFree(c->acc[l][s]); c->acc[l][s] = nullptr; }
+            for (int s = 0; s < kMaxAcc; ++s) if (c->acc[l][s]) { (void)hipFree(c->acc[l][s]); c->acc[l][s] = nullptr; }
         }
         c->emit_mode = 0;
         if (c->amr_Iout) { (void)hipFree(c->amr_Iout); c->amr_Iout = nullptr; }
@@ -804,6 +1159,7 @@ int ftte_set_grid(ftte_ctx *c, int nx, int ny, int nz, int64_t ncell, const int3
     c->n = nx; c->ncell = ncell; c->box = box_cm; c->grid_set = true;
     c->kappa_ready[0] = c->kappa_ready[1] = c->kappa_ready[2] = c->kappa_ready[3] = false;
     c->plan.valid = false;
+    c->bplan.valid = false;
     c->tree = std::move(tree);
     c->use_forest = c->tree.refined() || c->force_forest;
     return FTTE_OK;
@@ -909,11 +1265,33 @@ int ftte_set_option(ftte_ctx *c, const char *key, int value)
     } else if (!std::strcmp(key, "ldspad")) {
         if (value < 0 || value > 160 * 1024) return fail(c, FTTE_ERR_ARG, "ldspad must be 0..163840 bytes");
         set_lds_pad(value);
+    } else if (!std::strcmp(key, "engine")) {
+        if (value < 0 || value > 2) return fail(c, FTTE_ERR_ARG, "engine must be 0 (automatic), 1 (ray-following tiles) or 2 (cell-fixed bricks)");
+        c->engine = value;
+    } else if (!std::strcmp(key, "chunk")) {
+        if (value < 1 || value > 4096) return fail(c, FTTE_ERR_ARG, "chunk (layers per brick) must be 1..4096");
+        c->chunk = value;
+    } else if (!std::strcmp(key, "group")) {
+        if (value < 1 || value > kBrickMaxDirs) return fail(c, FTTE_ERR_ARG, "group (directions sharing a brick pass) must be 1..8");
+        c->group = value;
+    } else if (!std::strcmp(key, "lanes")) {
+        if (value < 1 || value > 16) return fail(c, FTTE_ERR_ARG, "lanes (streams the brick sweep spreads its frequency groups over) must be 1..16");
+        c->lanes = value;
+    } else if (!std::strcmp(key, "team")) {
+        if (value != 0 && value != 1) return fail(c, FTTE_ERR_ARG, "team must be 0 (one wavefront sweeps a group's directions in turn) or 1 (one wavefront per direction)");
+        c->team = value;
+    } else if (!std::strcmp(key, "share")) {
+        if (value < 0 || value > 2) return fail(c, FTTE_ERR_ARG, "share (groups sharing a J accumulator) must be 0 (none), 1 (passes of one izone) or 2 (and izone pairs)");
+        c->share = value;
+    } else if (!std::strcmp(key, "brick_waves")) {
+        if (value < 2 || value > 4) return fail(c, FTTE_ERR_ARG, "brick_waves must be 2..4");
+        c->brick_waves = value;
     } else if (!std::strcmp(key, "stack")) {
         if (value != 1 && value != 2 && value != 4 && value != 8) return fail(c, FTTE_ERR_ARG, "stack must be 1, 2, 4 or 8");
         c->stack = value;
     } else return fail(c, FTTE_ERR_ARG, std::string("unknown option: ") + key);
     c->plan.valid = false;
+    c->bplan.valid = false;
     return FTTE_OK;
 }
 
@@ -930,6 +1308,10 @@ int ftte_diffuse_sweep_device(ftte_ctx *c, int ndir, const double *phi, const do
     const size_t per_acc = (size_t)nnu * c->ncell;
 
     if (c->use_forest) return forest_sweep(c, ndir, phi, theta, w, uvb, J_dev, stream);
+    if (c->engine == 2 || (c->engine == 0 && !c->emit_mode)) {
+        if (c->emit_mode) return fail(c, FTTE_ERR_UNSUPPORTED, "the brick engine has no emission variant: set option \"engine\" to 0 or 1");
+        return brick_sweep(c, ndir, phi, theta, w, uvb, J_dev, stream);
+    }
     // the emission variants of the tiled kernel are built for one shape
     const int rows = c->emit_mode ? 8 : c->rows, stack = c->emit_mode ? 1 : c->stack;
     if ((rc = build_plan(c, rows, stack, ndir, phi, theta, w))) return rc;
@@ -955,7 +1337,7 @@ int ftte_diffuse_sweep_device(ftte_ctx *c, int ndir, const double *phi, const do
     // accumulators sized for this nnu
     if (c->acc_cap < per_acc) {
         for (int l = 0; l < 3; ++l)
-            for (int s = 0; s < kMaxSlots; ++s)
+            for (int s = 0; s < kMaxAcc; ++s)
                 if (c->acc[l][s]) { FTTE_HIP(c, hipFree(c->acc[l][s])); c->acc[l][s] = nullptr; }
         c->acc_cap = per_acc;
     }

@@ -1,0 +1,424 @@
+// ftte_brick.hip -- the cell-fixed brick organisation of the uniform-grid diffuse sweep (CDNA4, gfx950).
+//
+// Same computation as ftte::sweep_kernel (ftte_kernels.hip): the reference's cell transfer,
+//   transportRoutinesModule.f90:587-961  /  equiSources.f90:1580-1788,
+// same segment arithmetic (ftte_math.h), organised so that the directions of one izone share every opacity load and
+// every J store, and no cell is computed twice.
+#include <hip/hip_runtime.h>
+
+#include "ftte_internal.h"
+#include "ftte_kernels.h"
+#include "ftte_math.h"
+
+namespace ftte {
+
+using gcbyte = const __attribute__((address_space(1))) char;
+using gbyte = __attribute__((address_space(1))) char;
+using gcdouble = const __attribute__((address_space(1))) double;
+using gdouble = __attribute__((address_space(1))) double;
+
+__device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// ------------------------------------------------------------------------------------------------
+// Cell-fixed bricks (ftte_internal.h: BrickGroup, BrickTask, BrickLaunch).
+//
+// The tile kernel above follows the rays: a wave's cells drift with its direction, so nothing can be shared between
+// directions and every update costs a kappa load and a J read-modify-write of its own (24 B), plus a recomputed halo.
+// Here the cells stay put and the rays move through them:
+//   * lane l of the wave owns the column u = 64 tu + l + 1, registers hold kBrickRows rows of it;
+//   * per layer the opacity of the brick's cells is loaded ONCE and the cells' J contribution stored ONCE for all
+//     the directions of the group (directions of one izone: same memory frame, same sweep order);
+//   * a ray whose next segment lies in the next column moves one lane up (a DPP shift; lane 0 takes the ray handed
+//     over by the brick to the left, lane 63 hands its ray to the brick to the right), one whose next segment lies in
+//     the next row moves one register up (row 0 takes it from the brick below, the top row hands it on): every segment
+//     is computed by the lane that owns its cell, so a cell's mean needs no exchange and nothing is computed twice;
+//   * the ray state of the group's other directions waits in LDS (8 doubles per lane and direction) while one
+//     direction crosses the layer: one code path, no barrier, one wavefront per workgroup.
+// Faces in memory are rings over two chunks (a brick's consumers run exactly one stage later).
+// Arithmetic, segment order and the order of a cell's sum are those of the tile kernel (ftte_math.h): same bits.
+// ------------------------------------------------------------------------------------------------
+
+// value held by lane-1; lane 0, which has no lane below, receives in0 (bound_ctrl off: lanes without a source keep `old`)
+__device__ __forceinline__ double shift_up_inject(double x, double in0)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    const int ilo = __double2loint(in0), ihi = __double2hiint(in0);
+    lo = __builtin_amdgcn_update_dpp(ilo, lo, 0x138, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(ihi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// One direction crosses one layer of the brick.  cur[r]: the ray entering cell (row r, this lane) through its bottom,
+// on return the ray leaving through its top.  uin/vin: where the rays handed over by the brick to the left / below wait
+// (nullptr: the domain boundary, the inflow enters there); uout/vout: where this brick's leaving rays go (nullptr: they
+// leave the domain or nobody is there).
+template <int SHAPE>
+__device__ __forceinline__ void brick_step(const ftte_consts &K, double (&cur)[kBrickRows], const double (&kap)[kBrickRows],
+                                           double (&Jacc)[kBrickRows], bool third_first, double d0, double d1, double d2,
+                                           double w, double uvb, gcbyte *uin, gbyte *uout, gcbyte *vin, gbyte *vout, int lane)
+{
+    constexpr bool HAS_U = SHAPE == RC_TWO_U || SHAPE == RC_THREE_U || SHAPE == RC_THREE_V;
+    constexpr bool HAS_V = SHAPE == RC_TWO_V || SHAPE == RC_THREE_U || SHAPE == RC_THREE_V;
+    double ui[kBrickRows];
+    double carry = uvb; // the ray that moves up from the row below (row 0: from the brick below)
+    if (HAS_U) {
+#pragma unroll
+        for (int r = 0; r < kBrickRows; ++r) ui[r] = uvb;
+        if (uin) {
+#pragma unroll
+            for (int r = 0; r < kBrickRows; ++r) ui[r] = *(gcdouble *)(uin + 8 * r); // one address for the whole wave
+        }
+    }
+    if (HAS_V && vin) carry = *(gcdouble *)(vin + 8 * lane);
+    const bool hands_u = HAS_U && uout != nullptr && lane == 63;
+
+#pragma unroll
+    for (int r = 0; r < kBrickRows; ++r) {
+        double I = cur[r];
+        const double m0 = ftte_segment(&K, &I, kap[r] * d0); // xy piece, in the ray's own cell
+        double acc = m0;
+        if (SHAPE == RC_ONE) {
+            cur[r] = I;
+            Jacc[r] += ftte_cell_mean(acc, 1, w);
+        } else if (SHAPE == RC_TWO_U) {
+            if (hands_u) *(gdouble *)(uout + 8 * r) = I;
+            I = shift_up_inject(I, ui[r]);
+            acc += ftte_segment(&K, &I, kap[r] * d1);
+            cur[r] = I;
+            Jacc[r] += ftte_cell_mean(acc, 2, w);
+        } else if (SHAPE == RC_TWO_V) {
+            double b = carry;
+            carry = I;
+            acc += ftte_segment(&K, &b, kap[r] * d1);
+            cur[r] = b;
+            Jacc[r] += ftte_cell_mean(acc, 2, w);
+        } else if (SHAPE == RC_THREE_U) { // 2nd piece one column on, 3rd one row on
+            if (hands_u) *(gdouble *)(uout + 8 * r) = I;
+            I = shift_up_inject(I, ui[r]);
+            const double m1 = ftte_segment(&K, &I, kap[r] * d1);
+            double c = carry;
+            carry = I;
+            const double m2 = ftte_segment(&K, &c, kap[r] * d2);
+            // reference order: xy + xz + yz, whatever the chain order (transportRoutinesModule.f90:695-941)
+            acc += third_first ? m2 : m1;
+            acc += third_first ? m1 : m2;
+            cur[r] = c;
+            Jacc[r] += ftte_cell_mean(acc, 3, w);
+        } else { // RC_THREE_V: 2nd piece one row on, 3rd one column on
+            double b = carry;
+            carry = I;
+            const double m1 = ftte_segment(&K, &b, kap[r] * d1);
+            if (hands_u) *(gdouble *)(uout + 8 * r) = b;
+            b = shift_up_inject(b, ui[r]);
+            const double m2 = ftte_segment(&K, &b, kap[r] * d2);
+            acc += third_first ? m2 : m1;
+            acc += third_first ? m1 : m2;
+            cur[r] = b;
+            Jacc[r] += ftte_cell_mean(acc, 3, w);
+        }
+        asm volatile("" : "+v"(Jacc[r]));
+        __builtin_amdgcn_sched_barrier(0); // rows in program order: interleaved they multiply the live registers
+    }
+    if (HAS_V && vout) *(gdouble *)(vout + 8 * lane) = carry; // the top row's ray goes on in the brick above
+}
+
+// grid: ntasks * nnu workgroups of one wavefront; dynamic LDS: 4 KB per direction of the largest group
+template <int WAVES>
+__global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
+{
+    extern __shared__ double state[]; // [direction][row][lane]
+    constexpr int R = kBrickRows;
+    using cgroup = const __attribute__((address_space(4))) BrickGroup;
+    using clayer = const __attribute__((address_space(4))) LayerRec;
+    const int nnu = L.nnu;
+    const int nu = L.nu0 + blockIdx.x % nnu;
+    const BrickTask T = L.tasks[blockIdx.x / nnu];
+    const int tu = uniform((int)T.tu), tv = uniform((int)T.tv), ti = uniform((int)T.ti) & (kBrickAccumulate - 1);
+    const bool accumulate = (uniform((int)T.ti) & kBrickAccumulate) != 0;
+    cgroup *G = (cgroup *)(L.groups + uniform((int)T.group));
+    const int lane = threadIdx.x;
+    const int n = L.n, chunk = L.chunk, up = L.up, vp = L.vp;
+    const int ndir = G->ndir;
+    const double uvb = L.uvb[nu];
+
+    const int sv = G->sv, si = G->si;
+    const bool mirror_u = G->su < 0;
+    const long org = G->org;
+    gcbyte *kbase = (gcbyte *)(G->kappa + (long)nu * L.group_stride + org);
+    gbyte *jbase = (gbyte *)(G->J + (long)nu * L.group_stride + org);
+
+    // this lane's column and the brick's rows (1-based cell indices; clamped copies for loads of a ragged last brick)
+    const int cu = 64 * tu + lane + 1;
+    const int cv0 = R * tv + 1;
+    const int cuc = cu < n ? cu : n;
+    const unsigned off0 = 8u * (unsigned)(mirror_u ? n + 1 - cuc : cuc);
+    const bool own_lane = cu <= n;
+    const long row_bytes = 8l * sv;
+    const int i0 = ti * chunk + 1;
+    const int i1 = (i0 + chunk - 1 < n) ? i0 + chunk - 1 : n;
+
+    const bool has_u_in = tu > 0, has_u_out = 64 * (tu + 1) < n;
+    const bool has_v_in = tv > 0, has_v_out = R * (tv + 1) < n;
+    const bool has_i_in = ti > 0, has_i_out = i1 < n;
+    const long fnu = (long)nu * L.face_stride;
+    // element offsets inside a direction's face block (ftte_internal.h)
+    const long u_out = ((long)(tu * 2 + (ti & 1)) * chunk) * vp + R * tv;
+    const long u_in = ((long)((tu - 1) * 2 + (ti & 1)) * chunk) * vp + R * tv;
+    const long v_out = L.vface_off + ((long)(tv * 2 + (ti & 1)) * chunk) * up + 64 * tu;
+    const long v_in = L.vface_off + ((long)((tv - 1) * 2 + (ti & 1)) * chunk) * up + 64 * tu;
+    const long i_in = L.iface_off + ((long)(ti & 1) * vp + R * tv) * up + 64 * tu + lane;
+    const long i_out = L.iface_off + ((long)((ti + 1) & 1) * vp + R * tv) * up + 64 * tu + lane;
+
+    // rays entering the brick's bottom: the inflow, or what the chunk below left
+    for (int d = 0; d < ndir; ++d) {
+        gcdouble *f = (gcdouble *)(G->dir[d].faces + fnu);
+#pragma unroll
+        for (int r = 0; r < R; ++r) state[(d * R + r) * 64 + lane] = has_i_in ? f[i_in + (long)r * up] : uvb;
+    }
+
+    // the opacity of the brick's cells, one layer ahead of the layer being crossed
+    double kap_next[R];
+    {
+        gcbyte *kplane = kbase + 8l * i0 * si;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = (cv0 + r < n) ? cv0 + r : n;
+            kap_next[r] = *(gcdouble *)(kplane + row * row_bytes + off0);
+        }
+    }
+    for (int i = i0; i <= i1; ++i) {
+        const int il = i - i0;
+        double kap[R], Jacc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { kap[r] = kap_next[r]; Jacc[r] = 0.0; }
+        gbyte *jplane = jbase + 8l * i * si;
+        if (accumulate && own_lane) { // what the groups before this one left in these cells
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (cv0 + r <= n) Jacc[r] = __builtin_nontemporal_load((gcdouble *)(jplane + (cv0 + r) * row_bytes + off0));
+        }
+        if (i < i1) {
+            gcbyte *kplane = kbase + 8l * (i + 1) * si;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int row = (cv0 + r < n) ? cv0 + r : n;
+                kap_next[r] = *(gcdouble *)(kplane + row * row_bytes + off0);
+            }
+        }
+        for (int d = 0; d < ndir; ++d) {
+            clayer *rp = (clayer *)(G->dir[d].layers) + (i - 1);
+            const double d0 = rp->dpath[0], d1 = rp->dpath[1], d2 = rp->dpath[2];
+            const int rc = rp->info & 7;
+            const double w = G->dir[d].w;
+            gbyte *f = (gbyte *)(G->dir[d].faces + fnu);
+            gcbyte *uin = has_u_in ? (gcbyte *)f + 8 * (u_in + (long)il * vp) : nullptr;
+            gbyte *uout = has_u_out ? f + 8 * (u_out + (long)il * vp) : nullptr;
+            gcbyte *vin = has_v_in ? (gcbyte *)f + 8 * (v_in + (long)il * up) : nullptr;
+            gbyte *vout = has_v_out ? f + 8 * (v_out + (long)il * up) : nullptr;
+            double cur[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) cur[r] = state[(d * R + r) * 64 + lane];
+            const bool third_first = rc == RC_THREE_U_SWAP || rc == RC_THREE_V_SWAP;
+            switch (rc) {
+            case RC_ONE: brick_step<RC_ONE>(L.math, cur, kap, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane); break;
+            case RC_TWO_U: brick_step<RC_TWO_U>(L.math, cur, kap, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane); break;
+            case RC_TWO_V: brick_step<RC_TWO_V>(L.math, cur, kap, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane); break;
+            case RC_THREE_U:
+            case RC_THREE_U_SWAP:
+                brick_step<RC_THREE_U>(L.math, cur, kap, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane);
+                break;
+            default:
+                brick_step<RC_THREE_V>(L.math, cur, kap, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane);
+                break;
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) state[(d * R + r) * 64 + lane] = cur[r];
+        }
+        // the group's contribution to J of this layer's cells: stored once, read only by the merge
+        if (own_lane) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (cv0 + r <= n) __builtin_nontemporal_store(Jacc[r], (gdouble *)(jplane + (cv0 + r) * row_bytes + off0));
+        }
+    }
+
+    if (has_i_out) {
+        for (int d = 0; d < ndir; ++d) {
+            gdouble *f = (gdouble *)(G->dir[d].faces + fnu);
+#pragma unroll
+            for (int r = 0; r < R; ++r) f[i_out + (long)r * up] = state[(d * R + r) * 64 + lane];
+        }
+    }
+}
+
+// The same brick swept by a TEAM: one wavefront per direction of the group, all in one workgroup.  Each wave keeps its
+// direction's rays in registers for the whole chunk (no state in LDS, one code path), crosses the layer with brick_step,
+// and leaves its cells' contributions in LDS; after one barrier per layer the waves add the contributions up in direction
+// order -- wave d the rows d, d + ndir, ... -- and store the rows of J.  The barrier only couples the waves of a
+// team; the other teams resident on the CU fill the gaps.
+// grid: ntasks * nnu workgroups of 64 * (largest group) threads; dynamic LDS: 2 x 4 KB per wavefront (double buffered)
+template <int WAVES>
+__global__ void __launch_bounds__(64 * kBrickMaxDirs, WAVES) brick_team_kernel(const BrickLaunch L)
+{
+    extern __shared__ double contrib[]; // [parity][direction][row][lane]
+    constexpr int R = kBrickRows;
+    using cgroup = const __attribute__((address_space(4))) BrickGroup;
+    using clayer = const __attribute__((address_space(4))) LayerRec;
+    const int nnu = L.nnu;
+    const int nu = L.nu0 + blockIdx.x % nnu;
+    const BrickTask T = L.tasks[blockIdx.x / nnu];
+    const int tu = uniform((int)T.tu), tv = uniform((int)T.tv), ti = uniform((int)T.ti) & (kBrickAccumulate - 1);
+    const bool accumulate = (uniform((int)T.ti) & kBrickAccumulate) != 0;
+    cgroup *G = (cgroup *)(L.groups + uniform((int)T.group));
+    const int lane = threadIdx.x & 63;
+    const int d = uniform((int)(threadIdx.x >> 6));
+    const int ndir = G->ndir;
+    if (d >= ndir) return; // a smaller group in a launch sized for the largest: the barrier counts live waves only
+    const int n = L.n, chunk = L.chunk, up = L.up, vp = L.vp;
+    const double uvb = L.uvb[nu];
+
+    const int sv = G->sv, si = G->si;
+    const bool mirror_u = G->su < 0;
+    const long org = G->org;
+    gcbyte *kbase = (gcbyte *)(G->kappa + (long)nu * L.group_stride + org);
+    gbyte *jbase = (gbyte *)(G->J + (long)nu * L.group_stride + org);
+
+    const int cu = 64 * tu + lane + 1;
+    const int cv0 = R * tv + 1;
+    const int cuc = cu < n ? cu : n;
+    const unsigned off0 = 8u * (unsigned)(mirror_u ? n + 1 - cuc : cuc);
+    const bool own_lane = cu <= n;
+    const long row_bytes = 8l * sv;
+    const int i0 = ti * chunk + 1;
+    const int i1 = (i0 + chunk - 1 < n) ? i0 + chunk - 1 : n;
+
+    const bool has_u_in = tu > 0, has_u_out = 64 * (tu + 1) < n;
+    const bool has_v_in = tv > 0, has_v_out = R * (tv + 1) < n;
+    const bool has_i_in = ti > 0, has_i_out = i1 < n;
+    gbyte *f = (gbyte *)(G->dir[d].faces + (long)nu * L.face_stride);
+    clayer *layers = (clayer *)(G->dir[d].layers);
+    const double w = G->dir[d].w;
+    const long u_out = ((long)(tu * 2 + (ti & 1)) * chunk) * vp + R * tv;
+    const long u_in = ((long)((tu - 1) * 2 + (ti & 1)) * chunk) * vp + R * tv;
+    const long v_out = L.vface_off + ((long)(tv * 2 + (ti & 1)) * chunk) * up + 64 * tu;
+    const long v_in = L.vface_off + ((long)((tv - 1) * 2 + (ti & 1)) * chunk) * up + 64 * tu;
+    const long i_in = L.iface_off + ((long)(ti & 1) * vp + R * tv) * up + 64 * tu + lane;
+    const long i_out = L.iface_off + ((long)((ti + 1) & 1) * vp + R * tv) * up + 64 * tu + lane;
+
+    // this direction's rays entering the brick's bottom: the inflow, or what the chunk below left
+    double cur[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) cur[r] = has_i_in ? ((gcdouble *)f)[i_in + (long)r * up] : uvb;
+
+    double kap_next[R];
+    {
+        gcbyte *kplane = kbase + 8l * i0 * si;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = (cv0 + r < n) ? cv0 + r : n;
+            kap_next[r] = *(gcdouble *)(kplane + row * row_bytes + off0);
+        }
+    }
+    for (int i = i0; i <= i1; ++i) {
+        const int il = i - i0;
+        double kap[R], Jc[R], Jprev[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { kap[r] = kap_next[r]; Jc[r] = 0.0; Jprev[r] = 0.0; }
+        gbyte *jplane = jbase + 8l * i * si;
+        if (accumulate && own_lane) { // the rows this wave will add up: what the groups before this one left there
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int r = d + k * ndir;
+                if (r < R && cv0 + r <= n) Jprev[k] = __builtin_nontemporal_load((gcdouble *)(jplane + (cv0 + r) * row_bytes + off0));
+            }
+        }
+        if (i < i1) {
+            gcbyte *kplane = kbase + 8l * (i + 1) * si;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int row = (cv0 + r < n) ? cv0 + r : n;
+                kap_next[r] = *(gcdouble *)(kplane + row * row_bytes + off0);
+            }
+        }
+        clayer *rp = layers + (i - 1);
+        const double d0 = rp->dpath[0], d1 = rp->dpath[1], d2 = rp->dpath[2];
+        const int rc = rp->info & 7;
+        gcbyte *uin = has_u_in ? (gcbyte *)f + 8 * (u_in + (long)il * vp) : nullptr;
+        gbyte *uout = has_u_out ? f + 8 * (u_out + (long)il * vp) : nullptr;
+        gcbyte *vin = has_v_in ? (gcbyte *)f + 8 * (v_in + (long)il * up) : nullptr;
+        gbyte *vout = has_v_out ? f + 8 * (v_out + (long)il * up) : nullptr;
+        const bool third_first = rc == RC_THREE_U_SWAP || rc == RC_THREE_V_SWAP;
+        switch (rc) {
+        case RC_ONE: brick_step<RC_ONE>(L.math, cur, kap, Jc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane); break;
+        case RC_TWO_U: brick_step<RC_TWO_U>(L.math, cur, kap, Jc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane); break;
+        case RC_TWO_V: brick_step<RC_TWO_V>(L.math, cur, kap, Jc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane); break;
+        case RC_THREE_U:
+        case RC_THREE_U_SWAP:
+            brick_step<RC_THREE_U>(L.math, cur, kap, Jc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane);
+            break;
+        default:
+            brick_step<RC_THREE_V>(L.math, cur, kap, Jc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane);
+            break;
+        }
+        if (ndir == 1) { // nobody to add up with
+            if (own_lane) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (cv0 + r <= n)
+                        __builtin_nontemporal_store(accumulate ? Jprev[r] + Jc[r] : Jc[r], (gdouble *)(jplane + (cv0 + r) * row_bytes + off0));
+            }
+            continue;
+        }
+        double *buf = contrib + (size_t)(i & 1) * ((blockDim.x >> 6) * R * 64);
+#pragma unroll
+        for (int r = 0; r < R; ++r) buf[(d * R + r) * 64 + lane] = Jc[r];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int r = d + k * ndir;
+            if (r >= R) break;
+            double sum = buf[r * 64 + lane]; // direction 0
+            if (accumulate) sum = Jprev[k] + sum;
+            for (int q = 1; q < ndir; ++q) sum += buf[(q * R + r) * 64 + lane];
+            if (own_lane && cv0 + r <= n) __builtin_nontemporal_store(sum, (gdouble *)(jplane + (cv0 + r) * row_bytes + off0));
+        }
+    }
+
+    if (has_i_out) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) ((gdouble *)f)[i_out + (long)r * up] = cur[r];
+    }
+}
+
+int launch_brick_team(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stream)
+{
+    if (L.ntasks <= 0) return 0;
+    if (max_dirs < 1 || max_dirs > kBrickMaxDirs) return -1;
+    const dim3 grid((unsigned)L.ntasks * (unsigned)L.nnu);
+    const dim3 block(64u * (unsigned)max_dirs);
+    const size_t lds = max_dirs > 1 ? (size_t)2 * max_dirs * kBrickRows * 64 * sizeof(double) : 0;
+    switch (waves) {
+    case 2: hipLaunchKernelGGL((brick_team_kernel<2>), grid, block, lds, stream, L); break;
+    case 3: hipLaunchKernelGGL((brick_team_kernel<3>), grid, block, lds, stream, L); break;
+    case 4: hipLaunchKernelGGL((brick_team_kernel<4>), grid, block, lds, stream, L); break;
+    default: return -1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_brick(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stream)
+{
+    if (L.ntasks <= 0) return 0;
+    if (max_dirs < 1 || max_dirs > kBrickMaxDirs) return -1;
+    const dim3 grid((unsigned)L.ntasks * (unsigned)L.nnu);
+    const size_t lds = (size_t)max_dirs * kBrickRows * 64 * sizeof(double);
+    switch (waves) {
+    case 2: hipLaunchKernelGGL((brick_kernel<2>), grid, dim3(64), lds, stream, L); break;
+    case 3: hipLaunchKernelGGL((brick_kernel<3>), grid, dim3(64), lds, stream, L); break;
+    case 4: hipLaunchKernelGGL((brick_kernel<4>), grid, dim3(64), lds, stream, L); break;
+    default: return -1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+} // namespace ftte

@@ -58,7 +58,8 @@ struct WorkItem {
 };
 static_assert(sizeof(WorkItem) == 12, "WorkItem must be 12 bytes");
 
-constexpr int kMaxSlots = 16;
+constexpr int kMaxSlots = 16; // directions of one tile-kernel launch
+constexpr int kMaxAcc = 32;   // J accumulators per memory layout (tile kernel: one per slot; bricks: one per group)
 
 struct LaunchRec {
     DirRec dir[kMaxSlots];
@@ -70,6 +71,51 @@ struct LaunchRec {
     int32_t nnu;        // frequency groups; workgroup b handles group b % nnu of work item b / nnu
     int32_t emit;       // 0 none, 1 DirRec::emis is the reference's eta, 2 a source function
     ftte_consts math;   // constants of ftte_math.h, delivered through scalar registers
+};
+
+// ---- cell-fixed bricks (brick_kernel) -----------------------------------------------------------------
+// The second organisation of the uniform-grid sweep.  A brick is a block of cells fixed in space, 64 cells along u (the
+// wave's lanes) x kBrickRows along v (registers) x `chunk` layers along the march axis, swept by one wavefront for ALL
+// the directions of one group (directions that share an izone, hence a memory frame and a sweep order), layer by layer:
+// the opacity of a layer is loaded once and its J row stored once for the whole group, nothing is recomputed (no halo),
+// and the rays that cross a brick face travel through small ring buffers in memory.  A brick needs its three upstream
+// neighbours (u-1, v-1, chunk-1) to be done: bricks with equal tu + tv + ti form a stage, one launch per stage.
+constexpr int kBrickRows = 8;
+constexpr int kBrickMaxDirs = 8; // directions of one group (their ray state waits in LDS: 4 KB per direction and wave)
+
+struct BrickDir {
+    const LayerRec *layers; // [n]
+    double *faces;          // this direction's face rings, frequency group 0: [uface | vface | iface] (BrickLaunch)
+    double w;
+    double pad;
+};
+
+struct BrickGroup {
+    BrickDir dir[kBrickMaxDirs];
+    const double *kappa; // opacity in the layout of this izone's march axis, frequency group 0
+    double *J;           // this group's accumulator (same layout); shared with other groups only as BrickTask says
+    int64_t org;         // as DirRec
+    int32_t si, sv, su;
+    int32_t ndir;
+};
+
+// ti: chunk index; bit 14 set (kBrickAccumulate): another group that shares this group's accumulator has been through this
+// brick in an earlier launch, so J is read, added to and stored instead of stored
+struct BrickTask { int16_t group, tu, tv, ti; };
+constexpr int kBrickAccumulate = 0x4000;
+static_assert(sizeof(BrickTask) == 8, "BrickTask must be 8 bytes");
+
+struct BrickLaunch {
+    const BrickGroup *groups;
+    const BrickTask *tasks;   // of this stage
+    const double *uvb;        // [nnu]
+    int64_t group_stride;     // elements between frequency groups in kappa / J
+    int64_t face_stride;      // elements between frequency groups in a direction's face rings
+    int64_t vface_off, iface_off; // where the v-face and i-face rings start inside a direction's block (u-face ring at 0)
+    int32_t n, ntasks, nnu, chunk; // nnu: frequency groups THIS launch sweeps, nu0, nu0 + 1, ...
+    int32_t nu0;
+    int32_t up, vp;           // padded extents: 64 * ntu, kBrickRows * ntv
+    ftte_consts math;
 };
 
 // ---- refined cell arrays (ftte_amr.h) ------------------------------------------------------------------

@@ -10,6 +10,10 @@ namespace ftte {
 // rows x stack: 4x{1,4,8}, 8x{1,2,4}, 16x1; waves: 2, 3, 4, 6
 void set_lds_pad(int bytes); // diagnostic: dynamic LDS per workgroup, to cap residency
 int launch_sweep(const LaunchRec &L, int rows, int waves, int stack, int nnu, hipStream_t stream);
+// one stage of the cell-fixed brick sweep; max_dirs: directions of the launch's largest group (sizes the LDS); waves 2..4
+int launch_brick(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stream);
+// the same stage by teams: one wavefront per direction of a group in one workgroup
+int launch_brick_team(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stream);
 // cell-array order -> layout 1 ([jc][ic][kc]) or 2 ([kc][ic][jc]); nnu groups, group_stride apart
 int launch_to_layout(int layout, const double *src, double *dst, int n, int nnu, long group_stride, hipStream_t stream);
 // J (cell-array order) = acc[0] + acc[1] + ... in list order; layout[a] in {0,1,2}

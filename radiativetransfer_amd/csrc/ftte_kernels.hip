@@ -435,8 +435,8 @@ int launch_to_layout(int layout, const double *src, double *dst, int n, int nnu,
 // J[ic][jc][kc] = sum over the accumulators in list order (layout 0 first, then 1, then 2; within
 // a layout by slot).  One block per (32 jc x 32 kc) tile of one ic plane of one group.
 struct MergeRec {
-    const double *acc[3 * kMaxSlots];
-    int layout[3 * kMaxSlots];
+    const double *acc[3 * kMaxAcc];
+    int layout[3 * kMaxAcc];
     int count;
 };
 
@@ -489,7 +489,7 @@ __global__ void __launch_bounds__(256) merge_kernel(const MergeRec M, double *__
 int launch_merge(const double *const *acc, const int *layout, int count, double *J, int n, int nnu, long group_stride,
                  bool accumulate, hipStream_t stream)
 {
-    if (count > 3 * kMaxSlots) return -1;
+    if (count > 3 * kMaxAcc) return -1;
     MergeRec M;
     M.count = count;
     for (int a = 0; a < count; ++a) { M.acc[a] = acc[a]; M.layout[a] = layout[a]; }

@@ -1,0 +1,109 @@
+"""The cell-fixed brick organisation of the uniform-grid sweep (csrc/ftte_brick.hip, option "engine" = 2) against the
+oracle and the reference's goldens, through the C ABI.
+
+Tolerances as in test_parity_gpu.py: bitwise against the oracle with the device arithmetic for a single direction (the
+brick engine adds the directions of one izone group first and the groups in layout order, so several directions agree to
+SUM_RTOL); the reference bound against the goldens.
+"""
+import numpy as np
+import pytest
+
+import _oracle as O
+from radiativetransfer_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+EPS = np.finfo(np.float64).eps
+SUM_RTOL = 64 * EPS
+
+
+@pytest.fixture(params=["team", "solo"])
+def bricks(engine, request):
+    """Both forms of the brick kernel: a team of wavefronts, one per direction of a group (the default), and one wavefront
+    that takes the group's directions in turn."""
+    engine.set_option("engine", 2)
+    engine.set_option("team", 1 if request.param == "team" else 0)
+    yield engine
+    for key, value in (("engine", 0), ("team", 0), ("chunk", 16), ("group", 3), ("share", 2)):
+        engine.set_option(key, value)
+
+
+def one_per_izone():
+    phi, theta, _ = O.healpix_directions(3)
+    pick = {}
+    for p, t in zip(phi, theta):
+        pick.setdefault(O.fold_direction(p, t)[2], (p, t))
+    return [pick[z] for z in range(1, 25)]
+
+
+@pytest.mark.parametrize("chunk", [1, 7, 32, 4096])
+@pytest.mark.parametrize("n", [5, 16, 70, 130])
+def test_every_izone_bitwise(bricks, n, chunk):
+    """One direction per izone (24 rotations, all ray classes); grids smaller than a brick (5), one brick wide with a
+    ragged last row block (70 = 8 * 8 + 6, 64 + 6 columns), three bricks wide (130); chunks of one layer, of a length
+    that does not divide n, 32, and longer than the grid."""
+    if n == 130 and chunk in (1, 7):
+        pytest.skip("covered by the smaller grids")
+    kappa, uvb, box = synthetic.uniform_workload(n, 2, seed=n, tau_median=0.3)
+    bricks.set_option("chunk", chunk)
+    bricks.set_uniform_grid(n, box)
+    bricks.set_opacity(kappa)
+    for p, t in one_per_izone():
+        phi, theta, w = np.array([p]), np.array([t]), np.array([0.37])
+        J = bricks.transport(phi, theta, w, uvb)
+        ref = O.sweep_uniform(n, kappa, box, phi, theta, w, uvb, arith=O.ARITH_DEVICE)
+        assert np.array_equal(J, ref), f"izone {O.fold_direction(p, t)[2]}"
+
+
+@pytest.mark.parametrize("group,share", [(1, 2), (3, 1), (8, 0), (2, 2)])
+@pytest.mark.parametrize("name", ["uniform8_transparent", "uniform16_constant", "uniform16_lognormal_24zones",
+                                  "uniform24_lognormal_48dir"])
+def test_reference_goldens(bricks, golden, name, group, share):
+    g = golden(name)
+    n = int(g["n"])
+    bricks.set_option("group", group)
+    bricks.set_option("share", share)
+    bricks.set_option("chunk", 5)
+    bricks.set_uniform_grid(n, float(g["box"]))
+    bricks.set_opacity(g["kappa"])
+    J = bricks.transport(g["phi"], g["theta"], g["w"], g["uvb"])
+    args = (n, g["kappa"], float(g["box"]), g["phi"], g["theta"], g["w"], g["uvb"])
+    assert np.allclose(J, O.sweep_uniform(*args, arith=O.ARITH_DEVICE), rtol=SUM_RTOL, atol=0)
+    _, noise = O.sweep_uniform(*args, with_noise=True)
+    assert np.all(np.abs(J - g["J"]) <= 8 * noise + 12 * n * EPS * np.abs(g["J"]))
+
+
+@pytest.mark.parametrize("n,chunk", [(100, 24), (128, 16)])
+def test_bricks_equal_tiles_on_the_full_direction_set(engine, n, chunk):
+    """192 directions, 3 groups; a grid of 2 x 13 x 5 ragged bricks, where only the passes of one izone share an
+    accumulator, and one of 2 x 16 x 8 whole bricks, where pairs of izones share one as well: both organisations of the
+    sweep, same arithmetic, the sums over directions in different orders."""
+    kappa, uvb, box = synthetic.uniform_workload(n, 3, seed=11, tau_median=0.2)
+    phi, theta, w = O.healpix_directions(3)
+    engine.set_uniform_grid(n, box)
+    engine.set_opacity(kappa)
+    engine.set_option("engine", 1)
+    J_tiles = engine.transport(phi, theta, w, uvb)
+    engine.set_option("engine", 2)
+    engine.set_option("chunk", chunk)
+    engine.set_option("group", 3)
+    J_bricks = engine.transport(phi, theta, w, uvb)
+    J_again = engine.transport(phi, theta, w, uvb)
+    engine.set_option("engine", 0)
+    engine.set_option("chunk", 16)
+    engine.set_option("group", 3)
+    assert np.array_equal(J_bricks, J_again)  # no atomics, a fixed order: reproducible bit for bit
+    assert np.allclose(J_bricks, J_tiles, rtol=SUM_RTOL, atol=0)
+    assert 0 < J_bricks.min() and np.all(J_bricks <= uvb[:, None] * (1 + SUM_RTOL))
+
+
+def test_launch_records_account_for_every_update(bricks):
+    n, nnu = 70, 2
+    kappa, uvb, box = synthetic.uniform_workload(n, nnu, seed=2, tau_median=0.3)
+    phi, theta, w = O.healpix_directions(2)
+    bricks.set_uniform_grid(n, box)
+    bricks.set_opacity(kappa)
+    bricks.transport(phi, theta, w, uvb)
+    rec = bricks.launch_records()
+    assert sum(u for _, u in rec) == n ** 3 * nnu * len(phi)
+    assert all(ms >= 0 for ms, _ in rec)

@@ -23,6 +23,15 @@ EPS = np.finfo(np.float64).eps
 SUM_RTOL = 64 * EPS
 
 
+@pytest.fixture(autouse=True)
+def tiles(engine):
+    """This file exercises the ray-following tile kernel (option "engine" = 1) with its rows / slots / stack variants, and
+    the refined-grid path; the cell-fixed bricks, which a uniform grid takes by default, are in test_brick_gpu.py."""
+    engine.set_option("engine", 1)
+    yield
+    engine.set_option("engine", 0)
+
+
 def one_per_izone():
     phi, theta, _ = O.healpix_directions(3)
     pick = {}
