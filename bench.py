@@ -7,14 +7,20 @@ iteration on a 256^3 uniform grid, and the sweep kernel's achieved fraction of t
 
 A step is one full source iteration of the hot path on inputs already resident in HBM:
 new opacities are handed to the library (device-to-device, including the two layout transposes the
-sweep needs), every direction of this rank is swept for every frequency group, the per-slot
-accumulators are merged into J, and -- for N > 1 -- J is summed over ranks with an RCCL all-reduce.
+sweep needs), every direction of this rank is swept for every frequency group of this rank, the accumulators are merged
+into J, and -- for N > 1 -- the ranks' pieces of J are combined over RCCL.
 
 Workload (BASELINE.json configs[1], SURVEY.md section 8(d) "config 2"): 256^3 cells, 8 frequency groups,
-96 directions per GPU = NESTED pixels of nside 4 after the reference's rotateAngles, equal weights;
-log-normal opacity field (sigma_ln = 1, seed 12345), zero emissivity.  Multi-GPU is weak scaling in the
-angular quadrature: rank r sweeps pixels [96 r, 96 (r+1)) of the first 96 N pixels with weight 1/(96 N)
-(N = 2 is the reference's own 192-direction set, N = 8 all 768 pixels of nside 4... capped at 768).
+96 directions = NESTED pixels 0..95 of nside 4 after the reference's rotateAngles, equal weights;
+log-normal opacity field (sigma_ln = 1, seed 12345), zero emissivity.  --ndir 192 is configs[2] (all pixels of nside 4).
+
+Multi-GPU is STRONG scaling: the same 96 (or 192) directions x 8 groups whatever N (north_star: "96 directions, 8
+frequency bins at 1/2/4/8 MI355X").  Ranks form a (frequency slice) x (direction slice) grid, frequency groups first
+(radiativetransfer_amd/distributed.py: Shard2D): at N = 2, 4, 8 with 8 groups every rank owns 8/N groups for all
+directions, its J_nu is complete where it is computed and the only exchange is an all-gather of the slices; where N does
+not divide the groups the directions are split as well and the partial J is all-reduced first.  The line reports the time
+of the sweep and of the collective separately (config.compute_ms_per_step, config.collective_ms_per_step).
+--weak restores round 1's mode (96 directions per GPU, 96 N in all, all-reduce).
 
 The JSON line also carries
   roofline    : sweep kernel, algorithmic bytes (24 B per update) / HIP-event time of its launches
@@ -48,7 +54,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n", type=int, default=256)
     ap.add_argument("--nnu", type=int, default=8)
-    ap.add_argument("--ndir", type=int, default=96, help="directions per GPU")
+    ap.add_argument("--ndir", type=int, default=96, help="directions in all (per GPU with --weak)")
+    ap.add_argument("--weak", action="store_true", help="96 directions per GPU instead of 96 in all")
     ap.add_argument("--rows", type=int, default=0, help="rays per lane (4/8/16); 0 = library default")
     ap.add_argument("--slots", type=int, default=0, help="directions in flight per launch; 0 = library default")
     ap.add_argument("--waves", type=int, default=0, help="waves per SIMD the kernel is compiled for; 0 = library default")
@@ -64,45 +71,77 @@ def parse():
     return ap.parse_args()
 
 
-def directions(total: int, per_rank: int, rank: int):
+def directions(total: int):
+    """The first `total` NESTED pixels of the smallest HEALPix level that has that many (nside 4 for 96 and 192:
+    equiSources.f90:1385-1391 with nAngularLevel = 3), rotated as the reference rotates them, equal weights."""
     import radiativetransfer_amd as rt
-    nside = 4
+    nside = 1
     while 12 * nside * nside < total:
         nside *= 2
-    lo = rank * per_rank
-    ang = np.array([rt.pix2ang_nest(nside, i) for i in range(lo, lo + per_rank)])
-    return ang[:, 0].copy(), ang[:, 1].copy(), np.full(per_rank, 1.0 / total)
+    ang = np.array([rt.pix2ang_nest(nside, i) for i in range(total)])
+    return ang[:, 0].copy(), ang[:, 1].copy(), np.full(total, 1.0 / total)
+
+
+def host_identity():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return model, os.cpu_count() or 1, usable
+
+
+def _write_case(path, n, box, uvb3, kappa3, phi, theta, w):
+    ncell = n ** 3
+    with open(path, "wb") as f:
+        f.write(struct.pack("<4i", n, ncell, len(phi), 0))
+        f.write(struct.pack("<d", box))
+        f.write(np.asarray(uvb3, "<f8").tobytes())
+        f.write(np.zeros(ncell, "<i4").tobytes())
+        f.write(np.ascontiguousarray(kappa3, "<f8").tobytes())
+        for a in (phi, theta, w):
+            f.write(np.asarray(a, "<f8").tobytes())
+
+
+def _sweep_seconds(res):
+    for line in res.stdout.splitlines():
+        if line.strip().startswith("SWEEP_SECONDS"):
+            return float(line.split()[1])
+    return None
 
 
 def cpu_baseline(n, kappa_host3, uvb3, box, phi, theta, w):
     """Times the CPU path on a bounded sample of the same workload: the first three frequency groups
-    (the reference hard-wires three, definitionsModule.f90:169-171) and the first direction."""
+    (the reference hard-wires three, definitionsModule.f90:169-171) and the first directions; one core (the reference
+    is serial), and -- what a host could do at best with the reference's code -- one process per direction on all cores."""
+    from radiativetransfer_amd import synthetic
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    model, cores_total, cores_usable = host_identity()
     ncell = n ** 3
     nd = min(CPU_SAMPLE_DIRS, len(phi))
     updates = ncell * 3 * nd
     sample = f"{n}^3 grid, first 3 frequency groups, first {nd} directions of the workload ({updates:.3g} updates)"
+    ident = {"cpu_model": model, "host_cores": cores_total, "host_cores_usable": cores_usable}
     if os.path.exists(harness):
         with tempfile.TemporaryDirectory() as tmp:
             case, out = os.path.join(tmp, "case.bin"), os.path.join(tmp, "out.bin")
-            with open(case, "wb") as f:
-                f.write(struct.pack("<4i", n, ncell, nd, 0))
-                f.write(struct.pack("<d", box))
-                f.write(np.asarray(uvb3, "<f8").tobytes())
-                f.write(np.zeros(ncell, "<i4").tobytes())
-                f.write(np.ascontiguousarray(kappa_host3, "<f8").tobytes())
-                for a in (phi[:nd], theta[:nd], w[:nd]):
-                    f.write(np.asarray(a, "<f8").tobytes())
+            _write_case(case, n, box, uvb3, kappa_host3, phi[:nd], theta[:nd], w[:nd])
             try:
                 res = subprocess.run([harness, case, out], capture_output=True, text=True, timeout=900)
-                secs = None
-                for line in res.stdout.splitlines():
-                    if line.strip().startswith("SWEEP_SECONDS"):
-                        secs = float(line.split()[1])
+                secs = _sweep_seconds(res)
                 if secs and secs > 0:
-                    return {"value": updates / secs, "unit": "updates/s", "cores": 1, "kind": "reference",
-                            "sample": sample + "; reference modules compiled with amdflang -O2 (oracle/_ref), "
-                                               "pattern + neighbour set-up + transport timed, tree build excluded"}
+                    rec = {"value": updates / secs, "unit": "updates/s", "cores": 1, "kind": "reference",
+                           "sample": sample + "; reference modules compiled with amdflang -O2 (oracle/_ref), "
+                                              "pattern + neighbour set-up + transport timed, tree build excluded", **ident}
+                    rec.update(all_cores_leg(harness, tmp, box, uvb3, phi, theta, w, cores_usable))
+                    return rec
             except Exception as e:  # fall through to the port
                 print(f"[bench] reference harness failed: {e}", file=sys.stderr)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -111,7 +150,41 @@ def cpu_baseline(n, kappa_host3, uvb3, box, phi, theta, w):
     O.sweep_uniform(n, kappa_host3, box, phi[:nd], theta[:nd], w[:nd], uvb3)
     secs = time.perf_counter() - t0
     return {"value": updates / secs, "unit": "updates/s", "cores": 1, "kind": "port",
-            "sample": sample + "; C restatement oracle/ftte_oracle.c, gcc -O2"}
+            "sample": sample + "; C restatement oracle/ftte_oracle.c, gcc -O2", **ident}
+
+
+def all_cores_leg(harness, tmp, box, uvb3, phi, theta, w, cores_usable):
+    """The reference is serial; directions are independent, so the most a host can get out of its code is one process per
+    direction.  Each process holds the reference's 680-byte-per-cell tree (11.4 GB at 256^3), so this leg runs at 128^3
+    (1.4 GB per process): P = min(usable cores, 32) processes, 2 directions each, wall time of the slowest."""
+    from radiativetransfer_amd import synthetic
+    n2, per = 128, 2
+    procs = max(1, min(cores_usable, 32))
+    try:
+        k3, _, _ = synthetic.uniform_workload(n2, 3, seed=12345, tau_median=0.1)
+        cases = []
+        for p in range(procs):
+            lo = (p * per) % max(1, len(phi) - per)
+            case = os.path.join(tmp, f"case{p}.bin")
+            _write_case(case, n2, box, uvb3, k3, phi[lo:lo + per], theta[lo:lo + per], w[lo:lo + per])
+            cases.append(case)
+        running = [subprocess.Popen([harness, c, c + ".out"], stdout=subprocess.PIPE, text=True) for c in cases]
+        secs = []
+        for pr in running:
+            out, _ = pr.communicate(timeout=600)
+            t = None
+            for line in out.splitlines():
+                if line.strip().startswith("SWEEP_SECONDS"):
+                    t = float(line.split()[1])
+            secs.append(t)
+        if all(t and t > 0 for t in secs):
+            total = n2 ** 3 * 3 * per * procs
+            return {"all_cores": {"value": total / max(secs), "unit": "updates/s", "cores": procs,
+                                  "sample": f"{procs} concurrent processes of the same harness, {n2}^3 grid, 3 groups, {per} "
+                                            f"directions each ({total:.3g} updates), slowest process's sweep time"}}
+    except Exception as e:
+        print(f"[bench] all-cores leg failed: {e}", file=sys.stderr)
+    return {}
 
 
 def main():
@@ -136,13 +209,26 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    n, nnu, ndir = a.n, a.nnu, a.ndir
+    from radiativetransfer_amd.distributed import Shard2D
+    n, nnu = a.n, a.nnu
     ncell = n ** 3
-    total_dirs = ndir * world
-    phi, theta, w = directions(total_dirs, ndir, rank)
-    kappa_host, uvb, box = synthetic.uniform_workload(n, nnu, seed=12345, tau_median=0.1)
-    kappa = torch.from_numpy(kappa_host).to(dev)
-    J = torch.empty((nnu, ncell), dtype=torch.float64, device=dev)
+    total_dirs = a.ndir * world if a.weak else a.ndir
+    phi_all, theta_all, w_all = directions(total_dirs)
+    kappa_host, uvb_all, box = synthetic.uniform_workload(n, nnu, seed=12345, tau_median=0.1)
+    if a.weak:  # round 1's mode: every rank all groups, its own 96 directions, all-reduce
+        shard = None
+        nu_lo, nu_hi = 0, nnu
+        lo = rank * a.ndir
+        phi, theta, w = phi_all[lo:lo + a.ndir], theta_all[lo:lo + a.ndir], w_all[lo:lo + a.ndir]
+    else:
+        shard = Shard2D(rank, world, nnu)
+        nu_lo, nu_hi = shard.groups
+        phi, theta, w = shard.directions(phi_all, theta_all, w_all)
+    nnu_local = nu_hi - nu_lo
+    uvb = uvb_all[nu_lo:nu_hi].copy()
+    kappa = torch.from_numpy(np.ascontiguousarray(kappa_host[nu_lo:nu_hi])).to(dev)
+    J = torch.empty((nnu_local, ncell), dtype=torch.float64, device=dev)
+    J_full = torch.empty((nnu, ncell), dtype=torch.float64, device=dev) if (shard and shard.r_nu > 1) else None
 
     eng = rt.DiffuseTransfer(device=local)
     eng.set_uniform_grid(n, box)
@@ -168,11 +254,22 @@ def main():
         eng.set_option("lanes", a.lanes)
     stream = torch.cuda.current_stream().cuda_stream
 
-    def step():
-        eng.set_opacity_device(nnu, kappa.data_ptr())
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+
+    def step(timed=False):
+        if timed:
+            ev[0].record()
+        eng.set_opacity_device(nnu_local, kappa.data_ptr())
         eng.transport_device(phi, theta, w, uvb, J.data_ptr(), stream)
+        if timed:
+            ev[1].record()
         if world > 1:
-            dist.all_reduce(J)
+            if shard is None:
+                dist.all_reduce(J)
+            else:
+                shard.combine(J, out=J_full)
+        if timed:
+            ev[2].record()
 
     def fence():
         if world > 1:
@@ -182,44 +279,55 @@ def main():
     for _ in range(a.warmup):
         step()
     fence()
-    launch_ms, launch_updates = 0.0, 0
+    launch_ms, launch_updates, compute_ms, collective_ms = 0.0, 0, 0.0, 0.0
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        step()
+        step(timed=True)
         # the launch records of a sweep are read after the sweep has drained; the next sweep starts with a stream
         # synchronise anyway (it rewrites device tables), so this adds no bubble of its own
         torch.cuda.synchronize()
+        compute_ms += ev[0].elapsed_time(ev[1])
+        collective_ms += ev[1].elapsed_time(ev[2])
         for ms, upd in eng.launch_records():
             launch_ms += ms
             launch_updates += upd
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, compute_ms, collective_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, compute_ms, collective_ms = (float(x) for x in t.tolist())
 
     updates_per_step = ncell * total_dirs * nnu
     value = updates_per_step * a.steps / elapsed
     nlaunch = len(eng.launch_records()) * a.steps
     achieved = launch_updates * BYTES_PER_UPDATE / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
 
+    if world == 1:
+        parallelism = "single GPU"
+    elif shard is None:
+        parallelism = f"weak: {a.ndir} directions per rank, RCCL all-reduce of J"
+    else:
+        parallelism = f"{world} ranks = " + shard.describe() + " (RCCL)"
+    kernel = "ftte::brick_kernel (all stage launches of a sweep, two streams)" if len(eng.launch_records()) == 1 else "ftte::sweep_kernel"
     out = {
         "metric": "cell·dir·ν updates/sec per iteration, 256³ grid; achieved HBM GB/s vs peak",
         "value": value, "unit": "updates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{n}^3 uniform grid, {nnu} frequency groups, {ndir} directions per GPU "
-                               f"({total_dirs} in all, NESTED pixels of the rotated HEALPix set), diffuse sweep, "
-                               "log-normal opacity, zero emissivity (BASELINE.json configs[1])",
-                   "grid": n, "nnu": nnu, "ndir_per_gpu": ndir, "ndir_total": total_dirs,
-                   "parallelism": f"directions sharded over {world} rank(s), RCCL all-reduce of J" if world > 1
-                   else "single GPU"},
+        "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak" if a.weak else "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{n}^3 uniform grid, {nnu} frequency groups, {total_dirs} directions in all "
+                               "(NESTED pixels of the rotated HEALPix set), diffuse sweep, log-normal opacity, zero "
+                               "emissivity (BASELINE.json configs[" + ("2" if total_dirs == 192 else "1") + "])",
+                   "grid": n, "nnu": nnu, "ndir_total": total_dirs, "ndir_this_rank": len(phi), "nnu_this_rank": nnu_local,
+                   "parallelism": parallelism,
+                   "compute_ms_per_step": compute_ms / a.steps, "collective_ms_per_step": collective_ms / a.steps},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, nnu),
-                     "kernel": "ftte::sweep_kernel", "launches": nlaunch,
+                     "kernel": kernel, "launches": nlaunch,
                      "avg_launch_ms": launch_ms / nlaunch if nlaunch else None,
-                     "bytes_per_update": BYTES_PER_UPDATE},
+                     "bytes_per_update": BYTES_PER_UPDATE,
+                     "note": "achieved = 24 B x updates of rank 0's sweep launches / their HIP-event time; above 1 is "
+                             "legitimate: the directions of a group share the opacity load and the J store (DESIGN.md)"},
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cn = a.cpu_n or n
@@ -227,7 +335,7 @@ def main():
             k3 = kappa_host[:3]
         else:
             k3, _, _ = synthetic.uniform_workload(cn, 3, seed=12345, tau_median=0.1)
-        out["cpu_baseline"] = cpu_baseline(cn, k3, uvb[:3], box, phi, theta, w)
+        out["cpu_baseline"] = cpu_baseline(cn, k3, uvb_all[:3], box, phi_all, theta_all, w_all)
     if rank == 0:
         print(json.dumps(out, ensure_ascii=False))
     if world > 1:

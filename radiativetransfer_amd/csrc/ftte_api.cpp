@@ -67,17 +67,18 @@ struct Plan {
 struct BrickPlan {
     bool valid = false;
     // key
-    int n = 0, chunk = 0, gmax = 0;
+    int n = 0, chunk = 0, gmax = 0, share = 0, want_glanes = 0;
     double box = 0;
     std::vector<double> phi, theta, w;
     // content
     std::vector<DirPlan> dirs;
     std::vector<LayerRec> layers;
-    struct Group { int izone = 0, layout = 0, acc = 0, offset = 0; std::vector<int> dirs; };
+    struct Group { int izone = 0, layout = 0, acc = 0, offset = 0, lane = 0; std::vector<int> dirs; };
     std::vector<Group> groups;
     std::vector<BrickTask> tasks;      // stage after stage
-    std::vector<size_t> stage_off;     // [nstages + 1] into tasks
-    std::vector<int64_t> stage_updates; // cell.direction updates of a stage (per frequency group)
+    int glanes = 1, nstages = 0;       // the groups are dealt to `glanes` streams (the groups of one accumulator stay together)
+    std::vector<size_t> stage_off;     // [glanes][nstages + 1] into tasks
+    int64_t updates = 0;               // cell.direction updates of a sweep (per frequency group)
     int ntu = 0, ntv = 0, nti = 0, up = 0, vp = 0, max_dirs = 0;
     int64_t face_elems = 0, vface_off = 0, iface_off = 0;
     int nacc[3] = {0, 0, 0};
@@ -117,7 +118,7 @@ struct ftte_ctx {
 
     // which organisation sweeps a uniform grid: 0 = bricks unless emission is on (the tile kernel has the emission
     // variants), 1 = tile kernel (sweep_kernel), 2 = bricks (brick_kernel)
-    int engine = 0, chunk = 16, group = 3, brick_waves = 4, share = 2, team = 0, lanes = 2; // measured best at 256^3 x 8 x 96
+    int engine = 0, chunk = 0, group = 0, brick_waves = 4, share = 2, team = 0, lanes = 2; // chunk, group: 0 = by the parallelism (build_brick_plan)
     std::vector<hipStream_t> lane_stream;   // extra streams of the brick sweep (frequency groups are independent)
     std::vector<hipEvent_t> lane_done;
     hipEvent_t ev_fork = nullptr;
@@ -418,8 +419,15 @@ int build_plan(ftte_ctx *c, int rows, int stack, int ndir, const double *phi, co
 int build_brick_plan(ftte_ctx *c, int ndir, const double *phi, const double *theta, const double *w)
 {
     BrickPlan &P = c->bplan;
-    const int n = c->n, chunk = std::min(c->chunk, n), gmax = c->group;
-    if (P.valid && P.n == n && P.chunk == chunk && P.gmax == gmax && P.box == c->box && (int)P.phi.size() == ndir &&
+    const int n = c->n, nnu = c->nnu;
+    // Unset options (0) follow the parallelism there is: a stage offers (bricks of a plane) x groups x frequency groups
+    // tasks, and with few frequency groups on this GPU (a rank of a frequency-sharded run) shorter bricks and smaller
+    // groups keep the stages wide enough; the groups are then dealt to the streams instead of the frequency groups.
+    const int chunk = std::min(c->chunk > 0 ? c->chunk : (nnu >= 4 ? 16 : nnu >= 2 ? 8 : 4), n);
+    const int gmax = c->group > 0 ? c->group : (nnu >= 2 ? 3 : 2);
+    const int want_glanes = nnu >= c->lanes ? 1 : c->lanes;
+    if (P.valid && P.n == n && P.chunk == chunk && P.gmax == gmax && P.share == c->share && P.want_glanes == want_glanes && P.box == c->box &&
+        (int)P.phi.size() == ndir &&
         (ndir == 0 || (!std::memcmp(P.phi.data(), phi, sizeof(double) * ndir) &&
                        !std::memcmp(P.theta.data(), theta, sizeof(double) * ndir) &&
                        !std::memcmp(P.w.data(), w, sizeof(double) * ndir))))
@@ -427,7 +435,7 @@ int build_brick_plan(ftte_ctx *c, int ndir, const double *phi, const double *the
 
     ++c->n_plan_builds;
     P = BrickPlan();
-    P.n = n; P.chunk = chunk; P.gmax = gmax; P.box = c->box;
+    P.n = n; P.chunk = chunk; P.gmax = gmax; P.share = c->share; P.want_glanes = want_glanes; P.box = c->box;
     P.phi.assign(phi, phi + ndir); P.theta.assign(theta, theta + ndir); P.w.assign(w, w + ndir);
     P.dirs.resize(ndir);
     P.layers.resize((size_t)ndir * n);
@@ -512,11 +520,24 @@ int build_brick_plan(ftte_ctx *c, int ndir, const double *phi, const double *the
     for (int layout = 0; layout < 3; ++layout)
         if (P.nacc[layout] > kMaxAcc) return fail(c, FTTE_ERR_UNSUPPORTED, "too many direction groups for one memory layout: raise option \"group\"");
 
+    // streams: the groups of one accumulator stay on one stream (their launches are ordered against each other)
+    P.glanes = std::max(1, std::min(want_glanes, P.nacc[0] + P.nacc[1] + P.nacc[2]));
+    {
+        int next = 0;
+        std::vector<int> lane_of(3 * (size_t)kMaxAcc, -1);
+        for (auto &G : P.groups) {
+            int &l = lane_of[(size_t)G.layout * kMaxAcc + G.acc];
+            if (l < 0) l = next++ % P.glanes;
+            G.lane = l;
+        }
+    }
     int max_offset = 0;
     for (const auto &G : P.groups) max_offset = std::max(max_offset, G.offset);
     const int nstages = P.groups.empty() ? 0 : P.ntu + P.ntv + P.nti - 2 + max_offset;
-    P.stage_off.assign((size_t)nstages + 1, 0);
-    P.stage_updates.assign((size_t)nstages, 0);
+    P.nstages = nstages;
+    const size_t per_lane = (size_t)nstages + 1;
+    P.stage_off.assign((size_t)P.glanes * per_lane, 0);
+    P.updates = 0;
     if (!P.groups.empty()) {
         // launch in which each accumulator's cells are first written, per physical brick: whoever comes later accumulates
         const size_t nb = (size_t)P.ntu * P.ntv * P.nti;
@@ -536,29 +557,37 @@ int build_brick_plan(ftte_ctx *c, int ndir, const double *phi, const double *the
                         f = std::min(f, tu + tv + ti + G.offset);
                     }
         }
-        for (int pass = 0; pass < 2; ++pass) { // count, then fill
-            std::vector<size_t> fill(P.stage_off.begin(), P.stage_off.end() - 1);
-            for (size_t g = 0; g < P.groups.size(); ++g) {
-                const BrickPlan::Group &G = P.groups[g];
-                const std::vector<int> &F = first[(size_t)G.layout * kMaxAcc + G.acc];
-                for (int ti = 0; ti < P.nti; ++ti)
-                    for (int tv = 0; tv < P.ntv; ++tv)
-                        for (int tu = 0; tu < P.ntu; ++tu) {
-                            const int st = tu + tv + ti + G.offset;
-                            if (!pass) { ++P.stage_off[(size_t)st + 1]; continue; }
-                            BrickTask T;
-                            T.group = (int16_t)g; T.tu = (int16_t)tu; T.tv = (int16_t)tv;
-                            T.ti = (int16_t)(ti | (st > F[brick_of(G, tu, tv, ti)] ? kBrickAccumulate : 0));
-                            P.tasks[fill[(size_t)st]++] = T;
-                            const int64_t cu = std::min(64, n - 64 * tu), cv = std::min(kBrickRows, n - kBrickRows * tv),
-                                          ci = std::min(chunk, n - chunk * ti);
-                            P.stage_updates[(size_t)st] += cu * cv * ci * (int64_t)G.dirs.size();
-                        }
+        // count per (lane, stage) in slot [lane][stage + 1], turn into offsets (lanes one after the other), then fill
+        for (const auto &G : P.groups)
+            for (int ti = 0; ti < P.nti; ++ti)
+                for (int tv = 0; tv < P.ntv; ++tv)
+                    for (int tu = 0; tu < P.ntu; ++tu) ++P.stage_off[(size_t)G.lane * per_lane + (size_t)(tu + tv + ti + G.offset) + 1];
+        size_t run = 0;
+        for (int l = 0; l < P.glanes; ++l) {
+            P.stage_off[(size_t)l * per_lane] = run;
+            for (int st = 0; st < nstages; ++st) {
+                const size_t cnt = P.stage_off[(size_t)l * per_lane + (size_t)st + 1];
+                P.stage_off[(size_t)l * per_lane + (size_t)st + 1] = P.stage_off[(size_t)l * per_lane + (size_t)st] + cnt;
             }
-            if (!pass) {
-                for (int st = 0; st < nstages; ++st) P.stage_off[(size_t)st + 1] += P.stage_off[(size_t)st];
-                P.tasks.resize(P.stage_off[(size_t)nstages]);
-            }
+            run = P.stage_off[(size_t)l * per_lane + (size_t)nstages];
+        }
+        P.tasks.resize(run);
+        std::vector<size_t> fill(P.stage_off);
+        for (size_t g = 0; g < P.groups.size(); ++g) {
+            const BrickPlan::Group &G = P.groups[g];
+            const std::vector<int> &F = first[(size_t)G.layout * kMaxAcc + G.acc];
+            for (int ti = 0; ti < P.nti; ++ti)
+                for (int tv = 0; tv < P.ntv; ++tv)
+                    for (int tu = 0; tu < P.ntu; ++tu) {
+                        const int st = tu + tv + ti + G.offset;
+                        BrickTask T;
+                        T.group = (int16_t)g; T.tu = (int16_t)tu; T.tv = (int16_t)tv;
+                        T.ti = (int16_t)(ti | (st > F[brick_of(G, tu, tv, ti)] ? kBrickAccumulate : 0));
+                        P.tasks[fill[(size_t)G.lane * per_lane + (size_t)st]++] = T;
+                        const int64_t cu = std::min(64, n - 64 * tu), cv = std::min(kBrickRows, n - kBrickRows * tv),
+                                      ci = std::min(chunk, n - chunk * ti);
+                        P.updates += cu * cv * ci * (int64_t)G.dirs.size();
+                    }
         }
     }
     P.valid = true;
@@ -831,7 +860,7 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
     }
     (void)transposed;
 
-    if (!c->bplan_uploaded || c->d_faces_cap != face_need) {
+    if (!c->bplan_uploaded) {
         if ((rc = ensure(c, &c->d_blayers, &c->d_blayers_cap, P.layers.size()))) return rc;
         if ((rc = ensure(c, &c->d_btasks, &c->d_btasks_cap, P.tasks.size()))) return rc;
         if ((rc = ensure(c, &c->d_bgroups, &c->d_bgroups_cap, P.groups.size()))) return rc;
@@ -869,8 +898,9 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
     // (a subset of the frequency groups) on streams of their own, so that the tail of one lane's stage overlaps the next
     // stage of another.  Lane 0 is the caller's stream.  One pair of events brackets the whole phase: with kernels of
     // several streams in flight together the time of a single launch says little.
-    const size_t nstages = P.stage_updates.size();
-    const int nlanes = std::max(1, std::min(c->lanes, nnu));
+    const size_t nstages = (size_t)P.nstages, per_lane = nstages + 1;
+    const int nulanes = P.glanes > 1 ? 1 : std::max(1, std::min(c->lanes, nnu)); // streams over frequency groups ...
+    const int nlanes = nulanes * P.glanes;                                        // ... or over the groups of directions
     while ((int)c->lane_stream.size() < nlanes - 1) {
         hipStream_t q; hipEvent_t e;
         FTTE_HIP(c, hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
@@ -889,24 +919,26 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
     static const ftte_consts kMath = FTTE_CONSTS_INIT;
     if (!P.groups.empty()) {
         LaunchTiming &T = c->timing[0];
-        T.updates = 0;
-        for (size_t st = 0; st < nstages; ++st) T.updates += P.stage_updates[st] * nnu;
+        T.updates = P.updates * nnu;
         FTTE_HIP(c, hipEventRecord(T.start, stream));
         FTTE_HIP(c, hipEventRecord(c->ev_fork, stream));
         for (int lane = 0; lane < nlanes; ++lane) {
             hipStream_t q = lane == 0 ? stream : c->lane_stream[(size_t)lane - 1];
             if (lane) FTTE_HIP(c, hipStreamWaitEvent(q, c->ev_fork, 0));
-            const int nu0 = (int)((int64_t)nnu * lane / nlanes), nu1 = (int)((int64_t)nnu * (lane + 1) / nlanes);
+            const int gl = P.glanes > 1 ? lane : 0, nl = P.glanes > 1 ? 0 : lane;
+            const int nu0 = (int)((int64_t)nnu * nl / nulanes), nu1 = (int)((int64_t)nnu * (nl + 1) / nulanes);
+            const size_t *off = &P.stage_off[(size_t)gl * per_lane];
             for (size_t st = 0; st < nstages; ++st) {
+                if (off[st + 1] == off[st]) continue;
                 BrickLaunch L;
                 std::memset(&L, 0, sizeof L);
                 L.groups = c->d_bgroups;
-                L.tasks = c->d_btasks + P.stage_off[st];
+                L.tasks = c->d_btasks + off[st];
                 L.uvb = c->d_uvb;
                 L.group_stride = c->ncell;
                 L.face_stride = P.face_elems;
                 L.vface_off = P.vface_off; L.iface_off = P.iface_off;
-                L.n = n; L.ntasks = (int)(P.stage_off[st + 1] - P.stage_off[st]); L.nnu = nu1 - nu0; L.nu0 = nu0; L.chunk = P.chunk;
+                L.n = n; L.ntasks = (int)(off[st + 1] - off[st]); L.nnu = nu1 - nu0; L.nu0 = nu0; L.chunk = P.chunk;
                 L.up = P.up; L.vp = P.vp;
                 L.math = kMath;
                 const int lrc = c->team ? launch_brick_team(L, P.max_dirs, c->brick_waves, q) : launch_brick(L, P.max_dirs, c->brick_waves, q);
@@ -1269,10 +1301,10 @@ int ftte_set_option(ftte_ctx *c, const char *key, int value)
         if (value < 0 || value > 2) return fail(c, FTTE_ERR_ARG, "engine must be 0 (automatic), 1 (ray-following tiles) or 2 (cell-fixed bricks)");
         c->engine = value;
     } else if (!std::strcmp(key, "chunk")) {
-        if (value < 1 || value > 4096) return fail(c, FTTE_ERR_ARG, "chunk (layers per brick) must be 1..4096");
+        if (value < 0 || value > 4096) return fail(c, FTTE_ERR_ARG, "chunk (layers per brick) must be 1..4096, or 0 for the default");
         c->chunk = value;
     } else if (!std::strcmp(key, "group")) {
-        if (value < 1 || value > kBrickMaxDirs) return fail(c, FTTE_ERR_ARG, "group (directions sharing a brick pass) must be 1..8");
+        if (value < 0 || value > kBrickMaxDirs) return fail(c, FTTE_ERR_ARG, "group (directions sharing a brick pass) must be 1..8, or 0 for the default");
         c->group = value;
     } else if (!std::strcmp(key, "lanes")) {
         if (value < 1 || value > 16) return fail(c, FTTE_ERR_ARG, "lanes (streams the brick sweep spreads its frequency groups over) must be 1..16");

@@ -1,4 +1,4 @@
-"""Multi-GPU layout of the diffuse sweep: one process per GPU, directions sharded, J summed with RCCL.
+"""Multi-GPU layout of the diffuse sweep: one process per GPU, frequency groups x directions sharded, J combined with RCCL.
 
 Each (direction, frequency) sweep is independent and reads the opacities only; the single coupling is
 J_nu = sum over directions (transportRoutinesModule.f90:953-955).  Every GPU holds the whole grid (2 GB at
@@ -72,3 +72,79 @@ def allreduce_rates(rates_tensor, group=None):
     """In-place sum of rank-local point-source rates [6][ncell] over the process group; hand the result back to the
     library with StellarTransfer.set_rates before the equilibrium update."""
     return allreduce_J(rates_tensor, group)
+
+
+# ---- frequency groups x directions (SURVEY.md 8(e)) ------------------------------------------------------------------
+
+def decompose(world: int, nnu: int) -> Tuple[int, int]:
+    """(r_nu, r_dir) with r_nu * r_dir == world, frequency groups first: r_nu is the largest divisor of `world` that also
+    divides nnu.  With as many GPUs as groups (8 and 8) every rank owns one group for all directions and nothing has to be
+    reduced; ranks beyond that split the direction list, and their partial J is summed."""
+    import math
+    r_nu = math.gcd(world, nnu)
+    return r_nu, world // r_nu
+
+
+class Shard2D:
+    """Where one rank sits in the (frequency slice, direction slice) grid and what it has to sweep and exchange.
+
+        sh = Shard2D(rank, world, nnu)
+        nu_lo, nu_hi = sh.groups            # this rank's frequency groups
+        phi, theta, w = sh.directions(phi, theta, w)
+        J_full = sh.combine(J_local)        # J_local[nu_hi - nu_lo][ncell] -> J[nnu][ncell] on every rank
+
+    combine = sum over the ranks that hold the same groups for other directions (all-reduce, only if directions are split),
+    then all-gather of the group slices.  Works on any torch.distributed backend (nccl = RCCL on the GPUs, gloo in the
+    CPU tests)."""
+
+    def __init__(self, rank: int, world: int, nnu: int):
+        self.rank, self.world, self.nnu = rank, world, nnu
+        self.r_nu, self.r_dir = decompose(world, nnu)
+        self.i_nu, self.i_dir = rank % self.r_nu, rank // self.r_nu
+        self.groups = shard_bounds(nnu, self.i_nu, self.r_nu)
+        self._dir_group = self._nu_group = None
+        self._made = False
+
+    def directions(self, phi, theta, weight):
+        return shard_directions(phi, theta, weight, self.i_dir, self.r_dir)
+
+    def describe(self) -> str:
+        return (f"{self.r_nu} frequency slice(s) x {self.r_dir} direction slice(s): "
+                + ("no reduction, " if self.r_dir == 1 else "all-reduce over the direction slices, ")
+                + ("nothing to gather" if self.r_nu == 1 else "all-gather of the frequency slices"))
+
+    def _groups(self):
+        import torch.distributed as dist
+        if self._made or self.world == 1:
+            return
+        # every rank creates every group, in the same order
+        for i_nu in range(self.r_nu):
+            ranks = [i_nu + self.r_nu * j for j in range(self.r_dir)]
+            g = dist.new_group(ranks) if self.r_dir > 1 else None
+            if i_nu == self.i_nu:
+                self._dir_group = g
+        for i_dir in range(self.r_dir):
+            ranks = [i + self.r_nu * i_dir for i in range(self.r_nu)]
+            g = dist.new_group(ranks) if self.r_nu > 1 else None
+            if i_dir == self.i_dir:
+                self._nu_group = g
+        self._made = True
+
+    def combine(self, J_local, out=None):
+        """J_local: torch tensor [groups of this rank][ncell] (partial over directions if they are split).  Returns
+        J[nnu][ncell] (`out` if given)."""
+        import torch
+        import torch.distributed as dist
+        if self.world == 1:
+            return J_local
+        self._groups()
+        if self.r_dir > 1:
+            dist.all_reduce(J_local, op=dist.ReduceOp.SUM, group=self._dir_group)
+        if self.r_nu == 1:
+            return J_local
+        if out is None:
+            out = torch.empty((self.nnu, J_local.shape[1]), dtype=J_local.dtype, device=J_local.device)
+        if self.nnu % self.r_nu == 0:
+            dist.all_gather_into_tensor(out, J_local.contiguous(), group=self._nu_group)
+            return out
+        return gather_J(J_local, self.nnu, group=self._nu_group)

@@ -24,7 +24,7 @@ def bricks(engine, request):
     engine.set_option("engine", 2)
     engine.set_option("team", 1 if request.param == "team" else 0)
     yield engine
-    for key, value in (("engine", 0), ("team", 0), ("chunk", 16), ("group", 3), ("share", 2)):
+    for key, value in (("engine", 0), ("team", 0), ("chunk", 0), ("group", 0), ("share", 2), ("lanes", 2)):
         engine.set_option(key, value)
 
 
@@ -90,8 +90,8 @@ def test_bricks_equal_tiles_on_the_full_direction_set(engine, n, chunk):
     J_bricks = engine.transport(phi, theta, w, uvb)
     J_again = engine.transport(phi, theta, w, uvb)
     engine.set_option("engine", 0)
-    engine.set_option("chunk", 16)
-    engine.set_option("group", 3)
+    engine.set_option("chunk", 0)
+    engine.set_option("group", 0)
     assert np.array_equal(J_bricks, J_again)  # no atomics, a fixed order: reproducible bit for bit
     assert np.allclose(J_bricks, J_tiles, rtol=SUM_RTOL, atol=0)
     assert 0 < J_bricks.min() and np.all(J_bricks <= uvb[:, None] * (1 + SUM_RTOL))
@@ -107,3 +107,22 @@ def test_launch_records_account_for_every_update(bricks):
     rec = bricks.launch_records()
     assert sum(u for _, u in rec) == n ** 3 * nnu * len(phi)
     assert all(ms >= 0 for ms, _ in rec)
+
+
+@pytest.mark.parametrize("lanes", [1, 3, 5])
+def test_streams_over_frequency_groups_or_direction_groups(bricks, lanes):
+    """The stage sequence is issued on several streams: over the frequency groups when there are enough of them (4 groups,
+    3 streams), else over the groups of directions (1 frequency group: the accumulator-sharing sets are dealt to the
+    streams).  Same bits whatever the number of streams."""
+    n = 64
+    phi, theta, w = O.healpix_directions(2)
+    for nnu in (4, 1):
+        kappa, uvb, box = synthetic.uniform_workload(n, nnu, seed=21, tau_median=0.2)
+        bricks.set_uniform_grid(n, box)
+        bricks.set_opacity(kappa)
+        bricks.set_option("lanes", 1)
+        J_one = bricks.transport(phi, theta, w, uvb)
+        bricks.set_option("lanes", lanes)
+        J_many = bricks.transport(phi, theta, w, uvb)
+        assert np.array_equal(J_one, J_many)
+        assert np.allclose(J_one, O.sweep_uniform(n, kappa, box, phi, theta, w, uvb, arith=O.ARITH_DEVICE), rtol=SUM_RTOL, atol=0)

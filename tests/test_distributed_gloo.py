@@ -105,3 +105,74 @@ def test_sharded_groups_and_stars(tmp_path, world):
     rates = np.load(tmp_path / "rates.npy")
     scale = np.abs(ref).max(axis=1, keepdims=True)
     assert np.all(np.abs(rates - ref) <= 1e-13 * np.abs(ref) + 1e-15 * scale)
+
+
+def _worker_2d(rank, world, port, n, nnu, out_dir, use_gpu):
+    """What bench.py --gpus N does per rank: its frequency slice x its direction slice, then Shard2D.combine.  The sweep is
+    the oracle on CPU, or (use_gpu, run by the -m gpu test on one card) the HIP library through the C ABI."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    import torch
+    import torch.distributed as dist
+    import _oracle as O
+    from radiativetransfer_amd import synthetic
+    from radiativetransfer_amd.distributed import Shard2D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    kappa, uvb, box = synthetic.uniform_workload(n, nnu, seed=9, tau_median=0.3)
+    phi, theta, w = O.healpix_directions(2)
+    sh = Shard2D(rank, world, nnu)
+    lo, hi = sh.groups
+    p, t, ww = sh.directions(phi, theta, w)
+    if use_gpu:
+        import radiativetransfer_amd as rt
+        with rt.DiffuseTransfer(device=0) as eng:
+            eng.set_uniform_grid(n, box)
+            eng.set_opacity(kappa[lo:hi])
+            J_local = eng.transport(p, t, ww, uvb[lo:hi])
+    else:
+        J_local = O.sweep_uniform(n, kappa[lo:hi], box, p, t, ww, uvb[lo:hi], arith=O.ARITH_DEVICE)
+    J = sh.combine(torch.from_numpy(np.ascontiguousarray(J_local)))
+    np.save(os.path.join(out_dir, f"J{rank}.npy"), J.numpy())
+    if rank == 0:
+        with open(os.path.join(out_dir, "layout.txt"), "w") as f:
+            f.write(sh.describe())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _check_2d(tmp_path, world, nnu, n, use_gpu):
+    import torch.multiprocessing as mp
+    import _oracle as O
+    from radiativetransfer_amd import synthetic
+    from radiativetransfer_amd.distributed import decompose
+    O.build()
+    port = 33500 + os.getpid() % 2000 + 7 * world + nnu
+    mp.spawn(_worker_2d, args=(world, port, n, nnu, str(tmp_path), use_gpu), nprocs=world, join=True)
+    kappa, uvb, box = synthetic.uniform_workload(n, nnu, seed=9, tau_median=0.3)
+    phi, theta, w = O.healpix_directions(2)
+    ref = O.sweep_uniform(n, kappa, box, phi, theta, w, uvb, arith=O.ARITH_DEVICE)
+    for rank in range(world):  # every rank ends up with the whole J
+        J = np.load(tmp_path / f"J{rank}.npy")
+        assert J.shape == ref.shape
+        assert np.allclose(J, ref, rtol=64 * np.finfo(float).eps, atol=0)
+    r_nu, r_dir = decompose(world, nnu)
+    assert r_nu * r_dir == world and nnu % r_nu == 0
+    return open(tmp_path / "layout.txt").read()
+
+
+@pytest.mark.parametrize("world,nnu,expect", [(2, 2, "2 frequency slice(s) x 1 direction"), (3, 2, "1 frequency slice(s) x 3 direction"),
+                                              (4, 2, "2 frequency slice(s) x 2 direction"), (2, 8, "2 frequency slice(s) x 1 direction")])
+def test_frequency_by_direction_sharding(tmp_path, world, nnu, expect):
+    """bench.py's multi-GPU layout on CPU (gloo): frequency groups first (no reduction, an all-gather), directions split
+    only beyond that (all-reduce within a frequency slice, then the all-gather)."""
+    assert _check_2d(tmp_path, world, nnu, 8, use_gpu=False).startswith(expect)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,nnu", [(2, 4), (3, 2)])
+def test_frequency_by_direction_sharding_through_the_library(tmp_path, world, nnu):
+    """The same layout with every rank sweeping its share on the GPU through libftte.so (the ranks share the one card of the
+    test box; the exchange stays on gloo: RCCL needs one device per rank)."""
+    _check_2d(tmp_path, world, nnu, 24, use_gpu=True)
