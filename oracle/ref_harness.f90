@@ -8,9 +8,14 @@
 ! rather than out of a restatement of it.
 !
 ! What the reference does around these calls lives in the main program
-! (equiSources.f90:1385-1806) and is not callable; this harness performs the same
-! sequence of steps (fold direction, per-layer pattern advance, pattern
-! attachment, neighbour linking, transport) through the reference's public
+! (equiSources.f90:1385-1806) and is not callable.  Two routes:
+!   * dumpGeometry + 16 (what the goldens are made with): module driverExtract, the reference's own lines
+!     :1393-1801 lifted by line range at build time (oracle/Makefile), INCLUDING the inline branch for unrefined
+!     base cells (:1580-1788) -- nothing of the per-direction work is restated;
+!   * otherwise this file's sweepOneDirection: the same sequence of steps (fold direction, per-layer pattern advance,
+!     pattern attachment, neighbour linking, transport) written out here through the reference's public routines -- kept
+!     as a cross-check (tests assert both routes give the same bits) and for the grid-less geometry dump;
+!     it calls the reference's public
 ! routines: setPattern, setRaysRefined, localizeCellFindNeighbours, transport,
 ! patternNullify, rotateIndices.  Every leaf cell, refined or not, is pushed
 ! through the reference `transport` (transportRoutinesModule.f90:560), whose leaf
@@ -39,10 +44,12 @@ program ref_harness
   use definitions
   use rotateIndicesModule
   use transportRoutinesModule
+  use driverExtract
 
   implicit none
 
   integer :: n, ncell, ndir, dumpGeometry, idir, cursor, ios
+  logical :: liftedDriver
   integer, allocatable :: lev(:)
   real(kind=RealKind), allocatable :: kap(:,:), jout(:,:), phiIn(:), thetaIn(:), wIn(:)
   real(kind=RealKind) :: box, uvbIn(3)
@@ -61,6 +68,11 @@ program ref_harness
   open(11, file=trim(caseName), access='stream', form='unformatted', status='old', iostat=ios)
   if (ios /= 0) stop 'ref_harness: cannot open case file'
   read(11) n, ncell, ndir, dumpGeometry
+  ! dumpGeometry + 16: every direction goes through the reference's OWN driver lines (module driverExtract, lifted from
+  ! equiSources.f90:1393-1801 by oracle/Makefile) instead of this file's sweepOneDirection
+  liftedDriver = iand(dumpGeometry, 16) /= 0
+  dumpGeometry = iand(dumpGeometry, 15)
+  if (liftedDriver .and. dumpGeometry == 2) stop 'ref_harness: the lifted driver needs a grid (use dumpGeometry = 1)'
   read(11) box
   read(11) uvbIn
   allocate(lev(ncell), kap(ncell,3), jout(ncell,3), phiIn(ndir), thetaIn(ndir), wIn(ndir))
@@ -102,9 +114,16 @@ program ref_harness
   open(12, file=trim(outName), access='stream', form='unformatted', status='replace')
 
   call system_clock(tick0, tickRate)
-  do idir = 1, ndir
-     call sweepOneDirection(phiIn(idir), thetaIn(idir), wIn(idir))
-  enddo
+  if (liftedDriver) then
+     if (dumpGeometry /= 0) driverDumpUnit = 12
+     do idir = 1, ndir
+        call referenceDirection(phiIn(idir), thetaIn(idir), wIn(idir), n, n, n)
+     enddo
+  else
+     do idir = 1, ndir
+        call sweepOneDirection(phiIn(idir), thetaIn(idir), wIn(idir))
+     enddo
+  endif
   call system_clock(tick1)
   ! wall time of the direction loop alone (patterns + neighbour links + transport), for bench.py
   write(*,'(a,1x,es16.8)') 'SWEEP_SECONDS', dble(tick1-tick0)/dble(tickRate)

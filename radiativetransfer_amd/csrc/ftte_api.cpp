@@ -116,8 +116,8 @@ struct ftte_ctx {
 
     int rows = 8, slots = 8, waves = 4, stack = 1;
 
-    // which organisation sweeps a uniform grid: 0 = bricks unless emission is on (the tile kernel has the emission
-    // variants), 1 = tile kernel (sweep_kernel), 2 = bricks (brick_kernel)
+    // which organisation sweeps a uniform grid: 0 = the default = 2 = cell-fixed bricks (brick_kernel), 1 = ray-following tiles
+    // (sweep_kernel)
     int engine = 0, chunk = 0, group = 0, brick_waves = 4, share = 2, team = 0, lanes = 2; // chunk, group: 0 = by the parallelism (build_brick_plan)
     std::vector<hipStream_t> lane_stream;   // extra streams of the brick sweep (frequency groups are independent)
     std::vector<hipEvent_t> lane_done;
@@ -857,6 +857,12 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
             c->kappa_ready[l] = true;
             transposed = true;
         }
+        if (P.nacc[l] && c->emit_mode && !c->emis_ready[l]) {
+            if (!c->emis[l]) FTTE_HIP(c, hipMalloc((void **)&c->emis[l], sizeof(double) * c->kappa_cap));
+            if (launch_to_layout(l, c->emis[0], c->emis[l], n, nnu, (long)c->ncell, stream))
+                return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
+            c->emis_ready[l] = true;
+        }
     }
     (void)transposed;
 
@@ -878,6 +884,7 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
             const BrickPlan::Group &H = P.groups[g];
             const DirPlan &D0 = P.dirs[H.dirs[0]];
             G[g].kappa = c->kappa[H.layout];
+            G[g].emis = c->emit_mode ? c->emis[H.layout] : nullptr;
             G[g].J = c->acc[H.layout][H.acc];
             G[g].org = D0.org; G[g].si = D0.si; G[g].sv = D0.sv; G[g].su = D0.su;
             G[g].ndir = (int)H.dirs.size();
@@ -940,8 +947,9 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
                 L.vface_off = P.vface_off; L.iface_off = P.iface_off;
                 L.n = n; L.ntasks = (int)(off[st + 1] - off[st]); L.nnu = nu1 - nu0; L.nu0 = nu0; L.chunk = P.chunk;
                 L.up = P.up; L.vp = P.vp;
+                L.emit = c->emit_mode;
                 L.math = kMath;
-                const int lrc = c->team ? launch_brick_team(L, P.max_dirs, c->brick_waves, q) : launch_brick(L, P.max_dirs, c->brick_waves, q);
+                const int lrc = (c->team && !c->emit_mode) ? launch_brick_team(L, P.max_dirs, c->brick_waves, q) : launch_brick(L, P.max_dirs, c->brick_waves, q);
                 if (lrc) return fail(c, lrc == -1 ? FTTE_ERR_ARG : FTTE_ERR_NO_DEVICE, "brick kernel launch failed");
             }
             if (lane) {
@@ -1340,10 +1348,7 @@ int ftte_diffuse_sweep_device(ftte_ctx *c, int ndir, const double *phi, const do
     const size_t per_acc = (size_t)nnu * c->ncell;
 
     if (c->use_forest) return forest_sweep(c, ndir, phi, theta, w, uvb, J_dev, stream);
-    if (c->engine == 2 || (c->engine == 0 && !c->emit_mode)) {
-        if (c->emit_mode) return fail(c, FTTE_ERR_UNSUPPORTED, "the brick engine has no emission variant: set option \"engine\" to 0 or 1");
-        return brick_sweep(c, ndir, phi, theta, w, uvb, J_dev, stream);
-    }
+    if (c->engine != 1) return brick_sweep(c, ndir, phi, theta, w, uvb, J_dev, stream);
     // the emission variants of the tiled kernel are built for one shape
     const int rows = c->emit_mode ? 8 : c->rows, stack = c->emit_mode ? 1 : c->stack;
     if ((rc = build_plan(c, rows, stack, ndir, phi, theta, w))) return rc;

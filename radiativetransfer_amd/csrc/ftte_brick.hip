@@ -52,8 +52,16 @@ __device__ __forceinline__ double shift_up_inject(double x, double in0)
 // on return the ray leaving through its top.  uin/vin: where the rays handed over by the brick to the left / below wait
 // (nullptr: the domain boundary, the inflow enters there); uout/vout: where this brick's leaving rays go (nullptr: they
 // leave the domain or nobody is there).
-template <int SHAPE>
+template <int EMIT>
+__device__ __forceinline__ double brick_segment(const ftte_consts &K, double &I, double kap, double x, double dpath)
+{
+    if (EMIT == 0) return ftte_segment(&K, &I, kap * dpath);
+    return ftte_segment_emit(&K, &I, kap * dpath, EMIT == 1 ? x : 0.0, EMIT == 2 ? x : 0.0);
+}
+
+template <int SHAPE, int EMIT>
 __device__ __forceinline__ void brick_step(const ftte_consts &K, double (&cur)[kBrickRows], const double (&kap)[kBrickRows],
+                                           const double (&xs)[EMIT ? kBrickRows : 1],
                                            double (&Jacc)[kBrickRows], bool third_first, double d0, double d1, double d2,
                                            double w, double uvb, gcbyte *uin, gbyte *uout, gcbyte *vin, gbyte *vout, int lane)
 {
@@ -75,7 +83,7 @@ __device__ __forceinline__ void brick_step(const ftte_consts &K, double (&cur)[k
 #pragma unroll
     for (int r = 0; r < kBrickRows; ++r) {
         double I = cur[r];
-        const double m0 = ftte_segment(&K, &I, kap[r] * d0); // xy piece, in the ray's own cell
+        const double m0 = brick_segment<EMIT>(K, I, kap[r], xs[EMIT ? r : 0], d0); // xy piece, in the ray's own cell
         double acc = m0;
         if (SHAPE == RC_ONE) {
             cur[r] = I;
@@ -83,22 +91,22 @@ __device__ __forceinline__ void brick_step(const ftte_consts &K, double (&cur)[k
         } else if (SHAPE == RC_TWO_U) {
             if (hands_u) *(gdouble *)(uout + 8 * r) = I;
             I = shift_up_inject(I, ui[r]);
-            acc += ftte_segment(&K, &I, kap[r] * d1);
+            acc += brick_segment<EMIT>(K, I, kap[r], xs[EMIT ? r : 0], d1);
             cur[r] = I;
             Jacc[r] += ftte_cell_mean(acc, 2, w);
         } else if (SHAPE == RC_TWO_V) {
             double b = carry;
             carry = I;
-            acc += ftte_segment(&K, &b, kap[r] * d1);
+            acc += brick_segment<EMIT>(K, b, kap[r], xs[EMIT ? r : 0], d1);
             cur[r] = b;
             Jacc[r] += ftte_cell_mean(acc, 2, w);
         } else if (SHAPE == RC_THREE_U) { // 2nd piece one column on, 3rd one row on
             if (hands_u) *(gdouble *)(uout + 8 * r) = I;
             I = shift_up_inject(I, ui[r]);
-            const double m1 = ftte_segment(&K, &I, kap[r] * d1);
+            const double m1 = brick_segment<EMIT>(K, I, kap[r], xs[EMIT ? r : 0], d1);
             double c = carry;
             carry = I;
-            const double m2 = ftte_segment(&K, &c, kap[r] * d2);
+            const double m2 = brick_segment<EMIT>(K, c, kap[r], xs[EMIT ? r : 0], d2);
             // reference order: xy + xz + yz, whatever the chain order (transportRoutinesModule.f90:695-941)
             acc += third_first ? m2 : m1;
             acc += third_first ? m1 : m2;
@@ -107,10 +115,10 @@ __device__ __forceinline__ void brick_step(const ftte_consts &K, double (&cur)[k
         } else { // RC_THREE_V: 2nd piece one row on, 3rd one column on
             double b = carry;
             carry = I;
-            const double m1 = ftte_segment(&K, &b, kap[r] * d1);
+            const double m1 = brick_segment<EMIT>(K, b, kap[r], xs[EMIT ? r : 0], d1);
             if (hands_u) *(gdouble *)(uout + 8 * r) = b;
             b = shift_up_inject(b, ui[r]);
-            const double m2 = ftte_segment(&K, &b, kap[r] * d2);
+            const double m2 = brick_segment<EMIT>(K, b, kap[r], xs[EMIT ? r : 0], d2);
             acc += third_first ? m2 : m1;
             acc += third_first ? m1 : m2;
             cur[r] = b;
@@ -123,7 +131,7 @@ __device__ __forceinline__ void brick_step(const ftte_consts &K, double (&cur)[k
 }
 
 // grid: ntasks * nnu workgroups of one wavefront; dynamic LDS: 4 KB per direction of the largest group
-template <int WAVES>
+template <int WAVES, int EMIT>
 __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
 {
     extern __shared__ double state[]; // [direction][row][lane]
@@ -146,6 +154,7 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
     const long org = G->org;
     gcbyte *kbase = (gcbyte *)(G->kappa + (long)nu * L.group_stride + org);
     gbyte *jbase = (gbyte *)(G->J + (long)nu * L.group_stride + org);
+    gcbyte *xbase = EMIT ? (gcbyte *)(G->emis + (long)nu * L.group_stride + org) : nullptr;
 
     // this lane's column and the brick's rows (1-based cell indices; clamped copies for loads of a ragged last brick)
     const int cu = 64 * tu + lane + 1;
@@ -177,20 +186,21 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
     }
 
     // the opacity of the brick's cells, one layer ahead of the layer being crossed
-    double kap_next[R];
+    double kap_next[R], xs_next[EMIT ? R : 1];
     {
         gcbyte *kplane = kbase + 8l * i0 * si;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int row = (cv0 + r < n) ? cv0 + r : n;
             kap_next[r] = *(gcdouble *)(kplane + row * row_bytes + off0);
+            if (EMIT) xs_next[r] = *(gcdouble *)(xbase + 8l * i0 * si + row * row_bytes + off0);
         }
     }
     for (int i = i0; i <= i1; ++i) {
         const int il = i - i0;
-        double kap[R], Jacc[R];
+        double kap[R], xs[EMIT ? R : 1], Jacc[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) { kap[r] = kap_next[r]; Jacc[r] = 0.0; }
+        for (int r = 0; r < R; ++r) { kap[r] = kap_next[r]; Jacc[r] = 0.0; if (EMIT) xs[r] = xs_next[r]; }
         gbyte *jplane = jbase + 8l * i * si;
         if (accumulate && own_lane) { // what the groups before this one left in these cells
 #pragma unroll
@@ -203,6 +213,7 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
             for (int r = 0; r < R; ++r) {
                 const int row = (cv0 + r < n) ? cv0 + r : n;
                 kap_next[r] = *(gcdouble *)(kplane + row * row_bytes + off0);
+                if (EMIT) xs_next[r] = *(gcdouble *)(xbase + 8l * (i + 1) * si + row * row_bytes + off0);
             }
         }
         for (int d = 0; d < ndir; ++d) {
@@ -220,15 +231,15 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
             for (int r = 0; r < R; ++r) cur[r] = state[(d * R + r) * 64 + lane];
             const bool third_first = rc == RC_THREE_U_SWAP || rc == RC_THREE_V_SWAP;
             switch (rc) {
-            case RC_ONE: brick_step<RC_ONE>(L.math, cur, kap, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane); break;
-            case RC_TWO_U: brick_step<RC_TWO_U>(L.math, cur, kap, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane); break;
-            case RC_TWO_V: brick_step<RC_TWO_V>(L.math, cur, kap, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane); break;
+            case RC_ONE: brick_step<RC_ONE, EMIT>(L.math, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane); break;
+            case RC_TWO_U: brick_step<RC_TWO_U, EMIT>(L.math, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane); break;
+            case RC_TWO_V: brick_step<RC_TWO_V, EMIT>(L.math, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane); break;
             case RC_THREE_U:
             case RC_THREE_U_SWAP:
-                brick_step<RC_THREE_U>(L.math, cur, kap, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane);
+                brick_step<RC_THREE_U, EMIT>(L.math, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane);
                 break;
             default:
-                brick_step<RC_THREE_V>(L.math, cur, kap, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane);
+                brick_step<RC_THREE_V, EMIT>(L.math, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane);
                 break;
             }
 #pragma unroll
@@ -348,16 +359,17 @@ __global__ void __launch_bounds__(64 * kBrickMaxDirs, WAVES) brick_team_kernel(c
         gcbyte *vin = has_v_in ? (gcbyte *)f + 8 * (v_in + (long)il * up) : nullptr;
         gbyte *vout = has_v_out ? f + 8 * (v_out + (long)il * up) : nullptr;
         const bool third_first = rc == RC_THREE_U_SWAP || rc == RC_THREE_V_SWAP;
+        const double no_xs[1] = {0.0};
         switch (rc) {
-        case RC_ONE: brick_step<RC_ONE>(L.math, cur, kap, Jc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane); break;
-        case RC_TWO_U: brick_step<RC_TWO_U>(L.math, cur, kap, Jc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane); break;
-        case RC_TWO_V: brick_step<RC_TWO_V>(L.math, cur, kap, Jc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane); break;
+        case RC_ONE: brick_step<RC_ONE, 0>(L.math, cur, kap, no_xs, Jc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane); break;
+        case RC_TWO_U: brick_step<RC_TWO_U, 0>(L.math, cur, kap, no_xs, Jc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane); break;
+        case RC_TWO_V: brick_step<RC_TWO_V, 0>(L.math, cur, kap, no_xs, Jc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane); break;
         case RC_THREE_U:
         case RC_THREE_U_SWAP:
-            brick_step<RC_THREE_U>(L.math, cur, kap, Jc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane);
+            brick_step<RC_THREE_U, 0>(L.math, cur, kap, no_xs, Jc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane);
             break;
         default:
-            brick_step<RC_THREE_V>(L.math, cur, kap, Jc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane);
+            brick_step<RC_THREE_V, 0>(L.math, cur, kap, no_xs, Jc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane);
             break;
         }
         if (ndir == 1) { // nobody to add up with
@@ -412,10 +424,13 @@ int launch_brick(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stre
     if (max_dirs < 1 || max_dirs > kBrickMaxDirs) return -1;
     const dim3 grid((unsigned)L.ntasks * (unsigned)L.nnu);
     const size_t lds = (size_t)max_dirs * kBrickRows * 64 * sizeof(double);
-    switch (waves) {
-    case 2: hipLaunchKernelGGL((brick_kernel<2>), grid, dim3(64), lds, stream, L); break;
-    case 3: hipLaunchKernelGGL((brick_kernel<3>), grid, dim3(64), lds, stream, L); break;
-    case 4: hipLaunchKernelGGL((brick_kernel<4>), grid, dim3(64), lds, stream, L); break;
+    // emission: the log-mean's own division and polynomials need more registers than three waves per SIMD leave
+    if (L.emit == 1) hipLaunchKernelGGL((brick_kernel<2, 1>), grid, dim3(64), lds, stream, L);
+    else if (L.emit == 2) hipLaunchKernelGGL((brick_kernel<2, 2>), grid, dim3(64), lds, stream, L);
+    else switch (waves) {
+    case 2: hipLaunchKernelGGL((brick_kernel<2, 0>), grid, dim3(64), lds, stream, L); break;
+    case 3: hipLaunchKernelGGL((brick_kernel<3, 0>), grid, dim3(64), lds, stream, L); break;
+    case 4: hipLaunchKernelGGL((brick_kernel<4, 0>), grid, dim3(64), lds, stream, L); break;
     default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;

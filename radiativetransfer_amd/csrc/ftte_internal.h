@@ -93,6 +93,7 @@ struct BrickDir {
 struct BrickGroup {
     BrickDir dir[kBrickMaxDirs];
     const double *kappa; // opacity in the layout of this izone's march axis, frequency group 0
+    const double *emis;  // emissivity or source function in the same layout (BrickLaunch::emit), else null
     double *J;           // this group's accumulator (same layout); shared with other groups only as BrickTask says
     int64_t org;         // as DirRec
     int32_t si, sv, su;
@@ -114,6 +115,7 @@ struct BrickLaunch {
     int64_t vface_off, iface_off; // where the v-face and i-face rings start inside a direction's block (u-face ring at 0)
     int32_t n, ntasks, nnu, chunk; // nnu: frequency groups THIS launch sweeps, nu0, nu0 + 1, ...
     int32_t nu0;
+    int32_t emit;             // 0 none, 1 BrickGroup::emis is the reference's eta, 2 a source function (LaunchRec::emit)
     int32_t up, vp;           // padded extents: 64 * ntu, kBrickRows * ntv
     ftte_consts math;
 };

@@ -202,7 +202,12 @@ FTTE_HD double ftte_segment_emit(const ftte_consts *K, double *I, double tau, do
     /* (Iin-Iout)/log(Iin/Iout) = A s/atanh(s) with A = (Iin+Iout)/2, s = (Iin-Iout)/(Iin+Iout).  While Iin/Iout < sqrt(2)
      * (s < s_max: wherever the field is near the source function, and in every thin segment) s/atanh(s) = 1 + z h(z),
      * z = s^2, is a polynomial: one division, no logarithm. */
-    const double s = FTTE_DIV(diff, sum);
+    /* Deep inside an opaque, source-free region the intensities fall through the bottom of the normal range: below 2^-900 both
+     * operands are first scaled by 2^200 (exact, and the quotient is the same number), so that the device's division -- a
+     * reciprocal refined by Newton steps, which needs normal operands and a representable 1/sum -- and the host's `/` still
+     * round the same quotient the same way instead of the device producing NaN from 1/subnormal = inf. */
+    const double lift = (sum < 0x1p-900) ? 0x1p+200 : 1.0;
+    const double s = FTTE_DIV(diff * lift, sum * lift);
     const double z = s * s;
     double h = K->mn[6];
     h = FTTE_FMA(h, z, K->mn[5]);
@@ -213,7 +218,7 @@ FTTE_HD double ftte_segment_emit(const ftte_consts *K, double *I, double tau, do
     h = FTTE_FMA(h, z, K->mn[0]);
     double falling = FTTE_FMA(rising * z, h, rising);
     if (FTTE_ANY(s >= K->s_max)) { /* a steep drop somewhere in the wavefront: the general form for those lanes */
-        double steep = diff / ftte_log1p(K, diff / Iout); /* Iout == 0: selected away below */
+        double steep = diff / ftte_log1p(K, diff / Iout); /* Iout == 0: selected away below (IEEE divisions: the compiler's own) */
         FTTE_KEEP(steep);
         falling = (s >= K->s_max) ? steep : falling;
     }

@@ -33,13 +33,19 @@ HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
 GEOM_REC = np.dtype([("xy", "<f8", 3), ("xz", "<f8", 3), ("yz", "<f8", 3), ("flags", "<i4", 5)])
 
 
-def run_reference(n, level, kappa3, box, uvb3, phi, theta, w, dump_geometry=0):
-    """dump_geometry: 0 J only; 1 J + geometry records; 2 geometry records only (no grid needed)."""
+def run_reference(n, level, kappa3, box, uvb3, phi, theta, w, dump_geometry=0, lifted=True):
+    """dump_geometry: 0 J only; 1 J + geometry records; 2 geometry records only (no grid needed).
+    lifted: every direction goes through the reference's own driver lines (equiSources.f90:1393-1801 lifted by
+    oracle/Makefile, inline base-cell branch included); False: through ref_harness.f90's own restatement of the driver's
+    steps (cross-check; the only route for the grid-less geometry dump)."""
     ncell, ndir = len(level), len(phi)
+    if lifted and dump_geometry == 2:
+        raise ValueError("the lifted driver needs a grid")
+    header_flag = int(dump_geometry) + (16 if lifted else 0)
     with tempfile.TemporaryDirectory() as tmp:
         case, out = os.path.join(tmp, "case.bin"), os.path.join(tmp, "out.bin")
         with open(case, "wb") as f:
-            f.write(struct.pack("<4i", n, ncell, ndir, int(dump_geometry)))
+            f.write(struct.pack("<4i", n, ncell, ndir, header_flag))
             f.write(struct.pack("<d", box))
             f.write(np.asarray(uvb3, "<f8").tobytes())
             f.write(np.asarray(level, "<i4").tobytes())
@@ -94,9 +100,16 @@ def main():
 
     uvb3 = synthetic.frequency_groups(3)[2]
 
+    def both_routes(n, level, kappa, box, dirs):
+        """The lifted driver (what is stored) and the harness's own sequence of the same steps: the same bits."""
+        J, _ = run_reference(n, level, kappa, box, uvb3, *dirs)
+        J2, _ = run_reference(n, level, kappa, box, uvb3, *dirs, lifted=False)
+        assert np.array_equal(J, J2), "lifted driver and restated driver disagree"
+        return J
+
     def uniform_case(name, n, kappa, dirs, box=1.0):
         level = np.zeros(n ** 3, np.int32)
-        J, _ = run_reference(n, level, kappa, box, uvb3, *dirs)
+        J = both_routes(n, level, kappa, box, dirs)
         save(name, n=n, level=level, kappa=kappa, box=box, uvb=uvb3, phi=dirs[0], theta=dirs[1], w=dirs[2], J=J)
 
     # (1) transparent box: J must equal uvb * sum(w)
@@ -117,26 +130,67 @@ def main():
     rho = synthetic.lognormal_density(len(level), seed=99)
     kap = (0.3 * 8) * synthetic.frequency_groups(3)[1][:, None] * rho[None, :]
     dirs = one_per_izone()
-    J, _ = run_reference(8, level, kap, 1.0, uvb3, *dirs)
+    J = both_routes(8, level, kap, 1.0, dirs)
     save("amr8_block_level1", n=8, level=level, kappa=kap, box=1.0, uvb=uvb3, phi=dirs[0], theta=dirs[1], w=dirs[2], J=J)
     # (6) AMR: two nested levels in three scattered base cells, 48 directions
     level = synthetic.refine_levels(6, [(1, 1, 1), (2, 3, 4), (4, 4, 1)], depth=2)
     rho = synthetic.lognormal_density(len(level), seed=5)
     kap = (0.4 * 6) * synthetic.frequency_groups(3)[1][:, None] * rho[None, :]
     dirs = _oracle.healpix_directions(2)
-    J, _ = run_reference(6, level, kap, 1.0, uvb3, *dirs)
+    J = both_routes(6, level, kap, 1.0, dirs)
     save("amr6_scattered_level2", n=6, level=level, kappa=kap, box=1.0, uvb=uvb3, phi=dirs[0], theta=dirs[1], w=dirs[2], J=J)
 
-    # (7) geometry: fold + per-layer patterns. All 192 directions x 16 layers, 12 directions x 256 layers.
-    for name, n, dirs in (("geometry_192dir_16layers", 16, _oracle.healpix_directions(3)),
-                          ("geometry_12dir_256layers", 256, _oracle.healpix_directions(1))):
-        _, geo = run_reference(n, np.zeros(0, np.int32), np.zeros((3, 0)), 1.0, uvb3, *dirs, dump_geometry=2)
+    # (7) geometry: fold + per-layer patterns.  All 192 directions x 16 layers through the lifted driver (on a transparent 16^3
+    #     grid) and, bit for bit the same, through the grid-less route; 12 directions x 256 layers through the grid-less route
+    #     (a 256^3 tree of the reference's 680-byte cells is 11 GB).
+    def blank(geo):
         # inactive pieces hold whatever the reference's freshly allocated pattern had in memory: blank them
         lay = geo["layers"]
         lay["xz"][lay["flags"][..., 0] == 0] = 0.0
         lay["yz"][lay["flags"][..., 1] == 0] = 0.0
-        save(name, n=n, phi_in=dirs[0], theta_in=dirs[1], izone=geo["izone"], phi=geo["phi"], theta=geo["theta"],
-             layers=geo["layers"])
+        return geo
+
+    dirs = _oracle.healpix_directions(3)
+    _, geo = run_reference(16, np.zeros(16 ** 3, np.int32), np.zeros((3, 16 ** 3)), 1.0, uvb3, *dirs, dump_geometry=1)
+    _, geo2 = run_reference(16, np.zeros(0, np.int32), np.zeros((3, 0)), 1.0, uvb3, *dirs, dump_geometry=2, lifted=False)
+    geo, geo2 = blank(geo), blank(geo2)
+    for key in ("izone", "phi", "theta"):
+        assert np.array_equal(geo[key], geo2[key]), key
+    assert geo["layers"].tobytes() == geo2["layers"].tobytes(), "lifted driver and restated driver build different patterns"
+    save("geometry_192dir_16layers", n=16, phi_in=dirs[0], theta_in=dirs[1], izone=geo["izone"], phi=geo["phi"], theta=geo["theta"],
+         layers=geo["layers"])
+    dirs = _oracle.healpix_directions(1)
+    _, geo = run_reference(256, np.zeros(0, np.int32), np.zeros((3, 0)), 1.0, uvb3, *dirs, dump_geometry=2, lifted=False)
+    geo = blank(geo)
+    save("geometry_12dir_256layers", n=256, phi_in=dirs[0], theta_in=dirs[1], izone=geo["izone"], phi=geo["phi"], theta=geo["theta"],
+         layers=geo["layers"])
+
+    # (8) BASELINE configs[0]: 64^3 uniform, 1 frequency group, 6 directions -- the canonical direction (phi, theta) =
+    #     (0.3, 1.1) carried into izones 1, 2, 3 (march along storage i, j, k) and 13, 14, 15 (the same with theta < 0),
+    #     SURVEY.md 8(d) config 1.  The opacities are the bench workload's generator (seed in the file, not the 2 MB array);
+    #     the harness always carries three groups, the first is stored.
+    n = 64
+    kap64, uvb64, box64 = synthetic.uniform_workload(n, 3, seed=12345, tau_median=0.1)
+    dirs = config1_directions()
+    J, _ = run_reference(n, np.zeros(n ** 3, np.int32), kap64, box64, uvb64, *dirs)
+    zones = [_oracle.fold_direction(p, t)[2] for p, t in zip(dirs[0], dirs[1])]
+    assert zones == [1, 2, 3, 13, 14, 15], zones
+    save("config1_uniform64_6dir", n=n, seed=12345, tau_median=0.1, nnu_generated=3, box=box64, uvb=uvb64[:1], phi=dirs[0], theta=dirs[1],
+         w=dirs[2], izone=np.array(zones, np.int32), J=J[:1])
+
+
+def config1_directions():
+    """Un-folded angles whose fold (equiSources.f90:1395-1454) lands in izones 1, 2, 3, 13, 14, 15 with (nearly) the canonical
+    direction (0.3, 1.1): the fold permutes the axes cyclically so that the dominant one becomes the polar axis."""
+    pc, tc = 0.3, 1.1
+    c = np.array([np.cos(tc) * np.cos(pc), np.cos(tc) * np.sin(pc), np.sin(tc)])  # canonical (x', y', z')
+    vecs = [c, np.array([c[2], c[0], c[1]]), np.array([c[1], c[2], c[0]])]       # a = 0, 1 (x dominant), 2 (y dominant)
+    phi, theta = [], []
+    for sign in (1.0, -1.0):
+        for v in vecs:
+            phi.append(np.arctan2(v[1], v[0]))
+            theta.append(sign * np.arcsin(v[2]))
+    return np.array(phi), np.array(theta), np.full(6, 1.0 / 6)
 
 
 if __name__ == "__main__":

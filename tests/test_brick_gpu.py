@@ -126,3 +126,30 @@ def test_streams_over_frequency_groups_or_direction_groups(bricks, lanes):
         J_many = bricks.transport(phi, theta, w, uvb)
         assert np.array_equal(J_one, J_many)
         assert np.allclose(J_one, O.sweep_uniform(n, kappa, box, phi, theta, w, uvb, arith=O.ARITH_DEVICE), rtol=SUM_RTOL, atol=0)
+
+
+def test_emission_through_an_opaque_source_free_slab_stays_finite(engine):
+    """With emission switched on (the reference's log-mean (Iin-Iout)/log(Iin/Iout) is then evaluated from the intensities)
+    a ray that crosses an opaque region without sources falls through the bottom of the normal range: intensities of
+    1e-300 ... 1e-320 and then 0.  The device's division (reciprocal + Newton steps) must give what the host's `/` gives --
+    finite, bit for bit -- instead of NaN from 1/subnormal (both operands are lifted by 2^200 first, csrc/ftte_math.h)."""
+    n = 48
+    tau_cell = np.full((n, n, n), 0.02)
+    tau_cell[10:40] = 23.0                      # 30 opaque layers along storage-i: exp(-690) ~ 1e-300 and below
+    kappa = np.ascontiguousarray((tau_cell * n).reshape(1, n ** 3))
+    S = np.zeros_like(kappa)
+    uvb = np.array([1.0])
+    for engine_id in (1, 2):
+        engine.set_option("engine", engine_id)
+        engine.set_uniform_grid(n, 1.0)
+        engine.set_opacity(kappa)
+        engine.set_source_function(S)
+        for p, t in one_per_izone()[::5]:
+            phi, theta, w = np.array([p]), np.array([t]), np.array([1.0])
+            J = engine.transport(phi, theta, w, uvb)
+            assert np.all(np.isfinite(J)) and np.all(J >= 0)
+            ref = O.sweep_uniform(n, kappa, 1.0, phi, theta, w, uvb, src=S, arith=O.ARITH_DEVICE)
+            assert np.array_equal(J, ref)
+        assert 0 < J[J > 0].min() < 1e-290      # the subnormal range was really crossed
+        engine.set_source_function(None)
+    engine.set_option("engine", 0)

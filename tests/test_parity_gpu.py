@@ -23,12 +23,13 @@ EPS = np.finfo(np.float64).eps
 SUM_RTOL = 64 * EPS
 
 
-@pytest.fixture(autouse=True)
-def tiles(engine):
-    """This file exercises the ray-following tile kernel (option "engine" = 1) with its rows / slots / stack variants, and
-    the refined-grid path; the cell-fixed bricks, which a uniform grid takes by default, are in test_brick_gpu.py."""
-    engine.set_option("engine", 1)
-    yield
+@pytest.fixture(autouse=True, params=["tiles", "bricks"])
+def organisation(engine, request):
+    """Every test of this file runs with both organisations of the uniform-grid sweep: the ray-following tile kernel (option
+    "engine" = 1; its rows / slots / stack variants are options the bricks ignore) and the cell-fixed bricks a uniform grid
+    takes by default (more of them in test_brick_gpu.py).  Refined cell arrays take the forest path either way."""
+    engine.set_option("engine", 1 if request.param == "tiles" else 2)
+    yield request.param
     engine.set_option("engine", 0)
 
 
@@ -59,6 +60,26 @@ def test_every_izone_bitwise(engine, rows, n):
         ref = O.sweep_uniform(n, kappa, box, phi, theta, w, uvb, arith=O.ARITH_DEVICE)
         assert np.array_equal(J, ref), f"izone {O.fold_direction(p, t)[2]}"
     engine.set_option("rows", 8)
+
+
+def test_config1_plumbing_case(engine, golden, organisation):
+    """BASELINE configs[0] on the GPU: 64^3, 1 frequency group, 6 directions (izones 1, 2, 3, 13, 14, 15), against the J the
+    reference's own driver lines produced (tests/golden/config1_uniform64_6dir.npz), with the reference bound, and against
+    the oracle with the device arithmetic."""
+    from test_oracle_golden import config1_case
+    g, n, kappa, box = config1_case(golden)
+    engine.set_uniform_grid(n, box)
+    engine.set_opacity(kappa)
+    J = engine.transport(g["phi"], g["theta"], g["w"], g["uvb"])
+    assert J.shape == (1, n ** 3)
+    args = (n, kappa, box, g["phi"], g["theta"], g["w"], g["uvb"])
+    assert np.allclose(J, O.sweep_uniform(*args, arith=O.ARITH_DEVICE), rtol=SUM_RTOL, atol=0)
+    _, noise = O.sweep_uniform(*args, with_noise=True)
+    assert np.all(np.abs(J - g["J"]) <= reference_bound(n, g["J"], noise))
+    # the same six directions one by one: each alone is bit-identical to the oracle (no summation order involved)
+    for d in range(6):
+        one = (g["phi"][d:d + 1], g["theta"][d:d + 1], g["w"][d:d + 1])
+        assert np.array_equal(engine.transport(*one, g["uvb"]), O.sweep_uniform(n, kappa, box, *one, g["uvb"], arith=O.ARITH_DEVICE))
 
 
 GOLDEN_UNIFORM = ["uniform8_transparent", "uniform16_constant", "uniform16_lognormal_24zones", "uniform24_lognormal_48dir"]
