@@ -189,6 +189,21 @@ module ftte_binding
        integer(c_int), intent(out) :: highest_pixel_level
      end function ftte_point_sources
 
+     ! escape bookkeeping of the last ftte_point_sources call (equiSources.f90:3198-3233, 1342-1348); arrays as Fortran
+     ! (7,nsrc), (7,nsrc), (nsrc), (300,nsrc), (7,nsrc); pass c_null_ptr-associated dummies by using the _opt variant if unwanted
+     integer(c_int) function ftte_point_escape(ctx, nsrc, remaining, boundary, dust, spectrum, fraction) bind(C, name='ftte_point_escape')
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: nsrc
+       real(c_double), intent(out) :: remaining(*), boundary(*), dust(*), spectrum(*), fraction(*)
+     end function ftte_point_escape
+
+     integer(c_int) function ftte_set_output_sigma(ctx, sigma) bind(C, name='ftte_set_output_sigma')
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: sigma(*)
+     end function ftte_set_output_sigma
+
      integer(c_int) function ftte_get_point_rates(ctx, rates) bind(C, name='ftte_get_point_rates')
        import :: c_ptr, c_int, c_double
        type(c_ptr), value :: ctx

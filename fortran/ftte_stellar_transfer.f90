@@ -1,6 +1,6 @@
 ! ftte_stellar_transfer.f90 -- the drop-in for the point-source block: what replaces the star loop
-! equiSources.f90:1260-1362 inside `if (runStellarTransfer)` in the reference driver (without its escape-fraction
-! printout, which reads ndotRemaining/ndotBoundary: diagnostics the library does not accumulate).
+! equiSources.f90:1260-1362 inside `if (runStellarTransfer)` in the reference driver, its per-star `src:` line (escape fractions
+! at the seven output radii, :1342-1357) and the accumulation of cosmicSpectrum (:1350-1351) included.
 !
 ! Compiled TOGETHER WITH the reference (modules `definitions` and `dust`); this repository compiles it only as an
 ! interface check against oracle/_ref/*.mod (fortran/Makefile: target `dropin-check`).
@@ -8,11 +8,16 @@
 !   call setZeroRates(...)                                   ! unchanged, the reference zeroes the cells itself
 !   call ftteRunStellarTransfer(nx, nStars, star, iSpectrum, coefSpectrum)
 !
-! On return krate24..26 and crate24..26 of every leaf hold what the reference's startNewLongRay deposits.
+! On return krate24..26 and crate24..26 of every leaf hold what the reference's startNewLongRay deposits, highestPixelLevel and
+! (per star, as after the reference's loop the last star's) ndotRemaining, ndotBoundary, ndotDust, ndotSpectrum, fraction of
+! module localDefinitions / definitions are set, and cosmicSpectrum has received every star's share; the caller zeroes
+! cosmicSpectrum before (:1258) and divides by nStarsSpecificAge after (:1366), as the reference does around its loop.
+! localDefinitions is a module of the reference's main file: compile this file after it (INTEGRATION.md).
 module ftte_stellar_transfer
 
   use, intrinsic :: iso_c_binding
   use definitions
+  use localDefinitions
   use dust
   use ftte_binding
   implicit none
@@ -30,6 +35,7 @@ contains
     integer(c_int32_t), allocatable :: lev(:), pos(:)
     real(c_double), allocatable :: med(:,:), rates(:,:)
     real(c_double) :: ndot(1), totalIntegral, tmp, coefMetal
+    real(c_double) :: escRemaining(nradius), escBoundary(nradius), escDust(1), escSpectrum(nenergy), escFraction(nradius)
     integer(c_int) :: highest
     integer :: i, j, k, iStar, iMetal
 
@@ -84,6 +90,19 @@ contains
 
           ndot(1) = float(star(iStar)%weight)       ! :1303
           call ftteCheck(ctx, ftte_point_sources(ctx, 1, host, ndot, highest), 'ftte_point_sources')
+          highestPixelLevel = highest
+
+          ! what the tracer kept for this star (:3198-3233, :3336-3345), the src: line (:1342-1357) and the cosmic spectrum
+          call ftteCheck(ctx, ftte_point_escape(ctx, 1, escRemaining, escBoundary, escDust, escSpectrum, escFraction), 'ftte_point_escape')
+          ndotRemaining = escRemaining
+          ndotBoundary = escBoundary
+          ndotDust = escDust(1)
+          ndotSpectrum = escSpectrum
+          fraction = escFraction
+          cosmicSpectrum = cosmicSpectrum + float(star(iStar)%weight) * ndotSpectrum/(ndot(1)-ndotBoundary(nradius))
+          write(*,1015) iStar, star(iStar)%level, med(host(1)+1,1) * mh / (psi * med(host(1)+1,4)), &
+               highestPixelLevel, fraction, star(iStar)%weight
+1015      format('src: ', i5, i3, es13.5, i3, 7f9.5, i8)
        endif
     enddo
 

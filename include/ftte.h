@@ -171,6 +171,17 @@ int ftte_locate_cell(ftte_ctx *ctx, int level, const int32_t *position, int64_t 
  * rates.  highest_pixel_level (may be NULL): the largest value of the reference's highestPixelLevel over
  * these stars.  Deposition uses fp64 atomics: the last bits of the sums depend on the run. */
 int ftte_point_sources(ftte_ctx *ctx, int nsrc, const int64_t *src_cell, const double *src_ndot, int *highest_pixel_level);
+/* The escape bookkeeping startNewLongRay keeps per star (equiSources.f90:3198-3233, :3336-3345; reset per star at :1267-1270), for
+ * the nsrc stars of the LAST ftte_point_sources call, in its order: remaining[nsrc][7] = ndotRemaining and boundary[nsrc][7] =
+ * ndotBoundary at outputRadius = 0.1, 0.3, 1, 3, 10, 30, 100 kpc (equiSources.f90:10), dust[nsrc] = ndotDust, spectrum[nsrc][300] =
+ * ndotSpectrum at the last radius (zero unless the output cross-sections are known: ftte_stellar_beta_table computes them,
+ * ftte_set_output_sigma hands them over), fraction[nsrc][7] as the main program forms it for its `src:` line (:1342-1348:
+ * remaining / (ndot - boundary), or 0 once a whole photon unit has left through the box).  Any pointer may be NULL.  The sums are
+ * accumulated with fp64 atomics like the rates. */
+int ftte_point_escape(ftte_ctx *ctx, int nsrc, double *remaining, double *boundary, double *dust, double *spectrum, double *fraction);
+/* outputSigma24, outputSigma25, outputSigma26, outputSigmaDust (definitionsModule.f90:293-294; stellarBetaTable.f90:119-152),
+ * sigma[4][300] in that order, for tables that came in through ftte_set_rate_tables */
+int ftte_set_output_sigma(ftte_ctx *ctx, const double *sigma);
 /* rates[6][ncell]: krate24, krate25, krate26, crate24, crate25, crate26 (zoneType, definitionsModule.f90:166) */
 int ftte_get_point_rates(ftte_ctx *ctx, double *rates);
 /* The same [6][ncell] in device memory: a copy in the interface's layout (the tracer accumulates into a packed array),

@@ -118,6 +118,14 @@ int fo_point_sources(int n, int64_t ncell, const int32_t *level, const double *H
                      const double *pix /* may be NULL: (phi,theta) of all pixels of levels 1..pix_levels, concatenated */,
                      int pix_levels);
 
+/* the same with the escape bookkeeping of startNewLongRay (:3198-3233, 3336-3345): escape [nsrc][315] = per star
+ * ndotRemaining[7], ndotBoundary[7], ndotDust, ndotSpectrum[300]; out_sigma [4][300] as fo_stellar_beta_table returns it or
+ * NULL (spectrum left zero); fraction [nsrc][7] of the `src:` line (:1342-1348); escape, fraction may be NULL */
+int fo_point_sources_escape(int n, int64_t ncell, const int32_t *level, const double *HI, const double *HeI, const double *HeII,
+                            const double *rho, const double *abun2, double box, int dust, int nsrc, const int64_t *src_leaf,
+                            const double *src_ndot, const double *tables, double *rates, int *highest_pixel_level,
+                            const double *pix, int pix_levels, const double *out_sigma, double *escape, double *fraction);
+
 /* radiativetransfer_amd/csrc/ftte_math.h evaluated on the host, element-wise (for tests of the
  * device arithmetic itself): e = exp(-tau), g = (1-exp(-tau))/tau; out = (acc/nseg)*w. */
 void fo_device_attenuation(int64_t count, const double *tau, double *e, double *g);

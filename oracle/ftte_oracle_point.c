@@ -188,6 +188,11 @@ typedef struct {
     double box, rmax[30];
     double *rates; /* [6][ncell]: krate24, 25, 26, crate24, 25, 26 */
     int highest_pixel_level;
+    /* escape bookkeeping of the star being traced (module variables of localDefinitions, equiSources.f90:9-12, and of
+     * definitions, definitionsModule.f90:290-294): esc = {ndotRemaining[7], ndotBoundary[7], ndotDust, ndotSpectrum[300]} or
+     * NULL; out_sigma = outputSigma24, 25, 26, Dust [4][300] or NULL (then ndotSpectrum stays zero) */
+    double *esc;
+    const double *out_sigma;
     const double *pix; /* optional: (phi, theta) of all pixels of levels 1, 2, ... concatenated, instead of fo_pix2ang_nest */
     int pix_levels;
     /* what the reference passes through module globals */
@@ -340,6 +345,7 @@ static void pt_ray(ptree *T, int start_cell, const double *start_pt, const ppixe
     const int64_t nc = T->ncell;
     while (strategy == PT_PROCEED && !T->err) {
         double len;
+        const double old_radius = radius;
         pt_draw(T, cell, pt, px, lvl, seq, &radius, &strategy, &len);
         const double cell_size = T->box / ((double)((float)(1 << lvl) * (float)T->n));
         const double L = cell_size * len;
@@ -348,6 +354,33 @@ static void pt_ray(ptree *T, int start_cell, const double *start_pt, const ppixe
         double taud = 0.;
         if (T->dust == 1) taud = L * T->HI[c] * F(5.4116737e-22) * T->abun2[c] / F(0.2);
         else if (T->dust == 2) taud = L * F(0.76) * T->rho[c] / F(1.6726231e-24) * F(5.4116737e-22) * T->abun2[c] / F(0.2);
+        if (T->esc) { /* :3198-3233: what is left of the ray where it crosses the output radii, and what left through the box faces */
+            static const float out_radius[7] = {0.1f, 0.3f, 1.f, 3.f, 10.f, 30.f, 100.f}; /* [kpc], equiSources.f90:10 */
+            const double kpc = F(1.e3) * F(3.08568025e18);
+            for (int ir = 0; ir < 7; ++ir) {
+                const double tmp = (double)out_radius[ir] * kpc;
+                const double tmp1 = old_radius * T->box / (double)(float)T->n, tmp2 = radius * T->box / (double)(float)T->n;
+                if (tmp >= tmp1 && tmp <= tmp2) {
+                    const double ratio = (tmp - tmp1) / (tmp2 - tmp1);
+                    T->esc[ir] = T->esc[ir] + ndot * exp(-(ratio * (tau1 + taud) + d1 + dd));
+                    if (ir == 6) {
+                        const double o1 = ratio * tau1 + d1, o2 = ratio * tau2 + d2, o3 = ratio * tau3 + d3, od = ratio * taud + dd;
+                        T->esc[14] = T->esc[14] + ndot * exp(-od);
+                        if (T->out_sigma)
+                            for (int ie = 0; ie < 300; ++ie) {
+                                const double e1 = T->out_sigma[ie] / F(6.30e-18) * o1, e2 = T->out_sigma[600 + ie] / F(7.42e-18) * o2,
+                                             e3 = T->out_sigma[300 + ie] / F(1.58e-18) * o3, e4 = T->out_sigma[900 + ie] / F(5.4116737e-22) * od;
+                                T->esc[15 + ie] = T->esc[15 + ie] + ndot * exp(-(e1 + e2 + e3 + e4));
+                            }
+                    }
+                }
+            }
+            if (strategy == PT_BOUNDARY) {
+                const double tmp = radius * T->box / ((double)(float)T->n * kpc);
+                for (int ir = 0; ir < 7; ++ir)
+                    if ((double)out_radius[ir] > tmp) T->esc[7 + ir] = T->esc[7 + ir] + ndot;
+            }
+        }
         if (fmin(fmin(d1 + tau1, d2 + tau2), fmin(d3 + tau3, dd + taud)) > 100.) strategy = PT_BOUNDARY;
         double a, b, ea, eb;
         fo_get_rates(T->tables, T->dust, 1, d1, d2, d3, dd, &a, &ea);
@@ -385,7 +418,16 @@ static void pt_ray(ptree *T, int start_cell, const double *start_pt, const ppixe
         xb = xb + radius / fn * (cos(child.phi) * cos(child.theta) - cos(px->phi) * cos(px->theta));
         yb = yb + radius / fn * (sin(child.phi) * cos(child.theta) - sin(px->phi) * cos(px->theta));
         zb = zb + radius / fn * (sin(child.theta) - sin(px->theta));
-        if (xb < 0. || xb > 1. || yb < 0. || yb > 1. || zb < 0. || zb > 1.) strategy = PT_BOUNDARY; /* and stays so: :3336-3345 */
+        if (xb < 0. || xb > 1. || yb < 0. || yb > 1. || zb < 0. || zb > 1.) {
+            strategy = PT_BOUNDARY; /* and stays so: :3336-3345 */
+            if (T->esc) {
+                static const float out_radius[7] = {0.1f, 0.3f, 1.f, 3.f, 10.f, 30.f, 100.f};
+                const double kpc = F(1.e3) * F(3.08568025e18);
+                const double tmp = radius * T->box / ((double)(float)T->n * kpc);
+                for (int ir = 0; ir < 7; ++ir)
+                    if ((double)out_radius[ir] > tmp) T->esc[7 + ir] = T->esc[7 + ir] + ndot / 4.;
+            }
+        }
         if (strategy == PT_BOUNDARY) continue;
         /* localizeSplitContinuationCell, :3049-3118 */
         int cseq[40], cl = 0;
@@ -413,11 +455,25 @@ int fo_point_sources(int n, int64_t ncell, const int32_t *level, const double *H
                      const double *src_ndot, const double *tables, double *rates, int *highest_pixel_level,
                      const double *pix, int pix_levels)
 {
+    return fo_point_sources_escape(n, ncell, level, HI, HeI, HeII, rho, abun2, box, dust, nsrc, src_leaf, src_ndot, tables, rates,
+                                   highest_pixel_level, pix, pix_levels, NULL, NULL, NULL);
+}
+
+/* The same with the escape bookkeeping: escape [nsrc][315] = per star ndotRemaining[7], ndotBoundary[7], ndotDust,
+ * ndotSpectrum[300] (needs out_sigma [4][300] = outputSigma24, 25, 26, Dust; NULL leaves the spectrum zero), and
+ * fraction [nsrc][7] as the main program forms it for its `src:` line, equiSources.f90:1342-1348.  Either may be NULL. */
+int fo_point_sources_escape(int n, int64_t ncell, const int32_t *level, const double *HI, const double *HeI, const double *HeII,
+                            const double *rho, const double *abun2, double box, int dust, int nsrc, const int64_t *src_leaf,
+                            const double *src_ndot, const double *tables, double *rates, int *highest_pixel_level,
+                            const double *pix, int pix_levels, const double *out_sigma, double *escape, double *fraction)
+{
     ptree T;
     memset(&T, 0, sizeof T);
     T.pix = pix; T.pix_levels = pix_levels;
     T.levels = level; T.ncell = ncell; T.n = n; T.dust = dust; T.HI = HI; T.HeI = HeI; T.HeII = HeII; T.rho = rho;
     T.abun2 = abun2; T.tables = tables; T.box = box; T.rates = rates;
+    T.out_sigma = out_sigma;
+    double esc_one[315];
     fo_rmax(T.rmax);
     const int nbase = n * n * n;
     T.cap = nbase + 8; T.node = malloc((size_t)T.cap * sizeof *T.node); T.nnode = nbase;
@@ -440,12 +496,18 @@ int fo_point_sources(int n, int64_t ncell, const int32_t *level, const double *H
         }
         seq[0] = c / (n * n) + 1; seq[1] = (c / n) % n + 1; seq[2] = c % n + 1;
         const double centre[3] = {0.5, 0.5, 0.5};
+        T.esc = (escape || fraction) ? esc_one : NULL;
+        memset(esc_one, 0, sizeof esc_one); /* :1267-1270 */
         for (int iray = 1; iray <= 12; ++iray) {
             ppixel px;
             px.level = 1;
             if (pt_pixel(&T, 1, iray - 1, &px.phi, &px.theta)) { T.err = -31; break; }
             pt_ray(&T, host, centre, &px, iray, lvl, seq, 0.0, src_ndot[s] / 12.0, 0., 0., 0., 0.);
         }
+        if (escape) memcpy(escape + 315 * (size_t)s, esc_one, sizeof esc_one);
+        if (fraction)
+            for (int ir = 0; ir < 7; ++ir) /* :1342-1348 */
+                fraction[7 * s + ir] = esc_one[7 + ir] < 1. ? esc_one[ir] / (src_ndot[s] - esc_one[7 + ir]) : 0.;
     }
     if (highest_pixel_level) *highest_pixel_level = T.highest_pixel_level;
     free(T.node);

@@ -9,7 +9,9 @@
 !     time -- by line range, through a temporary file outside the repository -- into the module `pointExtract`
 !     (object and .mod in oracle/_ref/ only).
 ! What the main program does around them (equiSources.f90:296-309 rmax, :1256-1329 the per-source loop) is restated
-! here, without the escape-fraction printout.
+! here; of the escape bookkeeping the tracer accumulates (ndotRemaining, ndotBoundary, ndotDust, ndotSpectrum, :3198-3233,
+! :3336-3345) per star, and the `fraction` the main program prints in its `src:` line (:1342-1348), only that quotient is
+! written out here.
 !
 ! usage: point_harness <case.bin> <out.bin>
 ! case.bin (stream):
@@ -26,6 +28,7 @@
 !   real64 pix(2, 12*4^(L-1)) for L = 1..npixlevel    (phi, theta of pix2ang_nest)
 !   real64 rmax(30)
 !   real64 krate24, krate25, krate26, crate24, crate25, crate26 (ncell each) ; int32 highestPixelLevel
+!   real64 ndotRemaining(7,nsrc), ndotBoundary(7,nsrc), ndotDust(nsrc), ndotSpectrum(300,nsrc), fraction(7,nsrc)
 program point_harness
 
   use definitions
@@ -39,10 +42,10 @@ program point_harness
   integer*8 :: ipix, iray8
   integer, allocatable :: lev(:), srcLeaf(:), srcWeight(:)
   real(kind=RealKind), allocatable :: fHI(:), fHeI(:), fHeII(:), frho(:), fabun(:), sample(:,:), rates(:,:,:), &
-       pix(:,:), kout(:,:)
+       pix(:,:), kout(:,:), escRemaining(:,:), escBoundary(:,:), escDust(:), escSpectrum(:,:), escFraction(:,:)
   real(kind=RealKind) :: box, coefSpectrum, coefMetal, totalIntegral, ndot1
   character(len=512) :: caseName, outName
-  integer :: bi, bj, bk, want, pathLen
+  integer :: bi, bj, bk, want, pathLen, iradius
   integer(kind=8) :: tick0, tick1, tickRate
   integer, target :: path(33)
   type(zoneType), pointer :: host
@@ -131,6 +134,7 @@ program point_harness
   sphere%refined = .false.
   sphere%level = 0
   highestPixelLevel = 0
+  allocate(escRemaining(nradius,nsrc), escBoundary(nradius,nsrc), escDust(nsrc), escSpectrum(nenergy,nsrc), escFraction(nradius,nsrc))
   call system_clock(tick0, tickRate)
   do is = 1, nsrc
      ndotRemaining = 0.
@@ -175,6 +179,19 @@ program point_harness
         call startNewLongRay(host, startingPoint, leafPixel, iray8, int(host%level), path(1:pathLen), 0.d0, &
              ndot1/12.d0, 0.d0, 0.d0, 0.d0, 0.d0, n, n, n)
      enddo
+     ! what the tracer accumulated for this star, and the quotient of equiSources.f90:1342-1348
+     escRemaining(:,is) = ndotRemaining
+     escBoundary(:,is) = ndotBoundary
+     escDust(is) = ndotDust
+     escSpectrum(:,is) = ndotSpectrum
+     do iradius = 1, nradius
+        if (ndotBoundary(iradius).lt.1.) then
+           fraction(iradius) = ndotRemaining(iradius)/(ndot1-ndotBoundary(iradius))
+        else
+           fraction(iradius) = 0.
+        endif
+     enddo
+     escFraction(:,is) = fraction
   enddo
 
   call system_clock(tick1)
@@ -191,6 +208,7 @@ program point_harness
   enddo
   write(12) kout
   write(12) highestPixelLevel
+  write(12) escRemaining, escBoundary, escDust, escSpectrum, escFraction
   close(12)
 
 contains

@@ -57,6 +57,8 @@ SIGNATURES = {
     "ftte_set_zero_rates": (C.c_int, [_vp]),
     "ftte_locate_cell": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "ftte_point_sources": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int64), _dp, _ip]),
+    "ftte_point_escape": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, _dp]),
+    "ftte_set_output_sigma": (C.c_int, [_vp, _dp]),
     "ftte_get_point_rates": (C.c_int, [_vp, _dp]),
     "ftte_point_rates_device": (C.c_int, [_vp, C.POINTER(_vp)]),
     "ftte_set_point_rates": (C.c_int, [_vp, _dp]),

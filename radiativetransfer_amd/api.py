@@ -369,6 +369,22 @@ class StellarTransfer(DiffuseTransfer):
                                               C.byref(highest)))
         return highest.value
 
+    def escape(self, nsrc: int) -> dict:
+        """Escape bookkeeping of the last point_sources call (equiSources.f90:3198-3233, 1342-1348): dict of remaining [nsrc][7],
+        boundary [nsrc][7], dust [nsrc], spectrum [nsrc][300], fraction [nsrc][7]."""
+        out = dict(remaining=np.empty((nsrc, 7)), boundary=np.empty((nsrc, 7)), dust=np.empty(nsrc), spectrum=np.empty((nsrc, 300)),
+                   fraction=np.empty((nsrc, 7)))
+        self._ok(self._lib.ftte_point_escape(self._ctx, nsrc, _dp(out["remaining"]), _dp(out["boundary"]), _dp(out["dust"]),
+                                             _dp(out["spectrum"]), _dp(out["fraction"])))
+        return out
+
+    def set_output_sigma(self, sigma):
+        """outputSigma24, 25, 26, Dust [4][300] for tables handed over with set_rate_tables."""
+        sigma = _f64(sigma)
+        if sigma.shape != (4, 300):
+            raise ValueError("sigma must have shape [4][300]")
+        self._ok(self._lib.ftte_set_output_sigma(self._ctx, _dp(sigma)))
+
     def ray_steps(self) -> int:
         """Cell crossings of the last point_sources call, all rays."""
         return int(self._lib.ftte_point_ray_steps(self._ctx))

@@ -1704,6 +1704,34 @@ int ftte_point_sources(ftte_ctx *c, int nsrc, const int64_t *src_cell, const dou
     return point_trace(c->point, c->stream, c->tree, c->box, nsrc, src_cell, src_ndot, highest_pixel_level, &c->err);
 }
 
+int ftte_point_escape(ftte_ctx *c, int nsrc, double *remaining, double *boundary, double *dust, double *spectrum, double *fraction)
+{
+    if (!c) return FTTE_ERR_ARG;
+    const PointState &P = c->point;
+    if (nsrc < 0 || (size_t)nsrc * kEscapeRec != P.escape_host.size())
+        return fail(c, FTTE_ERR_ARG, "ftte_point_escape: nsrc is not the number of stars of the last ftte_point_sources");
+    for (int s = 0; s < nsrc; ++s) {
+        const double *E = P.escape_host.data() + (size_t)s * kEscapeRec;
+        for (int ir = 0; ir < kOutputRadii; ++ir) {
+            if (remaining) remaining[s * kOutputRadii + ir] = E[ir];
+            if (boundary) boundary[s * kOutputRadii + ir] = E[kOutputRadii + ir];
+            // equiSources.f90:1342-1348
+            if (fraction) fraction[s * kOutputRadii + ir] = E[kOutputRadii + ir] < 1. ? E[ir] / (P.escape_ndot[(size_t)s] - E[kOutputRadii + ir]) : 0.;
+        }
+        if (dust) dust[s] = E[2 * kOutputRadii];
+        if (spectrum) std::memcpy(spectrum + (size_t)s * kOutputEnergies, E + 2 * kOutputRadii + 1, sizeof(double) * kOutputEnergies);
+    }
+    return FTTE_OK;
+}
+
+int ftte_set_output_sigma(ftte_ctx *c, const double *sigma)
+{
+    if (!c) return FTTE_ERR_ARG;
+    if (!sigma) return fail(c, FTTE_ERR_ARG, "ftte_set_output_sigma: bad argument");
+    FTTE_HIP(c, hipSetDevice(c->device));
+    return point_set_output_sigma(c->point, c->stream, sigma, &c->err);
+}
+
 int ftte_get_point_rates(ftte_ctx *c, double *rates)
 {
     int rc = check_ready(c, false);

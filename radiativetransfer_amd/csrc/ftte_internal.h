@@ -155,6 +155,11 @@ constexpr int kTableDepths = 11;                    // ndepth + 1, definitionsMo
 constexpr int kTableSize = 11 * 11 * 11 * 11;       // one rate table
 constexpr int kMaxPixelLevel = 6;                   // localDefinitions, equiSources.f90:9
 constexpr int kPixelCount = 12 * (4096 - 1) / 3;    // pixels of levels 1..6: 12 (4^6 - 1)/3 = 16380
+constexpr int kOutputRadii = 7;                     // nradius, equiSources.f90:9
+constexpr int kOutputEnergies = 300;                // nenergy, definitionsModule.f90:290
+// one star's escape bookkeeping (startNewLongRay, equiSources.f90:3198-3233, 3336-3345): ndotRemaining[7], ndotBoundary[7],
+// ndotDust, ndotSpectrum[300]
+constexpr int kEscapeRec = 2 * kOutputRadii + 1 + kOutputEnergies;
 
 // One frequency bin of stellarBetaTable as the table kernel needs it
 struct FreqBin {
@@ -170,7 +175,7 @@ struct SplitRec {
     double depth[4]; // tau1, tau2, tau3, tauDust accumulated so far
     double ndot;     // photons/s carried by the parent ray
     int32_t pixel;   // parent's NESTED index at its level
-    int32_t pad;
+    int32_t src;     // which star of the batch the ray belongs to (its escape record)
 };
 
 // What the tracer touches per cell crossing is packed so that each kind of datum is one 64-byte line (or less):
@@ -202,6 +207,12 @@ struct TraceRec {
     int32_t *highest_level;
     int32_t *error;
     unsigned long long *steps; // cell crossings, all rays (instrumentation)
+    // escape bookkeeping
+    double *escape;            // [sources of this batch][kEscapeRec], accumulated with atomics
+    const double *sigma_ratio; // [4][300]: outputSigma24/6.30e-18, outputSigma25/1.58e-18, outputSigma26/7.42e-18, outputSigmaDust/5.41e-22,
+                               // or nullptr (no cross-sections known: ndotSpectrum stays zero)
+    double out_radius_kpc[kOutputRadii]; // outputRadius, equiSources.f90:10
+    double kpc;
 };
 
 // ---- ionisation equilibrium (solveRateEquations, equiSources.f90:3459-3677) -------------------------------------------

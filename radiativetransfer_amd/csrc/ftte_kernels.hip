@@ -772,12 +772,13 @@ __global__ void __launch_bounds__(64) point_trace_kernel(const TraceRec T)
     const int L = T.pixel_level;
     const int n = T.n;
     const double fn = (double)(float)n;
-    int pixel, cell;
+    int pixel, cell, src;
     double pt[3], radius, d1, d2, d3, dd, ndot;
     const int level_off = 4 * ((1 << (2 * (L - 1))) - 1); // 12 (4^(L-1) - 1) / 3
 
     if (L == 1) {
         const int s = tid / 12;
+        src = s;
         pixel = tid % 12;
         cell = T.src_node[s];
         pt[0] = pt[1] = pt[2] = 0.5;
@@ -792,13 +793,25 @@ __global__ void __launch_bounds__(64) point_trace_kernel(const TraceRec T)
         // the reference walks the four daughters in order and gives up on the rest once one starts outside the box
         // (strategy = boundary is never reset, equiSources.f90:3336-3345): daughter `which` exists only if it and all
         // its elder sisters start inside
+        src = R.src;
+        bool elder_outside = false;
         for (int sis = 0; sis <= which; ++sis) {
             const double *cd = T.pixdir + 3 * (size_t)(level_off + 4 * R.pixel + sis);
             base[0] = R.pos[0] + R.radius / fn * (cd[0] - pd[0]);
             base[1] = R.pos[1] + R.radius / fn * (cd[1] - pd[1]);
             base[2] = R.pos[2] + R.radius / fn * (cd[2] - pd[2]);
-            if (base[0] < 0. || base[0] > 1. || base[1] < 0. || base[1] > 1. || base[2] < 0. || base[2] > 1.) return;
+            const bool outside = base[0] < 0. || base[0] > 1. || base[1] < 0. || base[1] > 1. || base[2] < 0. || base[2] > 1.;
+            if (outside && sis == which && T.escape) {
+                // a daughter that starts outside the box counts as gone through the boundary, whatever her elder sisters did
+                // (:3336-3343 is evaluated for every daughter)
+                const double tmp = R.radius * T.box / (fn * T.kpc);
+                double *E = T.escape + (size_t)src * kEscapeRec;
+                for (int ir = 0; ir < kOutputRadii; ++ir)
+                    if (T.out_radius_kpc[ir] > tmp) unsafeAtomicAdd(E + kOutputRadii + ir, R.ndot / 4.);
+            }
+            elder_outside = elder_outside || outside;
         }
+        if (elder_outside) return;
         // localizeSplitContinuationCell, :3049-3118
         int ijk[3];
         for (int q = 0; q < 3; ++q) {
@@ -839,6 +852,7 @@ __global__ void __launch_bounds__(64) point_trace_kernel(const TraceRec T)
         Neighbour N;
         N.node = -1; N.a = N.b = 0.0; N.boundary = false;
         int side = 0;
+        const double old_radius = radius;
         if (radius * scale + len < rm || L == kMaxPixelLevel) {
             radius = radius + len / scale;
             const double ex = pt[0] + len * prox, ey = pt[1] + len * proy, ez = pt[2] + len * proz;
@@ -864,6 +878,32 @@ __global__ void __launch_bounds__(64) point_trace_kernel(const TraceRec T)
         double taud = 0.0;
         if (T.dust == 1) taud = path * hi * (double)5.4116737e-22f * M[4] / (double)0.2f;
         else if (T.dust == 2) taud = path * (double)0.76f * M[3] / (double)1.6726231e-24f * (double)5.4116737e-22f * M[4] / (double)0.2f;
+        if (T.escape) { // :3198-3233: what is left of the ray where it crosses the output radii, what leaves through the box faces
+            double *E = T.escape + (size_t)src * kEscapeRec;
+            const double tmp1 = old_radius * T.box / fn, tmp2 = radius * T.box / fn;
+            for (int ir = 0; ir < kOutputRadii; ++ir) {
+                const double tmp = T.out_radius_kpc[ir] * T.kpc;
+                if (tmp >= tmp1 && tmp <= tmp2) {
+                    const double ratio = (tmp - tmp1) / (tmp2 - tmp1);
+                    unsafeAtomicAdd(E + ir, ndot * exp(-(ratio * (tau1 + taud) + d1 + dd)));
+                    if (ir == kOutputRadii - 1) {
+                        const double o1 = ratio * tau1 + d1, o2 = ratio * tau2 + d2, o3 = ratio * tau3 + d3, od = ratio * taud + dd;
+                        unsafeAtomicAdd(E + 2 * kOutputRadii, ndot * exp(-od));
+                        if (T.sigma_ratio)
+                            for (int ie = 0; ie < kOutputEnergies; ++ie) {
+                                const double e1 = T.sigma_ratio[ie] * o1, e2 = T.sigma_ratio[2 * kOutputEnergies + ie] * o2,
+                                             e3 = T.sigma_ratio[kOutputEnergies + ie] * o3, e4 = T.sigma_ratio[3 * kOutputEnergies + ie] * od;
+                                unsafeAtomicAdd(E + 2 * kOutputRadii + 1 + ie, ndot * exp(-(e1 + e2 + e3 + e4)));
+                            }
+                    }
+                }
+            }
+            if (stop) { // drawSegment ended on a box face (the depth test below is not a boundary in this sense)
+                const double tmp = radius * T.box / (fn * T.kpc);
+                for (int ir = 0; ir < kOutputRadii; ++ir)
+                    if (T.out_radius_kpc[ir] > tmp) unsafeAtomicAdd(E + kOutputRadii + ir, ndot);
+            }
+        }
         if (fmin(fmin(d1 + tau1, d2 + tau2), fmin(d3 + tau3, dd + taud)) > 100.) { stop = true; split = false; }
         // a species without opacity in this cell takes nothing from the ray: R(d) - R(d) = 0 (and the reference adds that 0)
         double a, b, ea, eb;
@@ -920,7 +960,7 @@ __global__ void __launch_bounds__(64) point_trace_kernel(const TraceRec T)
     R.depth[0] = d1; R.depth[1] = d2; R.depth[2] = d3; R.depth[3] = dd;
     R.ndot = ndot;
     R.pixel = pixel;
-    R.pad = 0;
+    R.src = src;
     T.out[slot] = R;
 }
 

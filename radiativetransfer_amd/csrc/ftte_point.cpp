@@ -77,6 +77,8 @@ void PointState::release()
     drop_grid();
     drop(tables); drop(logtab); drop(bins); drop(pixdir);
     drop(queue[0]); drop(queue[1]); drop(counters); drop(src_node); drop(src_ndot); drop(sample_in); drop(sample_out);
+    drop(escape); drop(sigma_ratio);
+    escape_capacity = 0; sigma_ready = false;
     tables_ready = false;
     queue_capacity = src_capacity = sample_capacity = 0;
 }
@@ -294,6 +296,23 @@ int point_stellar_beta_table(PointState &P, hipStream_t stream, const double *a_
     if (total_integral) *total_integral = total;
 
     int rc;
+    {   // the output energies and the cross-sections on them, stellarBetaTable.f90:119-152 (nenergy = 300 between lowerEnergy
+        // and upperEnergy, definitionsModule.f90:290-292)
+        double sigma[4 * kOutputEnergies];
+        const double lower = kHydrogen, upper = W(10.) * kHydrogen; // lowerEnergy, upperEnergy
+        for (int ie = 1; ie <= kOutputEnergies; ++ie) {
+            // float(ienergy-1)/float(nenergy-1) is a single-precision quotient, :122
+            const double freq = lower * std::exp((double)((float)(ie - 1) / (float)(kOutputEnergies - 1)) * (std::log(upper) - std::log(lower)));
+            const double lambda = c_light() / (freq * ev_to_hz()) * W(1.e8);
+            sigma[3 * kOutputEnergies + ie - 1] = dust_cross_section(lambda / W(1.e4), a_smc) * W(1.e-22);
+            sigma[0 * kOutputEnergies + ie - 1] = freq > kHydrogen ? hydrogenic(W(6.3e-18), kHydrogen, freq) : freq == kHydrogen ? W(6.3e-18) : 0.0;
+            sigma[1 * kOutputEnergies + ie - 1] = freq > kHeII ? hydrogenic(W(1.58e-18), kHeII, freq) : 0.0;
+            sigma[2 * kOutputEnergies + ie - 1] = freq > kHeI ? W(7.42e-18) * (W(1.66) * std::pow(freq / kHeI, (double)(-2.05f)) -
+                                                                               W(0.66) * std::pow(freq / kHeI, (double)(-3.05f)))
+                                                              : 0.0;
+        }
+        if ((rc = point_set_output_sigma(P, stream, sigma, err))) return rc;
+    }
     if ((rc = ensure(P.tables, (size_t)6 * kTableSize, err))) return rc;
     if ((rc = ensure(P.logtab, (size_t)6 * kTableSize, err))) return rc;
     if ((rc = ensure(P.bins, (size_t)kFrequencies, err))) return rc;
@@ -304,8 +323,24 @@ int point_stellar_beta_table(PointState &P, hipStream_t stream, const double *a_
     return 0;
 }
 
+int point_set_output_sigma(PointState &P, hipStream_t stream, const double *sigma, std::string *err)
+{
+    // the tracer multiplies the threshold depths by sigma(E) / sigma(threshold), :3216-3219
+    double ratio[4 * kOutputEnergies];
+    const double thr[4] = {W(6.30e-18), W(1.58e-18), W(7.42e-18), W(5.4116737e-22)};
+    for (int q = 0; q < 4; ++q)
+        for (int ie = 0; ie < kOutputEnergies; ++ie) ratio[q * kOutputEnergies + ie] = sigma[q * kOutputEnergies + ie] / thr[q];
+    int rc;
+    if ((rc = ensure(P.sigma_ratio, (size_t)4 * kOutputEnergies, err))) return rc;
+    POINT_HIP(hipMemcpyAsync(P.sigma_ratio, ratio, sizeof ratio, hipMemcpyHostToDevice, stream));
+    POINT_HIP(hipStreamSynchronize(stream));
+    P.sigma_ready = true;
+    return 0;
+}
+
 int point_set_tables(PointState &P, hipStream_t stream, const double *tables, std::string *err)
 {
+    P.sigma_ready = false; // the cross-sections belong to the population whose tables these replace: ftte_set_output_sigma
     int rc;
     if ((rc = ensure(P.tables, (size_t)6 * kTableSize, err))) return rc;
     if ((rc = ensure(P.logtab, (size_t)6 * kTableSize, err))) return rc;
@@ -476,8 +511,22 @@ int point_trace(PointState &P, hipStream_t stream, const AmrTree &tree, double b
         node_of[s] = tree.refined() ? P.node_of_leaf[(size_t)src_cell[s]] : (int32_t)src_cell[s];
     }
 
+    if ((size_t)nsrc * kEscapeRec > P.escape_capacity) {
+        drop(P.escape);
+        P.escape_capacity = 0;
+        POINT_HIP(hipMalloc((void **)&P.escape, sizeof(double) * (size_t)nsrc * kEscapeRec));
+        P.escape_capacity = (size_t)nsrc * kEscapeRec;
+    }
+    POINT_HIP(hipMemsetAsync(P.escape, 0, sizeof(double) * (size_t)nsrc * kEscapeRec, stream)); // :1267-1270
+
     TraceRec T;
     std::memset(&T, 0, sizeof(T));
+    T.sigma_ratio = P.sigma_ready ? P.sigma_ratio : nullptr;
+    {
+        static const float radii[kOutputRadii] = {0.1f, 0.3f, 1.f, 3.f, 10.f, 30.f, 100.f}; // outputRadius [kpc], equiSources.f90:10
+        for (int ir = 0; ir < kOutputRadii; ++ir) T.out_radius_kpc[ir] = (double)radii[ir];
+        T.kpc = W(1.e3) * W(3.08568025e18); // definitionsModule.f90:21-22
+    }
     T.node = tree.refined() ? P.node : nullptr;
     T.n = tree.n; T.dust = P.dust; T.ncell = tree.ncell; T.box = box;
     T.medium = P.packed;
@@ -497,6 +546,7 @@ int point_trace(PointState &P, hipStream_t stream, const AmrTree &tree, double b
         POINT_HIP(hipMemcpyAsync(P.src_node, node_of.data() + s0, sizeof(int32_t) * ns, hipMemcpyHostToDevice, stream));
         POINT_HIP(hipMemcpyAsync(P.src_ndot, src_ndot + s0, sizeof(double) * ns, hipMemcpyHostToDevice, stream));
         int32_t nrec = 0;
+        T.escape = P.escape + (size_t)s0 * kEscapeRec;
         for (int L = 1; L <= kMaxPixelLevel; ++L) {
             T.pixel_level = L;
             T.nrays = L == 1 ? 12 * ns : 4 * nrec;
@@ -524,6 +574,9 @@ int point_trace(PointState &P, hipStream_t stream, const AmrTree &tree, double b
     }
     unsigned long long steps = 0;
     POINT_HIP(hipMemcpyAsync(&steps, P.counters + 4, sizeof steps, hipMemcpyDeviceToHost, stream));
+    P.escape_host.resize((size_t)nsrc * kEscapeRec);
+    P.escape_ndot.assign(src_ndot, src_ndot + nsrc);
+    POINT_HIP(hipMemcpyAsync(P.escape_host.data(), P.escape, sizeof(double) * (size_t)nsrc * kEscapeRec, hipMemcpyDeviceToHost, stream));
     POINT_HIP(hipStreamSynchronize(stream));
     P.ray_steps = (long long)steps;
     if (highest_pixel_level) *highest_pixel_level = highest;

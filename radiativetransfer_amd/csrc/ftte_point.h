@@ -50,6 +50,13 @@ struct PointState {
     int32_t src_capacity = 0;
     double *sample_in = nullptr, *sample_out = nullptr;
     int32_t sample_capacity = 0;
+    // escape bookkeeping of the last trace (startNewLongRay, equiSources.f90:3198-3233, 3336-3345): per star ndotRemaining[7],
+    // ndotBoundary[7], ndotDust, ndotSpectrum[300]
+    double *escape = nullptr;            // device, [stars of the call][kEscapeRec]
+    size_t escape_capacity = 0;
+    std::vector<double> escape_host, escape_ndot; // the same on the host after the trace; the stars' photon rates
+    double *sigma_ratio = nullptr;       // device [4][300]: outputSigma* / threshold cross-section (stellarBetaTable.f90:119-152)
+    bool sigma_ready = false;
 
     void release();
     void drop_grid(); // after ftte_set_grid: tree, medium and rates belong to the old grid
@@ -89,5 +96,7 @@ int point_rate_planes(PointState &P, hipStream_t stream, double **planes, std::s
 int point_set_rates(PointState &P, hipStream_t stream, int64_t ncell, const double *planes_host, std::string *err);
 int point_trace(PointState &P, hipStream_t stream, const AmrTree &tree, double box, int nsrc, const int64_t *src_cell,
                 const double *src_ndot, int *highest_pixel_level, std::string *err);
+// outputSigma24, 25, 26, Dust [4][300] (absolute cross-sections, as the reference's module arrays hold them)
+int point_set_output_sigma(PointState &P, hipStream_t stream, const double *sigma, std::string *err);
 
 } // namespace ftte

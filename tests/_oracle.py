@@ -226,6 +226,35 @@ def rmax_table():
     return out
 
 
+def point_sources_escape(n, level, HI, HeI, HeII, rho, abun2, box, dust, src_leaf, src_ndot, tables, out_sigma=None, pix=None):
+    """point_sources plus the per-star escape bookkeeping: returns rates, highestPixelLevel, dict(remaining [nsrc][7], boundary
+    [nsrc][7], dust [nsrc], spectrum [nsrc][300], fraction [nsrc][7])."""
+    level = np.ascontiguousarray(level, dtype=np.int32)
+    HI, HeI, HeII, rho, abun2, tables, src_ndot = map(_f64, (HI, HeI, HeII, rho, abun2, tables, src_ndot))
+    src_leaf = np.ascontiguousarray(src_leaf, dtype=np.int64)
+    nsrc = len(src_leaf)
+    rates = np.empty((6, len(level)))
+    esc, frac = np.zeros((nsrc, 315)), np.zeros((nsrc, 7))
+    hp = C.c_int()
+    L = lib()
+    dp = C.POINTER(C.c_double)
+    L.fo_point_sources_escape.argtypes = [C.c_int, C.c_int64, C.POINTER(C.c_int32), dp, dp, dp, dp, dp, C.c_double, C.c_int, C.c_int,
+                                          C.POINTER(C.c_int64), dp, dp, dp, C.POINTER(C.c_int), dp, C.c_int, dp, dp, dp]
+    pix_levels = 0
+    if pix is not None:
+        pix_levels = len(pix)
+        pix = _f64(np.concatenate([np.asarray(p).reshape(-1, 2) for p in pix]))
+    sig = _f64(out_sigma) if out_sigma is not None else None
+    rc = L.fo_point_sources_escape(n, len(level), level.ctypes.data_as(C.POINTER(C.c_int32)), _dp(HI), _dp(HeI), _dp(HeII), _dp(rho),
+                                   _dp(abun2), box, dust, nsrc, src_leaf.ctypes.data_as(C.POINTER(C.c_int64)), _dp(src_ndot),
+                                   _dp(tables), _dp(rates), C.byref(hp), _dp(pix) if pix is not None else None, pix_levels,
+                                   _dp(sig) if sig is not None else None, _dp(esc), _dp(frac))
+    if rc:
+        raise ValueError(f"fo_point_sources_escape -> {rc}")
+    return rates, hp.value, dict(remaining=esc[:, :7].copy(), boundary=esc[:, 7:14].copy(), dust=esc[:, 14].copy(),
+                                 spectrum=esc[:, 15:].copy(), fraction=frac)
+
+
 def point_sources(n, level, HI, HeI, HeII, rho, abun2, box, dust, src_leaf, src_ndot, tables, pix=None):
     level = np.ascontiguousarray(level, dtype=np.int32)
     HI, HeI, HeII, rho, abun2, tables, src_ndot = map(_f64, (HI, HeI, HeII, rho, abun2, tables, src_ndot))

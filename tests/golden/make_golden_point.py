@@ -89,6 +89,12 @@ def run_reference(n, level, HI, HeI, HeII, rho, abun2, box, dust, src_leaf, src_
     o["rmax"] = take(30)
     o["krate"] = take(6 * ncell).reshape(6, ncell)          # Fortran kout(ncell,6)
     o["highestPixelLevel"] = take(1, "<i4")[0]
+    # per star: the tracer's escape bookkeeping (equiSources.f90:3198-3233, 3336-3345) and the src: line's fraction (:1342-1348)
+    o["ndotRemaining"] = take(7 * nsrc).reshape(nsrc, 7)
+    o["ndotBoundary"] = take(7 * nsrc).reshape(nsrc, 7)
+    o["ndotDust"] = take(nsrc)
+    o["ndotSpectrum"] = take(300 * nsrc).reshape(nsrc, 300)
+    o["fraction"] = take(7 * nsrc).reshape(nsrc, 7)
     assert off == len(raw), (off, len(raw))
     return o
 
@@ -123,7 +129,8 @@ def main():
          src_leaf=np.array(src), src_weight=np.array([1]), a_smc=pop[0], wavelength=pop[1],
          iSpectrum=3, iMetal=2, coefSpectrum=0.4, coefMetal=0.7, samples=samples, totalIntegral=o["totalIntegral"],
          tables=o["tables"], outputSigma=o["outputSigma"], rates=o["rates"], pix1=o["pix"][0], pix2=o["pix"][1],
-         pix3=o["pix"][2], pix4=o["pix"][3], pix5=o["pix"][4], pix6=o["pix"][5], rmax=o["rmax"], krate=o["krate"], highestPixelLevel=o["highestPixelLevel"])
+         pix3=o["pix"][2], pix4=o["pix"][3], pix5=o["pix"][4], pix6=o["pix"][5], rmax=o["rmax"], krate=o["krate"], highestPixelLevel=o["highestPixelLevel"],
+         **escape(o))
     print("  highest pixel level", o["highestPixelLevel"], " sum krate24", o["krate"][0].sum(), " totalIntegral", o["totalIntegral"])
 
     # (2) refined: 10^3 base, a 2x2x2 block refined once, log-normal densities, dust ~ HI, two sources (one in a fine leaf)
@@ -144,8 +151,38 @@ def main():
     save("point10_refined_dust", n=n, level=level, HI=HI, HeI=HeI, HeII=HeII, rho=rho, abun2=abun2, box=float(n), dust=1,
          src_leaf=np.array([fine, coarse]), src_weight=np.array([2, 1]), a_smc=pop[0], wavelength=pop[1],
          iSpectrum=10, iMetal=1, coefSpectrum=0.25, coefMetal=0.1, tables=o["tables"], krate=o["krate"],
-         highestPixelLevel=o["highestPixelLevel"])
+         highestPixelLevel=o["highestPixelLevel"], **escape(o))
     print("  highest pixel level", o["highestPixelLevel"], " sum krate24", o["krate"][0].sum())
+
+    # (3) escape fractions: a box of physical size (80 kpc: the output radii 0.1 ... 30 kpc lie inside it, 100 kpc outside),
+    #     12^3 base with a refined 2x2x2 block around the first star, total optical depth of a few across the box, dust ~ total
+    #     hydrogen, three stars (one in a fine leaf, one near a face so that part of its light leaves early, one with weight 3)
+    n = 12
+    kpc = 1.0e3 * 3.08568025e18
+    box = 80.0 * kpc
+    blocks = [(5 + a, 5 + b, 6 + c) for a in range(2) for b in range(2) for c in range(2)]
+    level = synthetic.refine_levels(n, blocks, depth=1)
+    ncell = len(level)
+    dens = synthetic.lognormal_density(ncell, seed=31, sigma_ln=0.5)
+    HI = 2.5 / (sigma * box) * dens
+    HeI = 0.3 / (7.42e-18 * box) * dens
+    HeII = 0.05 / (1.58e-18 * box) * dens
+    rho = HI * 1.6726231e-24 / 0.76 * 50.0
+    abun2 = 0.05 * np.ones(ncell)
+    fine = int(np.nonzero(level == 1)[0][11])
+    near_face = int(np.nonzero(level == 0)[0][7])
+    inner = int(np.nonzero(level == 0)[0][900])
+    o = run_reference(n, level, HI, HeI, HeII, rho, abun2, box, 2, [fine, near_face, inner], [1, 2, 3], pop, 7, 2, 0.6, 0.35,
+                      samples[:4], npixlevel=6)
+    save("point12_escape", n=n, level=level, HI=HI, HeI=HeI, HeII=HeII, rho=rho, abun2=abun2, box=box, dust=2,
+         src_leaf=np.array([fine, near_face, inner]), src_weight=np.array([1, 2, 3]), a_smc=pop[0], wavelength=pop[1],
+         iSpectrum=7, iMetal=2, coefSpectrum=0.6, coefMetal=0.35, tables=o["tables"], outputSigma=o["outputSigma"], krate=o["krate"],
+         highestPixelLevel=o["highestPixelLevel"], **escape(o))
+    print("  highest pixel level", o["highestPixelLevel"], " fraction", np.round(o["fraction"], 4).tolist())
+
+
+def escape(o):
+    return {k: o[k] for k in ("ndotRemaining", "ndotBoundary", "ndotDust", "ndotSpectrum", "fraction")}
 
 
 if __name__ == "__main__":

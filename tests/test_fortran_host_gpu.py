@@ -100,18 +100,21 @@ def test_dropin_rate_equations_on_the_reference_tree(golden, tmp_path):
     assert np.array_equal(got[0], g["HI_out"]) and np.array_equal(got[1], g["HeI_out"]) and np.array_equal(got[2], g["HeII_out"])
 
 
-def test_dropin_stellar_transfer_on_the_reference_tree(golden, tmp_path):
+@pytest.mark.parametrize("name,metal_offset", [("point10_refined_dust", 0.1), ("point12_escape", 1.35)])
+def test_dropin_stellar_transfer_on_the_reference_tree(golden, tmp_path, name, metal_offset):
     """fortran/ftte_stellar_transfer.f90 in place of the star loop equiSources.f90:1260-1362: stars given as the reference
     holds them (level + call sequence), population picked from the host cell's metallicity as :1281-1291 does, module
     arrays a_smc / wavelength / specificLuminosity / metallicity; krate24..26, crate24..26 in the tree against the
-    reference's own tracer (tests/golden/point10_refined_dust.npz)."""
+    reference's own tracer, and the `src:` line the reference prints per star (:1353-1357: escape fractions at the seven
+    output radii) against the fractions its tracer's bookkeeping gives (tests/golden/point10_refined_dust.npz: a box so
+    small that all light counts as gone; point12_escape.npz: an 80 kpc box)."""
     import sys
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import make_golden_point as M
     if not os.path.exists(DROPIN):
         pytest.skip("tests/fortran/dropin_check not built (needs oracle/_ref and a Fortran compiler at build time)")
-    g = golden("point10_refined_dust")
+    g = golden(name)
     n, level = int(g["n"]), g["level"]
     a_smc, wavelength, spec = M.synthetic_population()
     # call sequences of the leaves, as readCellArray.f90:154-187 numbers them
@@ -131,9 +134,11 @@ def test_dropin_stellar_transfer_on_the_reference_tree(golden, tmp_path):
         for j in range(1, n + 1):
             for k in range(1, n + 1):
                 grow(0, [i, j, k])
-    # a metallicity grid that makes the drop-in pick the golden's (iMetal, coefMetal) = (1, 0.1) for abun2 = 0.2
-    tmp = np.log10(0.2)
-    metallicity = np.array([tmp - 0.1, tmp + 0.9, tmp + 1.9, tmp + 2.9, tmp + 3.9])
+    # a metallicity grid that makes the drop-in pick the golden's (iMetal, coefMetal) -- (1, 0.1) for abun2 = 0.2, (2, 0.35) for
+    # abun2 = 0.05 -- from the host cell's abundance
+    tmp = np.log10(float(g["abun2"][0]))
+    assert (int(g["iMetal"]) - 1) + float(g["coefMetal"]) == pytest.approx(metal_offset)
+    metallicity = tmp - metal_offset + np.arange(5.0)
     case, out = tmp_path / "case.bin", tmp_path / "rates.bin"
     with open(case, "wb") as f:
         f.write(np.array([n, level.size, g["src_leaf"].size, int(g["dust"])], "<i4").tobytes())
@@ -157,6 +162,13 @@ def test_dropin_stellar_transfer_on_the_reference_tree(golden, tmp_path):
     scale = np.abs(ref).max(axis=1, keepdims=True)
     assert np.all(np.abs(rates - ref) <= 1e-9 * np.abs(ref) + 1e-13 * scale)
     assert np.array_equal(rates == 0, ref == 0)
+    # src: iStar level neutralFraction highestPixelLevel fraction(1:7) weight   (format 1015, equiSources.f90:1357)
+    lines = [ln.split() for ln in res.stdout.splitlines() if ln.startswith("src:")]
+    assert len(lines) == g["src_leaf"].size
+    for s, ln in enumerate(lines):
+        assert int(ln[1]) == s + 1 and int(ln[-1]) == int(g["src_weight"][s])
+        assert np.allclose([float(x) for x in ln[5:12]], g["fraction"][s], rtol=0, atol=6e-6)  # five decimals printed
+    assert max(int(ln[4]) for ln in lines) == int(g["highestPixelLevel"])
 
 
 def test_fortran_host_runs_the_whole_iteration(golden, tmp_path):

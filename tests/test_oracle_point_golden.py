@@ -89,3 +89,32 @@ def test_photon_conservation(golden):
     r2, _ = O.point_sources(int(g["n"]), g["level"], dense["HI"], g["HeI"], g["HeII"], g["rho"], g["abun2"], float(g["box"]), 0,
                             g["src_leaf"], g["src_weight"].astype(float), tables)
     assert abs(r2[0].sum() / emitted - 1) < 1e-3
+
+
+ESCAPE_KEYS = (("remaining", "ndotRemaining"), ("boundary", "ndotBoundary"), ("dust", "ndotDust"), ("spectrum", "ndotSpectrum"),
+               ("fraction", "fraction"))
+
+
+def test_escape_bookkeeping_against_reference(golden):
+    """ndotRemaining / ndotBoundary / ndotDust / ndotSpectrum of startNewLongRay (equiSources.f90:3198-3233, :3336-3345) and the
+    `src:` line's fraction (:1342-1348), per star, as the reference's own tracer accumulated them: a box of physical size with
+    three stars (point12_escape: the 0.1 ... 30 kpc radii inside it; a star near a face; a star in a fine leaf; dust), and the
+    two older cases, whose boxes are so small that every ray counts as gone through the boundary at every radius."""
+    ghom = golden("point16_homogeneous")
+    pix = [ghom[f"pix{L}"] for L in range(1, 7)]
+    for name in ("point12_escape", "point10_refined_dust", "point16_homogeneous"):
+        g = golden(name)
+        sigma = g["outputSigma"] if "outputSigma" in g.files else None
+        rates, hp, esc = O.point_sources_escape(int(g["n"]), g["level"], g["HI"], g["HeI"], g["HeII"], g["rho"], g["abun2"], float(g["box"]),
+                                                int(g["dust"]), g["src_leaf"], g["src_weight"].astype(float), g["tables"].reshape(6, -1),
+                                                out_sigma=sigma, pix=pix)
+        assert hp == int(g["highestPixelLevel"])
+        for mine, ref in ESCAPE_KEYS:
+            if mine == "spectrum" and sigma is None:
+                continue
+            assert np.array_equal(esc[mine], g[ref]), (name, mine)
+    g = golden("point12_escape")
+    f = g["fraction"]
+    assert np.all(np.diff(f, axis=1) <= 0) and np.all((f >= 0) & (f <= 1))  # less and less is left further out
+    assert f[0, 0] > 0.99 and f[0, 6] == 0.0                                # the 100 kpc sphere lies outside the 80 kpc box
+    assert np.all(f[1, 4:] == 0.0) and np.all(g["ndotBoundary"][1, 4:] >= 1.0)  # star 2: a whole photon unit left through the face

@@ -332,3 +332,40 @@ def test_limiting_media(stellar, golden):
     ref, _ = O.point_sources(n, np.zeros(nc, np.int32), HI, zeros, zeros, zeros, zeros, box, 0, [0], [1.0], tables)
     _close(k, ref)
     assert k[0, 0] > 0 and np.all(k[0] >= 0)
+
+
+def test_escape_fractions_against_reference(stellar, golden, pop):
+    """SURVEY.md 8(a) P1's scalar outputs: what is left of each star's light at the seven output radii, what left through the box,
+    the spectrum at the last radius, and the `src:` line's fraction (equiSources.f90:3198-3233, :1342-1348) -- against what the
+    reference's own tracer accumulated.  Sums of many rays in atomic order, each an exp of the ROCm library: 1e-9 relative."""
+    for name in ("point12_escape", "point10_refined_dust", "point16_homogeneous"):
+        g = golden(name)
+        nsrc = len(g["src_leaf"])
+        stellar.set_grid(int(g["n"]), g["level"], float(g["box"]))
+        stellar.set_medium(g["HI"], g["HeI"], g["HeII"], g["rho"], g["abun2"], int(g["dust"]))
+        stellar.set_rate_tables(g["tables"])
+        if "outputSigma" in g.files:
+            stellar.set_output_sigma(g["outputSigma"])
+        stellar.set_zero_rates()
+        hp = stellar.point_sources(g["src_leaf"], g["src_weight"].astype(float))
+        assert hp == int(g["highestPixelLevel"])
+        esc = stellar.escape(nsrc)
+        for mine, ref in (("remaining", "ndotRemaining"), ("boundary", "ndotBoundary"), ("dust", "ndotDust"), ("fraction", "fraction")):
+            want = g[ref]
+            assert np.all(np.abs(esc[mine] - want) <= 1e-9 * np.abs(want) + 1e-300), (name, mine)
+        if "outputSigma" in g.files:
+            assert np.all(np.abs(esc["spectrum"] - g["ndotSpectrum"]) <= 1e-9 * np.abs(g["ndotSpectrum"]) + 1e-300), name
+        else:  # tables set by hand and no cross-sections given: the spectrum is left at zero
+            assert not esc["spectrum"].any()
+    # the cross-sections the library computes itself with the tables (stellarBetaTable.f90:119-152) give the same spectrum
+    g = golden("point12_escape")
+    stellar.set_grid(int(g["n"]), g["level"], float(g["box"]))
+    stellar.set_medium(g["HI"], g["HeI"], g["HeII"], g["rho"], g["abun2"], int(g["dust"]))
+    stellar.stellar_beta_table(pop[0], pop[1], pop[2], int(g["iSpectrum"]), float(g["coefSpectrum"]), int(g["iMetal"]), float(g["coefMetal"]))
+    stellar.set_zero_rates()
+    stellar.point_sources(g["src_leaf"], g["src_weight"].astype(float))
+    esc = stellar.escape(3)
+    assert np.all(np.abs(esc["spectrum"] - g["ndotSpectrum"]) <= 1e-9 * np.abs(g["ndotSpectrum"]) + 1e-300)
+    assert np.all(np.abs(esc["fraction"] - g["fraction"]) <= 1e-9 * np.abs(g["fraction"]))
+    with pytest.raises(Exception):
+        stellar.escape(2)  # not the number of stars of the last call
