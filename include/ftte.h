@@ -254,6 +254,31 @@ int ftte_assign_uvb_radiation_device(ftte_ctx *ctx, int nnu, const double *uvb, 
 /* bisection steps of the last ftte_solve_rate_equations*, summed over the cells */
 long long ftte_rate_equation_steps(const ftte_ctx *ctx);
 
+/* ---- grid ingest (no device needed) -----------------------------------------------------------------
+ * What the reference does between reading its grid file and the first transfer (equiSources.f90:427-618,
+ * placeCellProjectWithVelocity :1870-1974): per refinement level a list of SPH-projected cells -- position [kpc], log10 of
+ * temperature, hydrogen density and neutral fraction, optionally velocities and four abundances -- becomes the octree, and the
+ * octree the cell array in writeCell's order (:4044-4079), the order ftte_set_grid, ftte_set_medium and the .dat file take.
+ * Level 1 must fill an n^3 base grid (FTTE_ERR_NOT_CUBIC otherwise, :436-439); a cell of level L lies L-1 refinements deep;
+ * cells of a refined cell that no list covers keep their parent's state, as in the reference.  The HDF4 container the
+ * reference reads the lists from (:316-423) is not read here: the lists are handed over as arrays. */
+typedef struct {
+    int64_t ncell;
+    const float *pos;            /* (ncell,3) as the Fortran array lies: all x, then all y, then all z [kpc] */
+    const float *lT, *lnH, *lx;  /* log10 T [K], log10 n_H [cm^-3], log10 neutral fraction */
+    const float *vel;            /* (ncell,3) or NULL (the reference's readKinematics) */
+    const float *abun;           /* (ncell,4) or NULL (readMetals); column 2 becomes abun2, smoothed on level 1 (:526-578) */
+} ftte_level_list;
+typedef struct ftte_cellarray ftte_cellarray;
+int ftte_ingest_levels(int nlevels, const ftte_level_list *lists, ftte_cellarray **out);
+/* base grid size, number of leaves, physicalBoxSize [cm] (:481) */
+int ftte_cellarray_info(const ftte_cellarray *a, int *nx, int64_t *ncell, double *box_cm, int *has_velocity, int *has_metals);
+/* the leaf arrays, cell-array order, as the tree holds them (binary64); any pointer may be NULL.  tgas and rho are zoneType's
+ * fields; abun2 is 0.02 everywhere without metals (:1958). */
+int ftte_cellarray_fields(const ftte_cellarray *a, int32_t *level, double *HI, double *HeI, double *HeII, double *tgas, double *rho,
+                          double *velx, double *vely, double *velz, double *abun2);
+void ftte_cellarray_free(ftte_cellarray *a);
+
 /* ---- host arrays ------------------------------------------------------------------------------
  * The reference keeps its fields in host memory (the zoneType tree, definitionsModule.f90:163-180); the drop-ins
  * flatten them into cell-array order and hand them over.  Pageable arrays cross PCIe through pinned staging blocks

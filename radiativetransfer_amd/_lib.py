@@ -78,6 +78,10 @@ SIGNATURES = {
     "ftte_rate_coefficient_tables": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_int, _dp, _dp, _dp, _dp]),
     "ftte_uniform_table": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_double, _dp, _dp]),
     "ftte_dust_cross_section": (C.c_double, [C.c_double, _dp]),
+    "ftte_ingest_levels": (C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),
+    "ftte_cellarray_info": (C.c_int, [_vp, _ip, C.POINTER(C.c_int64), _dp, _ip, _ip]),
+    "ftte_cellarray_fields": (C.c_int, [_vp, C.POINTER(C.c_int32), _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "ftte_cellarray_free": (None, [_vp]),
     "ftte_host_register": (C.c_int, [_vp, _vp, C.c_size_t]),
     "ftte_host_unregister": (C.c_int, [_vp, _vp]),
     "ftte_counter": (C.c_longlong, [_vp, C.c_char_p]),
