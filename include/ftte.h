@@ -49,7 +49,8 @@ typedef enum {
     FTTE_ERR_PATTERN = -10,       /* transportRoutinesModule.f90:33-36,60-63; equiSources.f90:1523 */
     FTTE_ERR_IZONE = -11,         /* rotateIndices called with izone outside 1..24                 */
     FTTE_ERR_PIXEL = -12,         /* equiSources.f90:2152-2160 'nside/ipix out of range'           */
-    FTTE_ERR_RATES = -13          /* equiSources.f90:3637-3654: a species fraction left [0, 1]     */
+    FTTE_ERR_RATES = -13,         /* equiSources.f90:3637-3654: a species fraction left [0, 1]     */
+    FTTE_ERR_MEMORY = -14         /* not enough device memory for the request (see message)         */
 } ftte_status;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */

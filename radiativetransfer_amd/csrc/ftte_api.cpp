@@ -573,7 +573,11 @@ int build_brick_plan(ftte_ctx *c, int ndir, const double *phi, const double *the
         }
         P.tasks.resize(run);
         std::vector<size_t> fill(P.stage_off);
-        for (size_t g = 0; g < P.groups.size(); ++g) {
+        // within a stage the groups with the most directions first: their bricks take longest, the short ones fill the tail
+        std::vector<size_t> by_size(P.groups.size());
+        for (size_t g = 0; g < by_size.size(); ++g) by_size[g] = g;
+        std::stable_sort(by_size.begin(), by_size.end(), [&](size_t x, size_t y) { return P.groups[x].dirs.size() > P.groups[y].dirs.size(); });
+        for (size_t g : by_size) {
             const BrickPlan::Group &G = P.groups[g];
             const std::vector<int> &F = first[(size_t)G.layout * kMaxAcc + G.acc];
             for (int ti = 0; ti < P.nti; ++ti)
@@ -727,15 +731,33 @@ int forest_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
         c->forest_key = key;
     }
 
+    // Scratch: outgoing intensity and mean of every segment of every direction of a batch.  The batch is as large as the
+    // direction list, kAmrBatch and the free memory allow (two arrays of 3 ncell nnu doubles per direction: 38 GB for 48
+    // directions of a 128^3 x 8 tree), and shrinks once more if the allocation still fails.
     const size_t per_dir = (size_t)nseg * nnu;
-    if (c->amr_scratch_cap < per_dir * kAmrBatch) {
+    int batch = std::max(1, std::min(ndir, kAmrBatch));
+    if (c->amr_scratch_cap < per_dir * (size_t)batch) {
         FTTE_HIP(c, hipStreamSynchronize(stream));
         if (c->amr_Iout) { FTTE_HIP(c, hipFree(c->amr_Iout)); c->amr_Iout = nullptr; }
         if (c->amr_mean) { FTTE_HIP(c, hipFree(c->amr_mean)); c->amr_mean = nullptr; }
-        FTTE_HIP(c, hipMalloc((void **)&c->amr_Iout, sizeof(double) * per_dir * kAmrBatch));
-        FTTE_HIP(c, hipMalloc((void **)&c->amr_mean, sizeof(double) * per_dir * kAmrBatch));
-        c->amr_scratch_cap = per_dir * kAmrBatch;
-    }
+        c->amr_scratch_cap = 0;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t fits = (size_t)(0.9 * (double)free_b) / (2 * sizeof(double) * per_dir);
+            batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)batch, fits));
+        }
+        for (;;) {
+            hipError_t e1 = hipMalloc((void **)&c->amr_Iout, sizeof(double) * per_dir * (size_t)batch);
+            hipError_t e2 = e1 == hipSuccess ? hipMalloc((void **)&c->amr_mean, sizeof(double) * per_dir * (size_t)batch) : e1;
+            if (e1 == hipSuccess && e2 == hipSuccess) break;
+            if (c->amr_Iout) { (void)hipFree(c->amr_Iout); c->amr_Iout = nullptr; }
+            c->amr_mean = nullptr;
+            (void)hipGetLastError();
+            if (batch == 1) return fail(c, FTTE_ERR_MEMORY, "refined-grid sweep: not enough device memory for the segment scratch of one direction");
+            batch = (batch + 1) / 2;
+        }
+        c->amr_scratch_cap = per_dir * (size_t)batch;
+    } else batch = (int)std::min<size_t>((size_t)kAmrBatch, c->amr_scratch_cap / per_dir);
     FTTE_HIP(c, hipStreamSynchronize(stream)); // d_uvb below may still be read by the previous sweep
     if ((rc = ensure(c, &c->d_uvb, &c->d_uvb_cap, (size_t)nnu))) return rc;
     FTTE_HIP(c, hipMemcpy(c->d_uvb, uvb, sizeof(double) * nnu, hipMemcpyHostToDevice));
@@ -758,7 +780,7 @@ int forest_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
     }
     }
 
-    const int nbatch = (ndir + kAmrBatch - 1) / kAmrBatch;
+    const int nbatch = (ndir + batch - 1) / batch;
     while ((int)c->timing.size() < nbatch) {
         LaunchTiming t;
         FTTE_HIP(c, hipEventCreate(&t.start));
@@ -770,7 +792,7 @@ int forest_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
 
     static const ftte_consts kMath = FTTE_CONSTS_INIT;
     for (int b = 0; b < nbatch; ++b) {
-        const int d0 = b * kAmrBatch, nb = std::min(kAmrBatch, ndir - d0);
+        const int d0 = b * batch, nb = std::min(batch, ndir - d0);
         AmrLevelRec A;
         std::memset(&A, 0, sizeof A);
         A.kappa = cell_major ? c->amr_kappa : c->kappa[0];

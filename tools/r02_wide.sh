@@ -1,0 +1,23 @@
+#!/bin/bash
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r02n
+mkdir -p $OUT
+cd $GRAFT_REPO_ROOT/radiativetransfer_amd/csrc
+run() { tag=$1; shift; (cd $GRAFT_REPO_ROOT && python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline "$@" > $OUT/$tag.json 2> $OUT/$tag.err); python3 - <<PY
+import json
+try:
+    r=json.load(open("$OUT/$tag.json"))
+    print("$tag", "ms/step %.2f"%r["ms_per_step"], "frac %.3f"%r["roofline"]["frac"], "sweep phase ms/step %.2f"%(r["roofline"]["avg_launch_ms"]), flush=True)
+except Exception as e:
+    print("$tag FAILED", e, open("$OUT/$tag.err").read()[-300:])
+PY
+}
+for N in 1 2 4; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-gpu-rdc -x hip -c ftte_brick.hip -o ftte_brick.o -DFTTE_BRICK_WIDE=$N 2> $OUT/build_$N.err
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libftte.so ftte_kernels.o ftte_brick.o ftte_api.o ftte_geometry.o ftte_amr.o ftte_point.o ftte_ingest.o
+  if [ $N = 2 ]; then (cd $GRAFT_REPO_ROOT && python -m pytest tests/test_brick_gpu.py -x -q -m gpu 2>&1 | tail -2); fi
+  for G in 3 4 6 8; do
+  run w${N}_g${G}_v2 --brick-waves 2 --group $G
+  done
+  run w${N}_g3_v3 --brick-waves 3 --group 3
+  run w${N}_g4_v3 --brick-waves 3 --group 4
+done
