@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--brick-waves", type=int, default=0, help="bricks: waves per SIMD the kernel is compiled for")
     ap.add_argument("--team", type=int, default=-1, help="bricks: 1 one wavefront per direction (default), 0 one wavefront per group")
     ap.add_argument("--share", type=int, default=-1, help="bricks: accumulator sharing 0/1/2")
+    ap.add_argument("--dataflow", type=int, default=-1, help="bricks: 1 one launch with flags (default where the grid allows), 0 a launch per stage")
     ap.add_argument("--lanes", type=int, default=0, help="bricks: streams the frequency groups are spread over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=0, help="grid size of the CPU sample (default: --n)")
@@ -252,6 +253,8 @@ def main():
         eng.set_option("share", a.share)
     if a.lanes:
         eng.set_option("lanes", a.lanes)
+    if a.dataflow >= 0:
+        eng.set_option("dataflow", a.dataflow)
     stream = torch.cuda.current_stream().cuda_stream
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]

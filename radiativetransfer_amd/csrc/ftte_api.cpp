@@ -67,7 +67,7 @@ struct Plan {
 struct BrickPlan {
     bool valid = false;
     // key
-    int n = 0, chunk = 0, gmax = 0, share = 0, want_glanes = 0;
+    int n = 0, chunk = 0, gmax = 0, share = 0, want_glanes = 0, want_dataflow = 0;
     double box = 0;
     std::vector<double> phi, theta, w;
     // content
@@ -76,6 +76,9 @@ struct BrickPlan {
     struct Group { int izone = 0, layout = 0, acc = 0, offset = 0, lane = 0; std::vector<int> dirs; };
     std::vector<Group> groups;
     std::vector<BrickTask> tasks;      // stage after stage
+    bool dataflow = false;             // one launch, bricks wait for each other through flags (needs whole bricks: n % 64 == 0)
+    std::vector<int32_t> deps;         // [tasks][kBrickDeps]
+    int ut = kBrickRows, uw = 0;       // u-face ring: doubles per brick and layer, per layer
     int glanes = 1, nstages = 0;       // the groups are dealt to `glanes` streams (the groups of one accumulator stay together)
     std::vector<size_t> stage_off;     // [glanes][nstages + 1] into tasks
     int64_t updates = 0;               // cell.direction updates of a sweep (per frequency group)
@@ -122,6 +125,14 @@ struct ftte_ctx {
     std::vector<hipStream_t> lane_stream;   // extra streams of the brick sweep (frequency groups are independent)
     std::vector<hipEvent_t> lane_done;
     hipEvent_t ev_fork = nullptr;
+    // option: 0 = a launch per stage (default); 1, 2 = the bricks of a sweep in ONE launch where the grid allows it, waiting for each
+    // other through flags (measured: no faster -- the stage boundaries are not what limits the sweep, DESIGN.md -- so not the default)
+    int dataflow = 0;
+    int32_t *d_bdeps = nullptr; size_t d_bdeps_cap = 0;
+    uint32_t *d_bdone = nullptr; size_t d_bdone_cap = 0;
+    uint32_t *d_bsync = nullptr;      // [0] ticket, [1] error
+    uint32_t *h_berror = nullptr;     // pinned: the error flag of the last dataflow sweep, copied back behind it
+    uint32_t bepoch = 0;
     BrickPlan bplan;
     bool bplan_uploaded = false;
     LayerRec *d_blayers = nullptr; size_t d_blayers_cap = 0;
@@ -425,8 +436,10 @@ int build_brick_plan(ftte_ctx *c, int ndir, const double *phi, const double *the
     // groups keep the stages wide enough; the groups are then dealt to the streams instead of the frequency groups.
     const int chunk = std::min(c->chunk > 0 ? c->chunk : (nnu >= 4 ? 16 : nnu >= 2 ? 8 : 4), n);
     const int gmax = c->group > 0 ? c->group : (nnu >= 2 ? 3 : 2);
-    const int want_glanes = nnu >= c->lanes ? 1 : c->lanes;
-    if (P.valid && P.n == n && P.chunk == chunk && P.gmax == gmax && P.share == c->share && P.want_glanes == want_glanes && P.box == c->box &&
+    const int want_dataflow = (c->dataflow && n % 64 == 0 && n % kBrickRows == 0 && n % chunk == 0 && !c->team) ? 1 : 0;
+    const int want_glanes = want_dataflow ? 1 : (nnu >= c->lanes ? 1 : c->lanes);
+    if (P.valid && P.n == n && P.chunk == chunk && P.gmax == gmax && P.share == c->share && P.want_glanes == want_glanes &&
+        P.want_dataflow == want_dataflow && P.box == c->box &&
         (int)P.phi.size() == ndir &&
         (ndir == 0 || (!std::memcmp(P.phi.data(), phi, sizeof(double) * ndir) &&
                        !std::memcmp(P.theta.data(), theta, sizeof(double) * ndir) &&
@@ -435,7 +448,7 @@ int build_brick_plan(ftte_ctx *c, int ndir, const double *phi, const double *the
 
     ++c->n_plan_builds;
     P = BrickPlan();
-    P.n = n; P.chunk = chunk; P.gmax = gmax; P.share = c->share; P.want_glanes = want_glanes; P.box = c->box;
+    P.n = n; P.chunk = chunk; P.gmax = gmax; P.share = c->share; P.want_glanes = want_glanes; P.want_dataflow = want_dataflow; P.box = c->box;
     P.phi.assign(phi, phi + ndir); P.theta.assign(theta, theta + ndir); P.w.assign(w, w + ndir);
     P.dirs.resize(ndir);
     P.layers.resize((size_t)ndir * n);
@@ -449,7 +462,10 @@ int build_brick_plan(ftte_ctx *c, int ndir, const double *phi, const double *the
     }
     P.ntu = (n + 63) / 64; P.ntv = (n + kBrickRows - 1) / kBrickRows; P.nti = (n + chunk - 1) / chunk;
     P.up = 64 * P.ntu; P.vp = kBrickRows * P.ntv;
-    P.vface_off = (int64_t)P.ntu * 2 * chunk * P.vp;
+    P.dataflow = want_dataflow != 0;
+    P.ut = P.dataflow ? 16 : kBrickRows; // a 128-byte line of its own per brick and layer when bricks of one launch exchange rays
+    P.uw = P.ntv * P.ut;
+    P.vface_off = (int64_t)P.ntu * 2 * chunk * P.uw;
     P.iface_off = P.vface_off + (int64_t)P.ntv * 2 * chunk * P.up;
     P.face_elems = P.iface_off + (int64_t)2 * P.vp * P.up;
 
@@ -594,6 +610,41 @@ int build_brick_plan(ftte_ctx *c, int ndir, const double *phi, const double *the
                     }
         }
     }
+    if (P.dataflow && !P.tasks.empty()) {
+        // what each brick waits for.  All of them lie earlier in the (stage-ordered) list.
+        const size_t nt = P.tasks.size(), nb = (size_t)P.ntu * P.ntv * P.nti;
+        std::vector<int32_t> index(P.groups.size() * nb, -1);
+        auto at = [&](size_t g, int tu, int tv, int ti) -> int32_t & { return index[g * nb + ((size_t)ti * P.ntv + tv) * P.ntu + tu]; };
+        for (size_t q = 0; q < nt; ++q) at((size_t)P.tasks[q].group, P.tasks[q].tu, P.tasks[q].tv, P.tasks[q].ti & (kBrickAccumulate - 1)) = (int32_t)q;
+        P.deps.assign(nt * kBrickDeps, -1);
+        // the visitors of every J tile, per accumulator, in launch order
+        struct Visit { int launch; int32_t task; };
+        std::vector<std::vector<std::vector<Visit>>> visits(3 * (size_t)kMaxAcc);
+        for (size_t q = 0; q < nt; ++q) {
+            const BrickTask &T = P.tasks[q];
+            const BrickPlan::Group &G = P.groups[(size_t)T.group];
+            const int ti = T.ti & (kBrickAccumulate - 1);
+            int32_t *D = &P.deps[q * kBrickDeps];
+            if (T.tu > 0) D[0] = at((size_t)T.group, T.tu - 1, T.tv, ti);
+            if (T.tv > 0) D[1] = at((size_t)T.group, T.tu, T.tv - 1, ti);
+            if (ti > 0) D[2] = at((size_t)T.group, T.tu, T.tv, ti - 1);
+            if (ti >= 2 && T.tu + 1 < P.ntu) D[4] = at((size_t)T.group, T.tu + 1, T.tv, ti - 2); // read the u-face slot this brick rewrites
+            if (ti >= 2 && T.tv + 1 < P.ntv) D[5] = at((size_t)T.group, T.tu, T.tv + 1, ti - 2); // the v-face slot
+            auto &V = visits[(size_t)G.layout * kMaxAcc + G.acc];
+            if (V.empty()) V.resize(nb);
+            const DirPlan &D0 = P.dirs[G.dirs[0]];
+            const int bu = D0.su < 0 ? P.ntu - 1 - T.tu : T.tu, bv = D0.sv < 0 ? P.ntv - 1 - T.tv : T.tv, bi = D0.si < 0 ? P.nti - 1 - ti : ti;
+            V[((size_t)bi * P.ntv + bv) * P.ntu + bu].push_back({T.tu + T.tv + ti + G.offset, (int32_t)q});
+        }
+        for (auto &V : visits)
+            for (auto &list : V) {
+                std::sort(list.begin(), list.end(), [](const Visit &x, const Visit &y) { return x.launch < y.launch; });
+                for (size_t k = 1; k < list.size(); ++k) P.deps[(size_t)list[k].task * kBrickDeps + 3] = list[k - 1].task;
+            }
+        for (size_t q = 0; q < nt; ++q)
+            for (int k = 0; k < kBrickDeps; ++k)
+                if (P.deps[q * kBrickDeps + k] >= (int32_t)q) return fail(c, FTTE_ERR_STATE, "brick plan: a dependency does not precede its brick");
+    }
     P.valid = true;
     return FTTE_OK;
 }
@@ -636,6 +687,10 @@ int wait_sweep(ftte_ctx *c)
     if (c->sweep_pending) {
         FTTE_HIP(c, hipEventSynchronize(c->ev_sweep_done));
         c->sweep_pending = false;
+        if (c->h_berror && *c->h_berror) {
+            *c->h_berror = 0;
+            return fail(c, FTTE_ERR_NO_DEVICE, "the previous sweep gave up: a brick waited too long for the bricks it depends on (its J is not valid)");
+        }
     }
     return FTTE_OK;
 }
@@ -896,6 +951,10 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
             FTTE_HIP(c, hipMemcpy(c->d_blayers, P.layers.data(), sizeof(LayerRec) * P.layers.size(), hipMemcpyHostToDevice));
         if (!P.tasks.empty())
             FTTE_HIP(c, hipMemcpy(c->d_btasks, P.tasks.data(), sizeof(BrickTask) * P.tasks.size(), hipMemcpyHostToDevice));
+        if (P.dataflow && !P.deps.empty()) {
+            if ((rc = ensure(c, &c->d_bdeps, &c->d_bdeps_cap, P.deps.size()))) return rc;
+            FTTE_HIP(c, hipMemcpy(c->d_bdeps, P.deps.data(), sizeof(int32_t) * P.deps.size(), hipMemcpyHostToDevice));
+        }
         c->bplan_uploaded = true;
     }
     // the group records carry pointers that depend on nnu (face blocks) and on the buffers: rebuilt per sweep (a few KB)
@@ -950,8 +1009,40 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
         LaunchTiming &T = c->timing[0];
         T.updates = P.updates * nnu;
         FTTE_HIP(c, hipEventRecord(T.start, stream));
+        if (P.dataflow) {
+            // every brick of the sweep in one launch; flags of `epoch` mark the finished ones (the array is zeroed when it is
+            // (re)allocated and when the epoch wraps, never in between)
+            const size_t nflags = P.tasks.size() * (size_t)nnu;
+            if (c->d_bdone_cap < nflags || c->bepoch == 0xffffffffu) {
+                if ((rc = ensure(c, &c->d_bdone, &c->d_bdone_cap, nflags))) return rc;
+                FTTE_HIP(c, hipMemsetAsync(c->d_bdone, 0, sizeof(uint32_t) * c->d_bdone_cap, stream));
+                c->bepoch = 0;
+            }
+            if (!c->d_bsync) {
+                FTTE_HIP(c, hipMalloc((void **)&c->d_bsync, sizeof(uint32_t) * 2));
+                FTTE_HIP(c, hipHostMalloc((void **)&c->h_berror, sizeof(uint32_t), hipHostMallocDefault));
+                *c->h_berror = 0;
+            }
+            FTTE_HIP(c, hipMemsetAsync(c->d_bsync, 0, sizeof(uint32_t) * 2, stream));
+            BrickLaunch L;
+            std::memset(&L, 0, sizeof L);
+            L.groups = c->d_bgroups;
+            L.tasks = c->d_btasks;
+            L.uvb = c->d_uvb;
+            L.group_stride = c->ncell;
+            L.face_stride = P.face_elems;
+            L.vface_off = P.vface_off; L.iface_off = P.iface_off;
+            L.n = n; L.ntasks = (int)P.tasks.size(); L.nnu = nnu; L.nu0 = 0; L.chunk = P.chunk;
+            L.up = P.up; L.vp = P.vp; L.uw = P.uw; L.ut = P.ut;
+            L.emit = c->emit_mode;
+            L.ticket = c->d_bsync; L.error = c->d_bsync + 1; L.done = c->d_bdone; L.deps = c->d_bdeps; L.epoch = ++c->bepoch; L.pad_ = c->dataflow == 2 ? 1 : 0;
+            L.math = kMath;
+            const int lrc = launch_brick(L, P.max_dirs, c->brick_waves, stream);
+            if (lrc) return fail(c, lrc == -1 ? FTTE_ERR_ARG : FTTE_ERR_NO_DEVICE, "brick kernel launch failed");
+            FTTE_HIP(c, hipMemcpyAsync(c->h_berror, c->d_bsync + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        }
         FTTE_HIP(c, hipEventRecord(c->ev_fork, stream));
-        for (int lane = 0; lane < nlanes; ++lane) {
+        for (int lane = 0; lane < nlanes && !P.dataflow; ++lane) {
             hipStream_t q = lane == 0 ? stream : c->lane_stream[(size_t)lane - 1];
             if (lane) FTTE_HIP(c, hipStreamWaitEvent(q, c->ev_fork, 0));
             const int gl = P.glanes > 1 ? lane : 0, nl = P.glanes > 1 ? 0 : lane;
@@ -968,7 +1059,7 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
                 L.face_stride = P.face_elems;
                 L.vface_off = P.vface_off; L.iface_off = P.iface_off;
                 L.n = n; L.ntasks = (int)(off[st + 1] - off[st]); L.nnu = nu1 - nu0; L.nu0 = nu0; L.chunk = P.chunk;
-                L.up = P.up; L.vp = P.vp;
+                L.up = P.up; L.vp = P.vp; L.uw = P.uw; L.ut = P.ut;
                 L.emit = c->emit_mode;
                 L.math = kMath;
                 const int lrc = (c->team && !c->emit_mode) ? launch_brick_team(L, P.max_dirs, c->brick_waves, q) : launch_brick(L, P.max_dirs, c->brick_waves, q);
@@ -1133,6 +1224,10 @@ int ftte_destroy(ftte_ctx *c)
         if (c->emis[l]) (void)hipFree(c->emis[l]);
         for (int s = 0; s < kMaxAcc; ++s) if (c->acc[l][s]) (void)hipFree(c->acc[l][s]);
     }
+    if (c->d_bdeps) (void)hipFree(c->d_bdeps);
+    if (c->d_bdone) (void)hipFree(c->d_bdone);
+    if (c->d_bsync) (void)hipFree(c->d_bsync);
+    if (c->h_berror) (void)hipHostFree(c->h_berror);
     if (c->d_blayers) (void)hipFree(c->d_blayers);
     if (c->d_bgroups) (void)hipFree(c->d_bgroups);
     if (c->d_btasks) (void)hipFree(c->d_btasks);
@@ -1336,6 +1431,9 @@ int ftte_set_option(ftte_ctx *c, const char *key, int value)
     } else if (!std::strcmp(key, "group")) {
         if (value < 0 || value > kBrickMaxDirs) return fail(c, FTTE_ERR_ARG, "group (directions sharing a brick pass) must be 1..8, or 0 for the default");
         c->group = value;
+    } else if (!std::strcmp(key, "dataflow")) {
+        if (value < 0 || value > 2) return fail(c, FTTE_ERR_ARG, "dataflow must be 0 (a launch per stage), 1 (one launch, bricks wait for each other) or 2 (the same with write-through stores)");
+        c->dataflow = value;
     } else if (!std::strcmp(key, "lanes")) {
         if (value < 1 || value > 16) return fail(c, FTTE_ERR_ARG, "lanes (streams the brick sweep spreads its frequency groups over) must be 1..16");
         c->lanes = value;
@@ -1525,7 +1623,8 @@ int ftte_diffuse_sweep(ftte_ctx *c, int ndir, const double *phi, const double *t
     const size_t elems = (size_t)c->nnu * c->ncell;
     if ((rc = ensure(c, &c->host_J_dev, &c->host_J_cap, elems))) return rc; // kept from call to call
     if ((rc = ftte_diffuse_sweep_device(c, ndir, phi, theta, w, uvb, c->host_J_dev, nullptr))) return rc;
-    return download(c, J, c->host_J_dev, sizeof(double) * elems);
+    if ((rc = download(c, J, c->host_J_dev, sizeof(double) * elems))) return rc;
+    return wait_sweep(c); // the sweep has drained: report a dataflow sweep that gave up now rather than at the next call
 }
 
 /* Pins a caller-owned host array for as long as it stays registered: ftte_set_opacity / ftte_diffuse_sweep then move

@@ -63,7 +63,7 @@ template <int SHAPE, int EMIT>
 __device__ __forceinline__ void brick_step(const ftte_consts &K, double (&cur)[kBrickRows], const double (&kap)[kBrickRows],
                                            const double (&xs)[EMIT ? kBrickRows : 1],
                                            double (&Jacc)[kBrickRows], bool third_first, double d0, double d1, double d2,
-                                           double w, double uvb, gcbyte *uin, gbyte *uout, gcbyte *vin, gbyte *vout, int lane)
+                                           double w, double uvb, gcbyte *uin, gbyte *uout, gcbyte *vin, gbyte *vout, int lane, bool through = false)
 {
     constexpr bool HAS_U = SHAPE == RC_TWO_U || SHAPE == RC_THREE_U || SHAPE == RC_THREE_V;
     constexpr bool HAS_V = SHAPE == RC_TWO_V || SHAPE == RC_THREE_U || SHAPE == RC_THREE_V;
@@ -89,7 +89,7 @@ __device__ __forceinline__ void brick_step(const ftte_consts &K, double (&cur)[k
             cur[r] = I;
             Jacc[r] += ftte_cell_mean(acc, 1, w);
         } else if (SHAPE == RC_TWO_U) {
-            if (hands_u) *(gdouble *)(uout + 8 * r) = I;
+            if (hands_u) { if (through) __hip_atomic_store((double *)(uout + 8 * r), I, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *(gdouble *)(uout + 8 * r) = I; }
             I = shift_up_inject(I, ui[r]);
             acc += brick_segment<EMIT>(K, I, kap[r], xs[EMIT ? r : 0], d1);
             cur[r] = I;
@@ -101,7 +101,7 @@ __device__ __forceinline__ void brick_step(const ftte_consts &K, double (&cur)[k
             cur[r] = b;
             Jacc[r] += ftte_cell_mean(acc, 2, w);
         } else if (SHAPE == RC_THREE_U) { // 2nd piece one column on, 3rd one row on
-            if (hands_u) *(gdouble *)(uout + 8 * r) = I;
+            if (hands_u) { if (through) __hip_atomic_store((double *)(uout + 8 * r), I, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *(gdouble *)(uout + 8 * r) = I; }
             I = shift_up_inject(I, ui[r]);
             const double m1 = brick_segment<EMIT>(K, I, kap[r], xs[EMIT ? r : 0], d1);
             double c = carry;
@@ -116,7 +116,7 @@ __device__ __forceinline__ void brick_step(const ftte_consts &K, double (&cur)[k
             double b = carry;
             carry = I;
             const double m1 = brick_segment<EMIT>(K, b, kap[r], xs[EMIT ? r : 0], d1);
-            if (hands_u) *(gdouble *)(uout + 8 * r) = b;
+            if (hands_u) { if (through) __hip_atomic_store((double *)(uout + 8 * r), b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *(gdouble *)(uout + 8 * r) = b; }
             b = shift_up_inject(b, ui[r]);
             const double m2 = brick_segment<EMIT>(K, b, kap[r], xs[EMIT ? r : 0], d2);
             acc += third_first ? m2 : m1;
@@ -127,7 +127,10 @@ __device__ __forceinline__ void brick_step(const ftte_consts &K, double (&cur)[k
         asm volatile("" : "+v"(Jacc[r]));
         __builtin_amdgcn_sched_barrier(0); // rows in program order: interleaved they multiply the live registers
     }
-    if (HAS_V && vout) *(gdouble *)(vout + 8 * lane) = carry; // the top row's ray goes on in the brick above
+    if (HAS_V && vout) { // the top row's ray goes on in the brick above
+        if (through) __hip_atomic_store((double *)(vout + 8 * lane), carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *(gdouble *)(vout + 8 * lane) = carry;
+    }
 }
 
 // grid: ntasks * nnu workgroups of one wavefront; dynamic LDS: 4 KB per direction of the largest group
@@ -139,12 +142,23 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
     using cgroup = const __attribute__((address_space(4))) BrickGroup;
     using clayer = const __attribute__((address_space(4))) LayerRec;
     const int nnu = L.nnu;
-    const int nu = L.nu0 + blockIdx.x % nnu;
-    const BrickTask T = L.tasks[blockIdx.x / nnu];
+    const int lane = threadIdx.x;
+    unsigned work = blockIdx.x;
+    if (L.ticket) { // dataflow: tasks are taken in list order, whatever order the workgroups start in
+        unsigned t = 0;
+        if (lane == 0) t = atomicAdd(L.ticket, 1u);
+        work = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+        if (work >= (unsigned)L.ntasks * (unsigned)nnu) return;
+    }
+    // dataflow with write-through stores (sc1: the line goes to memory and leaves this XCD's L2) instead of an L2 write-back
+    // before the flag
+    const bool through = L.ticket != nullptr && L.pad_ != 0;
+    const int nu = L.nu0 + (int)(work % (unsigned)nnu);
+    const unsigned task_index = work / (unsigned)nnu;
+    const BrickTask T = L.tasks[task_index];
     const int tu = uniform((int)T.tu), tv = uniform((int)T.tv), ti = uniform((int)T.ti) & (kBrickAccumulate - 1);
     const bool accumulate = (uniform((int)T.ti) & kBrickAccumulate) != 0;
     cgroup *G = (cgroup *)(L.groups + uniform((int)T.group));
-    const int lane = threadIdx.x;
     const int n = L.n, chunk = L.chunk, up = L.up, vp = L.vp;
     const int ndir = G->ndir;
     const double uvb = L.uvb[nu];
@@ -171,12 +185,41 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
     const bool has_i_in = ti > 0, has_i_out = i1 < n;
     const long fnu = (long)nu * L.face_stride;
     // element offsets inside a direction's face block (ftte_internal.h)
-    const long u_out = ((long)(tu * 2 + (ti & 1)) * chunk) * vp + R * tv;
-    const long u_in = ((long)((tu - 1) * 2 + (ti & 1)) * chunk) * vp + R * tv;
+    const int uw = L.uw, ut = L.ut;
+    const long u_out = ((long)(tu * 2 + (ti & 1)) * chunk) * uw + ut * tv;
+    const long u_in = ((long)((tu - 1) * 2 + (ti & 1)) * chunk) * uw + ut * tv;
     const long v_out = L.vface_off + ((long)(tv * 2 + (ti & 1)) * chunk) * up + 64 * tu;
     const long v_in = L.vface_off + ((long)((tv - 1) * 2 + (ti & 1)) * chunk) * up + 64 * tu;
     const long i_in = L.iface_off + ((long)(ti & 1) * vp + R * tv) * up + 64 * tu + lane;
     const long i_out = L.iface_off + ((long)((ti + 1) & 1) * vp + R * tv) * up + 64 * tu + lane;
+
+    if (L.ticket) {
+        // Wait for the bricks this one depends on.  They come earlier in the list, so workgroups that started before this one
+        // hold them: no waiting cycle.  Bounded all the same: after about a second without progress the sweep is given up
+        // (error flag; every later brick gives up too) rather than left hanging.
+        const int32_t *dep = L.deps + (size_t)task_index * kBrickDeps;
+        const unsigned slot = (unsigned)(nu - L.nu0);
+        bool failed = false;
+        for (int q = 0; q < kBrickDeps && !failed; ++q) {
+            const int32_t dq = uniform(dep[q]);
+            if (dq < 0) continue;
+            const uint32_t *flag = L.done + (size_t)dq * nnu + slot;
+            unsigned spins = 0;
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != L.epoch) {
+                __builtin_amdgcn_s_sleep(20);
+                if ((++spins & 1023u) == 0 && (spins >= (1u << 21) || __hip_atomic_load(L.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                    failed = true;
+                    break;
+                }
+            }
+        }
+        if (failed) {
+            if (lane == 0) __hip_atomic_store(L.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
 
     // rays entering the brick's bottom: the inflow, or what the chunk below left
     for (int d = 0; d < ndir; ++d) {
@@ -222,8 +265,8 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
             const int rc = rp->info & 7;
             const double w = G->dir[d].w;
             gbyte *f = (gbyte *)(G->dir[d].faces + fnu);
-            gcbyte *uin = has_u_in ? (gcbyte *)f + 8 * (u_in + (long)il * vp) : nullptr;
-            gbyte *uout = has_u_out ? f + 8 * (u_out + (long)il * vp) : nullptr;
+            gcbyte *uin = has_u_in ? (gcbyte *)f + 8 * (u_in + (long)il * uw) : nullptr;
+            gbyte *uout = has_u_out ? f + 8 * (u_out + (long)il * uw) : nullptr;
             gcbyte *vin = has_v_in ? (gcbyte *)f + 8 * (v_in + (long)il * up) : nullptr;
             gbyte *vout = has_v_out ? f + 8 * (v_out + (long)il * up) : nullptr;
             double cur[R];
@@ -231,15 +274,15 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
             for (int r = 0; r < R; ++r) cur[r] = state[(d * R + r) * 64 + lane];
             const bool third_first = rc == RC_THREE_U_SWAP || rc == RC_THREE_V_SWAP;
             switch (rc) {
-            case RC_ONE: brick_step<RC_ONE, EMIT>(L.math, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane); break;
-            case RC_TWO_U: brick_step<RC_TWO_U, EMIT>(L.math, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane); break;
-            case RC_TWO_V: brick_step<RC_TWO_V, EMIT>(L.math, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane); break;
+            case RC_ONE: brick_step<RC_ONE, EMIT>(L.math, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through); break;
+            case RC_TWO_U: brick_step<RC_TWO_U, EMIT>(L.math, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through); break;
+            case RC_TWO_V: brick_step<RC_TWO_V, EMIT>(L.math, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through); break;
             case RC_THREE_U:
             case RC_THREE_U_SWAP:
-                brick_step<RC_THREE_U, EMIT>(L.math, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane);
+                brick_step<RC_THREE_U, EMIT>(L.math, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through);
                 break;
             default:
-                brick_step<RC_THREE_V, EMIT>(L.math, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane);
+                brick_step<RC_THREE_V, EMIT>(L.math, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through);
                 break;
             }
 #pragma unroll
@@ -249,7 +292,10 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
         if (own_lane) {
 #pragma unroll
             for (int r = 0; r < R; ++r)
-                if (cv0 + r <= n) __builtin_nontemporal_store(Jacc[r], (gdouble *)(jplane + (cv0 + r) * row_bytes + off0));
+                if (cv0 + r <= n) {
+                    if (through) __hip_atomic_store((double *)(jplane + (cv0 + r) * row_bytes + off0), Jacc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else __builtin_nontemporal_store(Jacc[r], (gdouble *)(jplane + (cv0 + r) * row_bytes + off0));
+                }
         }
     }
 
@@ -257,8 +303,21 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
         for (int d = 0; d < ndir; ++d) {
             gdouble *f = (gdouble *)(G->dir[d].faces + fnu);
 #pragma unroll
-            for (int r = 0; r < R; ++r) f[i_out + (long)r * up] = state[(d * R + r) * 64 + lane];
+            for (int r = 0; r < R; ++r) {
+                if (through) __hip_atomic_store((double *)&f[i_out + (long)r * up], state[(d * R + r) * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else f[i_out + (long)r * up] = state[(d * R + r) * 64 + lane];
+            }
         }
+    }
+    if (L.ticket) {
+        // publish: every store of this wavefront drained, the XCD's L2 written back, then the flag
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!through) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (lane == 0)
+            __hip_atomic_store(L.done + (size_t)task_index * nnu + (unsigned)(nu - L.nu0), L.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -309,8 +368,9 @@ __global__ void __launch_bounds__(64 * kBrickMaxDirs, WAVES) brick_team_kernel(c
     gbyte *f = (gbyte *)(G->dir[d].faces + (long)nu * L.face_stride);
     clayer *layers = (clayer *)(G->dir[d].layers);
     const double w = G->dir[d].w;
-    const long u_out = ((long)(tu * 2 + (ti & 1)) * chunk) * vp + R * tv;
-    const long u_in = ((long)((tu - 1) * 2 + (ti & 1)) * chunk) * vp + R * tv;
+    const int uw = L.uw, ut = L.ut;
+    const long u_out = ((long)(tu * 2 + (ti & 1)) * chunk) * uw + ut * tv;
+    const long u_in = ((long)((tu - 1) * 2 + (ti & 1)) * chunk) * uw + ut * tv;
     const long v_out = L.vface_off + ((long)(tv * 2 + (ti & 1)) * chunk) * up + 64 * tu;
     const long v_in = L.vface_off + ((long)((tv - 1) * 2 + (ti & 1)) * chunk) * up + 64 * tu;
     const long i_in = L.iface_off + ((long)(ti & 1) * vp + R * tv) * up + 64 * tu + lane;
@@ -354,8 +414,8 @@ __global__ void __launch_bounds__(64 * kBrickMaxDirs, WAVES) brick_team_kernel(c
         clayer *rp = layers + (i - 1);
         const double d0 = rp->dpath[0], d1 = rp->dpath[1], d2 = rp->dpath[2];
         const int rc = rp->info & 7;
-        gcbyte *uin = has_u_in ? (gcbyte *)f + 8 * (u_in + (long)il * vp) : nullptr;
-        gbyte *uout = has_u_out ? f + 8 * (u_out + (long)il * vp) : nullptr;
+        gcbyte *uin = has_u_in ? (gcbyte *)f + 8 * (u_in + (long)il * uw) : nullptr;
+        gbyte *uout = has_u_out ? f + 8 * (u_out + (long)il * uw) : nullptr;
         gcbyte *vin = has_v_in ? (gcbyte *)f + 8 * (v_in + (long)il * up) : nullptr;
         gbyte *vout = has_v_out ? f + 8 * (v_out + (long)il * up) : nullptr;
         const bool third_first = rc == RC_THREE_U_SWAP || rc == RC_THREE_V_SWAP;

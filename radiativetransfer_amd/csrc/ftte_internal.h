@@ -81,6 +81,7 @@ struct LaunchRec {
 // and the rays that cross a brick face travel through small ring buffers in memory.  A brick needs its three upstream
 // neighbours (u-1, v-1, chunk-1) to be done: bricks with equal tu + tv + ti form a stage, one launch per stage.
 constexpr int kBrickRows = 8;
+constexpr int kBrickDeps = 6;    // the bricks a brick waits for: u-1, v-1, chunk-1, the previous writer of its J tile, the readers of the two ring slots it reuses
 constexpr int kBrickMaxDirs = 8; // directions of one group (their ray state waits in LDS: 4 KB per direction and wave)
 
 struct BrickDir {
@@ -117,6 +118,15 @@ struct BrickLaunch {
     int32_t nu0;
     int32_t emit;             // 0 none, 1 BrickGroup::emis is the reference's eta, 2 a source function (LaunchRec::emit)
     int32_t up, vp;           // padded extents: 64 * ntu, kBrickRows * ntv
+    int32_t uw, ut;           // u-face ring: doubles per layer (ntv * ut) and per brick (ut = kBrickRows, or 16 = one 128-byte line
+                              // of its own per brick and layer when bricks of one launch hand rays to each other)
+    // Dataflow form (ticket != nullptr): ONE launch holds every brick of the sweep; a workgroup draws the next task of the
+    // (topologically ordered) list from `ticket`, waits until the tasks it depends on have published `epoch` in `done`, and
+    // publishes its own when its stores are visible.  deps: [ntasks][kBrickDeps] task indices or -1.
+    uint32_t *ticket, *done, *error;
+    const int32_t *deps;
+    uint32_t epoch;
+    int32_t pad_;
     ftte_consts math;
 };
 

@@ -153,3 +153,29 @@ def test_emission_through_an_opaque_source_free_slab_stays_finite(engine):
         assert 0 < J[J > 0].min() < 1e-290      # the subnormal range was really crossed
         engine.set_source_function(None)
     engine.set_option("engine", 0)
+
+
+@pytest.mark.parametrize("nnu,ndirs,group", [(2, 3, 3), (1, 2, 2), (3, 3, 4)])
+def test_one_launch_with_flags_equals_a_launch_per_stage(engine, nnu, ndirs, group):
+    """Grids of whole bricks (n a multiple of 64) are swept in ONE launch: a workgroup takes the next brick of the list, waits for
+    the flags of the bricks it depends on (upstream neighbours, the previous writer of its J tile, the readers of the ring slots
+    it reuses) and raises its own.  Same bits as the launch-per-stage form, sweep after sweep (the flags carry an epoch), with
+    shared accumulators and several passes per izone."""
+    n = 128
+    phi, theta, w = O.healpix_directions(ndirs)
+    kappa, uvb, box = synthetic.uniform_workload(n, nnu, seed=31 + nnu, tau_median=0.15)
+    engine.set_option("engine", 2)
+    engine.set_option("group", group)
+    engine.set_uniform_grid(n, box)
+    engine.set_opacity(kappa)
+    engine.set_option("dataflow", 0)
+    J_stages = engine.transport(phi, theta, w, uvb)
+    for form in (1, 2):   # 2: write-through stores instead of an L2 write-back before the flag
+        engine.set_option("dataflow", form)
+        for _ in range(3):
+            J_flags = engine.transport(phi, theta, w, uvb)
+            assert np.array_equal(J_flags, J_stages), form
+    for key, value in (("engine", 0), ("group", 0), ("dataflow", 0)):
+        engine.set_option(key, value)
+    one = (phi[:1], theta[:1], w[:1])
+    assert np.array_equal(engine.transport(*one, uvb), O.sweep_uniform(n, kappa, box, *one, uvb, arith=O.ARITH_DEVICE))
