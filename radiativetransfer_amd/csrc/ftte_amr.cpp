@@ -55,6 +55,8 @@ std::string AmrTree::build(int n_, int64_t ncell_, const int32_t *lv)
 
 namespace {
 
+constexpr int kBrickRowsHost = 8; // kBrickRows of ftte_internal.h
+
 struct PatNode {
     ftte_pattern p;
     int32_t sub[2]; // patterns of the lower / upper sub-layer of a refined cell carrying this pattern
@@ -73,8 +75,23 @@ struct Builder {
     int seq[64][3];
     int status = 0;
     std::string err;
+    const ForestRegion *reg = nullptr;
 
     Builder(const AmrTree &t, AmrForest &f) : T(t), F(f) {}
+
+    // Where the ray that enters base cell (i, j, k) [sweep frame] through `face` (0: from layer i-1, 1: from j-1, 2: from k-1)
+    // waits in the direction's face block when the cell on the other side belongs to a brick: the element the brick kernel
+    // writes (uout / vout / the chunk's top) and reads (uin / vin / the chunk's bottom), ftte_brick.hip.
+    int32_t face_element(int i, int j, int k, int face) const
+    {
+        const ForestRegion &R = *reg;
+        const int u = R.u_is_k ? k : j, v = R.u_is_k ? j : k;
+        const int ti = (i - 1) / R.chunk, il = (i - 1) % R.chunk, tu = (u - 1) / 64, tv = (v - 1) / kBrickRowsHost;
+        if (face == 0) return (int32_t)(R.iface_off + ((int64_t)(ti % R.nslot) * R.vp + (v - 1)) * R.up + (u - 1));
+        const bool along_u = (face == 2) == R.u_is_k; // face 2 steps along sweep-k
+        if (along_u) return (int32_t)((((int64_t)(tu - 1) * R.nslot + ti % R.nslot) * R.chunk + il) * ((int64_t)R.ntv * R.ut) + (int64_t)R.ut * tv + (v - 1) % kBrickRowsHost);
+        return (int32_t)(R.vface_off + (((int64_t)(tv - 1) * R.nslot + ti % R.nslot) * R.chunk + il) * R.up + (u - 1));
+    }
 
     static int slot_of(int top) { return top == 1 ? 0 : (top == 3 ? 1 : 2); } // xyEnd, xzEnd, yzEnd -> 0, 1, 2
 
@@ -181,6 +198,12 @@ struct Builder {
             int32_t d = 0;
             if (U < 0) {
                 F.up[seg] = AmrForest::kInflow;
+            } else if (reg && node_pat[U] < 0) {
+                // the upstream leaf was not visited: it lies outside the region, in a brick.  The rim of the region is made of
+                // unrefined base cells, so this is a base cell behind a base cell and the ray waits in the brick's face buffer.
+                if (lvl != 0 || T.child0[U] >= 0 || T.parent[U] >= 0) { status = FTTE_ERR_STATE; err = "hybrid sweep: a refined cell touches the region's surface"; return; }
+                F.up[seg] = AmrForest::kImport;
+                F.import_at[seg] = face_element(seq[0][0], seq[0][1], seq[0][2], face);
             } else {
                 const ftte_pattern &Q = pats[node_pat[U]].p;
                 const int top = face == 0 ? Q.xy_top : (face == 1 ? Q.xz_top : Q.yz_top);
@@ -225,7 +248,8 @@ struct Builder {
 
 } // namespace
 
-int build_forest(const AmrTree &tree, double phi, double theta, int izone, double box, AmrForest *out, std::string *err)
+int build_forest(const AmrTree &tree, double phi, double theta, int izone, double box, AmrForest *out, std::string *err,
+                 const ForestRegion *region)
 {
     AmrForest &F = *out;
     const int n = tree.n;
@@ -235,8 +259,10 @@ int build_forest(const AmrTree &tree, double phi, double theta, int izone, doubl
     F.up2.assign(nseg, -1);
     F.dpath.assign(nseg, 0.0);
 
+    F.import_at.clear(); F.exports.clear(); F.inside.clear();
+    if (region) { F.import_at.assign(nseg, -1); F.inside.assign((size_t)tree.ncell, 0); }
     Builder B(tree, F);
-    B.izone = izone; B.phi = phi; B.theta = theta;
+    B.izone = izone; B.phi = phi; B.theta = theta; B.reg = region;
     for (int i = 0; i < 2; ++i)
         for (int j = 0; j < 2; ++j)
             for (int k = 0; k < 2; ++k) {
@@ -261,9 +287,35 @@ int build_forest(const AmrTree &tree, double phi, double theta, int izone, doubl
                 int ic, jc, kc;
                 rotate_indices(i, j, k, n, n, n, izone, &ic, &jc, &kc);
                 B.seq[0][0] = i; B.seq[0][1] = j; B.seq[0][2] = k;
+                if (region && !region->contains(i, j, k)) continue;
                 B.visit((int32_t)(((int64_t)(ic - 1) * n + (jc - 1)) * n + (kc - 1)), i - 1, 0, cell);
             }
     if (B.status) { *err = B.err; return B.status; }
+    if (region) {
+        for (size_t v = 0; v < tree.parent.size(); ++v)
+            if (B.node_pat[v] >= 0 && tree.leaf[v] >= 0) F.inside[(size_t)tree.leaf[v]] = 1;
+        // the rays that leave the region: for every base cell just outside its far faces, the piece of the cell inside that
+        // ends on the shared face (same rule as a link inside the forest; the rim cells are unrefined base cells)
+        const ForestRegion &R = *region;
+        for (int face = 0; face < 3; ++face) {
+            if (R.hi[face] >= n) continue; // the region reaches the domain boundary: the rays leave the grid
+            int lo[3] = {R.lo[0], R.lo[1], R.lo[2]}, hi[3] = {R.hi[0], R.hi[1], R.hi[2]};
+            lo[face] = hi[face] = R.hi[face]; // the region's last layer of cells along this axis
+            for (int i = lo[0]; i <= hi[0]; ++i)
+                for (int j = lo[1]; j <= hi[1]; ++j)
+                    for (int k = lo[2]; k <= hi[2]; ++k) {
+                        int ic, jc, kc;
+                        rotate_indices(i, j, k, n, n, n, izone, &ic, &jc, &kc);
+                        const int32_t U = (int32_t)(((int64_t)(ic - 1) * n + (jc - 1)) * n + (kc - 1));
+                        if (tree.child0[U] >= 0) { *err = "hybrid sweep: a refined cell touches the region's surface"; return FTTE_ERR_STATE; }
+                        const ftte_pattern &Q = B.pats[B.node_pat[U]].p;
+                        const int top = face == 0 ? Q.xy_top : (face == 1 ? Q.xz_top : Q.yz_top);
+                        if (top == 0) continue; // no piece of this layer's pattern ends on that face: nothing crosses it
+                        const int di = i + (face == 0), dj = j + (face == 1), dk = k + (face == 2);
+                        F.exports.push_back({B.face_element(di, dj, dk, face), (int32_t)(3 * tree.leaf[U] + Builder::slot_of(top))});
+                    }
+        }
+    }
 
     // counting sort of the active segments by depth
     int32_t maxd = 0;

@@ -34,14 +34,32 @@ struct AmrTree {
     bool refined() const { return max_level > 0; }
 };
 
+// A box of base cells in the sweep frame of one izone (1-based, inclusive; i = march axis, j, k) to which a forest can be
+// restricted, and where the rays that cross its surface live in the face buffers of the brick sweep (ftte_internal.h:
+// BrickLaunch).  Hybrid sweep of a refined cell array: the bricks outside the box are swept by the brick kernel, the box --
+// every refined cell plus a rim of unrefined base cells, so that its surface separates unrefined base cells only -- by the forest.
+struct ForestRegion {
+    int lo[3] = {1, 1, 1}, hi[3] = {0, 0, 0}; // i, j, k
+    bool u_is_k = true;                        // which of sweep-j / sweep-k is the lane axis u of the bricks
+    int chunk = 1, ut = 8, nslot = 1;          // layers per brick, u-face doubles per brick and layer, face slots along the march
+    int ntv = 1, up = 64, vp = 8;              // v bricks, padded extents
+    int64_t vface_off = 0, iface_off = 0;      // as BrickLaunch
+    bool contains(int i, int j, int k) const { return i >= lo[0] && i <= hi[0] && j >= lo[1] && j <= hi[1] && k >= lo[2] && k <= hi[2]; }
+};
+
 // One direction's segment forest.  Segment id = 3 * leaf + slot, slot 0 xy, 1 xz, 2 yz (the order in which the
 // reference adds them into the cell's mean).
 struct AmrForest {
     static constexpr int32_t kInflow = -1;   // upstream is the domain boundary
     static constexpr int32_t kInactive = -2; // the leaf's pattern has no such segment
+    static constexpr int32_t kImport = -3;   // upstream lies outside the region: the ray waits in a face buffer (import_at)
     std::vector<int32_t> up;     // [3 ncell] upstream segment, kInflow, or kInactive
     std::vector<int32_t> up2;    // [3 ncell] second upstream segment of the mean-of-two rule, else -1
     std::vector<double> dpath;   // [3 ncell] cell size * segment length (transportRoutinesModule.f90:651)
+    std::vector<int32_t> import_at; // [3 ncell] element offset in the direction's face block, for kImport segments (region only)
+    struct Export { int32_t at, seg; };  // face element <- outgoing intensity of segment `seg`
+    std::vector<Export> exports;    // the rays that leave the region into a brick (region only)
+    std::vector<uint8_t> inside;    // [ncell] the leaf belongs to the region (region only; empty = all)
     std::vector<int32_t> order;  // active segments sorted by depth
     std::vector<int64_t> depth_off; // [ndepth + 1] ranges of `order`
     int izone = 0;
@@ -50,7 +68,8 @@ struct AmrForest {
 
 // Returns 0, or an ftte_status (FTTE_ERR_PATTERN where the reference stops: a pattern leaving the unit cell,
 // or a same-level upstream leaf without a segment on the shared face, transportRoutinesModule.f90:613-616).
+// region (may be null): restrict the forest to the leaves of that box; links across its surface become imports / exports.
 int build_forest(const AmrTree &tree, double phi_folded, double theta_folded, int izone, double box, AmrForest *out,
-                 std::string *err);
+                 std::string *err, const ForestRegion *region = nullptr);
 
 } // namespace ftte

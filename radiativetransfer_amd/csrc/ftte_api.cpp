@@ -79,6 +79,7 @@ struct BrickPlan {
     bool dataflow = false;             // one launch, bricks wait for each other through flags (needs whole bricks: n % 64 == 0)
     std::vector<int32_t> deps;         // [tasks][kBrickDeps]
     int ut = kBrickRows, uw = 0;       // u-face ring: doubles per brick and layer, per layer
+    int nslot = 2;                     // face slots along the march (BrickLaunch::nslot)
     int glanes = 1, nstages = 0;       // the groups are dealt to `glanes` streams (the groups of one accumulator stay together)
     std::vector<size_t> stage_off;     // [glanes][nstages + 1] into tasks
     int64_t updates = 0;               // cell.direction updates of a sweep (per frequency group)
@@ -161,6 +162,8 @@ struct ftte_ctx {
     };
     std::vector<ForestDev> forests;
     std::vector<double> forest_key; // phi, theta, w of the cached forests (+ box)
+    AmrDirRec *d_amr_dirs = nullptr; size_t d_amr_dirs_cap = 0;      // per-direction records of the forest batches
+    int64_t *d_amr_tables = nullptr; size_t d_amr_tables_cap = 0;    // per batch and depth: count[], begin[]
     double *amr_Iout = nullptr, *amr_mean = nullptr;
     double *amr_kappa = nullptr, *amr_emis = nullptr; // [ncell][nnu] copies
     size_t amr_kappa_cap = 0, amr_emis_cap = 0;
@@ -173,6 +176,25 @@ struct ftte_ctx {
     // overwrite what that sweep reads
     hipEvent_t ev_sweep_done = nullptr;
     bool sweep_pending = false;
+
+    // Hybrid sweep of a refined cell array: bricks outside a box around the refined cells, the segment forest inside it
+    int hybrid = 1;                       // option: 0 = the whole tree through the forest path
+    struct HybridPlan {
+        bool valid = false, worthwhile = false;
+        std::vector<double> key;          // box, chunk, group, share, then phi, theta, w
+        BrickPlan bricks;                 // groups, tasks of the bricks outside the regions (phase 1, then phase 3)
+        size_t phase1_stages = 0;         // stage lists [0, phase1_stages) come before the forest pass, the rest after it
+        std::vector<size_t> stage_off;    // into bricks.tasks
+        int64_t brick_updates = 0;        // cell.direction updates the bricks perform (per frequency group)
+        struct Dir { SegRec *rec = nullptr; uint8_t *active = nullptr; AmrExport *exports = nullptr; int64_t nexports = 0;
+                     std::vector<int64_t> depth_off; };
+        std::vector<Dir> dirs;
+        int32_t *cells = nullptr; int64_t ncells = 0; // the leaves inside the box of at least one direction
+        bool uploaded = false;
+    } hplan;
+    int32_t *d_leaf_of_base = nullptr;
+    double *base_kappa[3] = {nullptr, nullptr, nullptr};
+    size_t base_kappa_cap = 0;
 
     PointState point; // point sources: rate tables, medium, tracer scratch
 
@@ -423,36 +445,18 @@ int build_plan(ftte_ctx *c, int rows, int stack, int ndir, const double *phi, co
     return FTTE_OK;
 }
 
-// Bricks: group the directions by izone (input order within an izone, at most `group` per group), cut the grid into
-// bricks of 64 x kBrickRows x chunk cells, and order the bricks of every group into stages tu + tv + ti: a brick's three
-// upstream neighbours lie one stage earlier, its consumers exactly one stage later (which is what lets the face buffers be
-// rings over two chunks).  Pure host work, cached like the tile plan.
-int build_brick_plan(ftte_ctx *c, int ndir, const double *phi, const double *theta, const double *w)
+// The part of a brick plan that does not depend on which bricks are swept: the directions, the brick geometry and the face
+// block layout, the groups and their accumulators.
+int plan_brick_groups(ftte_ctx *c, BrickPlan &P, int ndir, const double *phi, const double *theta, const double *w, int chunk, int gmax,
+                      int want_dataflow, bool whole_faces)
 {
-    BrickPlan &P = c->bplan;
-    const int n = c->n, nnu = c->nnu;
-    // Unset options (0) follow the parallelism there is: a stage offers (bricks of a plane) x groups x frequency groups
-    // tasks, and with few frequency groups on this GPU (a rank of a frequency-sharded run) shorter bricks and smaller
-    // groups keep the stages wide enough; the groups are then dealt to the streams instead of the frequency groups.
-    const int chunk = std::min(c->chunk > 0 ? c->chunk : (nnu >= 4 ? 16 : nnu >= 2 ? 8 : 4), n);
-    const int gmax = c->group > 0 ? c->group : (nnu >= 2 ? 3 : 2);
-    const int want_dataflow = (c->dataflow && n % 64 == 0 && n % kBrickRows == 0 && n % chunk == 0 && !c->team) ? 1 : 0;
-    const int want_glanes = want_dataflow ? 1 : (nnu >= c->lanes ? 1 : c->lanes);
-    if (P.valid && P.n == n && P.chunk == chunk && P.gmax == gmax && P.share == c->share && P.want_glanes == want_glanes &&
-        P.want_dataflow == want_dataflow && P.box == c->box &&
-        (int)P.phi.size() == ndir &&
-        (ndir == 0 || (!std::memcmp(P.phi.data(), phi, sizeof(double) * ndir) &&
-                       !std::memcmp(P.theta.data(), theta, sizeof(double) * ndir) &&
-                       !std::memcmp(P.w.data(), w, sizeof(double) * ndir))))
-        return FTTE_OK;
-
+    const int n = c->n;
     ++c->n_plan_builds;
     P = BrickPlan();
-    P.n = n; P.chunk = chunk; P.gmax = gmax; P.share = c->share; P.want_glanes = want_glanes; P.want_dataflow = want_dataflow; P.box = c->box;
+    P.n = n; P.chunk = chunk; P.gmax = gmax; P.share = c->share; P.want_dataflow = want_dataflow; P.box = c->box;
     P.phi.assign(phi, phi + ndir); P.theta.assign(theta, theta + ndir); P.w.assign(w, w + ndir);
     P.dirs.resize(ndir);
     P.layers.resize((size_t)ndir * n);
-    c->bplan_uploaded = false;
 
     std::vector<ftte_pattern> pat(n);
     std::vector<int> du_cum(n + 1), dv_cum(n + 1);
@@ -465,9 +469,10 @@ int build_brick_plan(ftte_ctx *c, int ndir, const double *phi, const double *the
     P.dataflow = want_dataflow != 0;
     P.ut = P.dataflow ? 16 : kBrickRows; // a 128-byte line of its own per brick and layer when bricks of one launch exchange rays
     P.uw = P.ntv * P.ut;
-    P.vface_off = (int64_t)P.ntu * 2 * chunk * P.uw;
-    P.iface_off = P.vface_off + (int64_t)P.ntv * 2 * chunk * P.up;
-    P.face_elems = P.iface_off + (int64_t)2 * P.vp * P.up;
+    P.nslot = whole_faces ? P.nti : 2; // rings over two chunks, or every chunk's faces kept (hybrid sweep)
+    P.vface_off = (int64_t)P.ntu * P.nslot * chunk * P.uw;
+    P.iface_off = P.vface_off + (int64_t)P.ntv * P.nslot * chunk * P.up;
+    P.face_elems = P.iface_off + (int64_t)P.nslot * P.vp * P.up;
 
     if (P.nti >= kBrickAccumulate) return fail(c, FTTE_ERR_UNSUPPORTED, "brick engine: more than 16383 chunks along the march axis: raise option \"chunk\"");
 
@@ -535,6 +540,37 @@ int build_brick_plan(ftte_ctx *c, int ndir, const double *phi, const double *the
     }
     for (int layout = 0; layout < 3; ++layout)
         if (P.nacc[layout] > kMaxAcc) return fail(c, FTTE_ERR_UNSUPPORTED, "too many direction groups for one memory layout: raise option \"group\"");
+
+    return FTTE_OK;
+}
+
+// Bricks: group the directions by izone (input order within an izone, at most `group` per group), cut the grid into
+// bricks of 64 x kBrickRows x chunk cells, and order the bricks of every group into stages tu + tv + ti: a brick's three
+// upstream neighbours lie one stage earlier, its consumers exactly one stage later (which is what lets the face buffers be
+// rings over two chunks).  Pure host work, cached like the tile plan.
+int build_brick_plan(ftte_ctx *c, int ndir, const double *phi, const double *theta, const double *w)
+{
+    BrickPlan &P = c->bplan;
+    const int n = c->n, nnu = c->nnu;
+    int rc;
+    // Unset options (0) follow the parallelism there is: a stage offers (bricks of a plane) x groups x frequency groups
+    // tasks, and with few frequency groups on this GPU (a rank of a frequency-sharded run) shorter bricks and smaller
+    // groups keep the stages wide enough; the groups are then dealt to the streams instead of the frequency groups.
+    const int chunk = std::min(c->chunk > 0 ? c->chunk : (nnu >= 4 ? 16 : nnu >= 2 ? 8 : 4), n);
+    const int gmax = c->group > 0 ? c->group : (nnu >= 2 ? 3 : 2);
+    const int want_dataflow = (c->dataflow && n % 64 == 0 && n % kBrickRows == 0 && n % chunk == 0 && !c->team && !c->emit_mode) ? 1 : 0;
+    const int want_glanes = want_dataflow ? 1 : (nnu >= c->lanes ? 1 : c->lanes);
+    if (P.valid && P.n == n && P.chunk == chunk && P.gmax == gmax && P.share == c->share && P.want_glanes == want_glanes &&
+        P.want_dataflow == want_dataflow && P.box == c->box &&
+        (int)P.phi.size() == ndir &&
+        (ndir == 0 || (!std::memcmp(P.phi.data(), phi, sizeof(double) * ndir) &&
+                       !std::memcmp(P.theta.data(), theta, sizeof(double) * ndir) &&
+                       !std::memcmp(P.w.data(), w, sizeof(double) * ndir))))
+        return FTTE_OK;
+
+    if ((rc = plan_brick_groups(c, P, ndir, phi, theta, w, chunk, gmax, want_dataflow, false))) return rc;
+    P.want_glanes = want_glanes;
+    c->bplan_uploaded = false;
 
     // streams: the groups of one accumulator stay on one stream (their launches are ordered against each other)
     P.glanes = std::max(1, std::min(want_glanes, P.nacc[0] + P.nacc[1] + P.nacc[2]));
@@ -713,6 +749,88 @@ void free_forests(ftte_ctx *c)
     c->forest_key.clear();
 }
 
+// One direction of a forest pass as the host knows it
+struct ForestDirHost {
+    const SegRec *rec; const uint8_t *active; double w;
+    double *faces; const AmrExport *exports; int64_t nexports; // hybrid sweep only, else null / 0
+    const std::vector<int64_t> *depth_off;
+};
+
+// The forests of `dirs`, `batch` directions at a time: depth after depth (one launch per depth for the whole batch), then the
+// rays that leave the region (hybrid), then the per-leaf means into J in list order.  A.dir / A.count / A.begin are filled here:
+// the per-direction records and the per-depth tables live in device memory (a batch of 96 would not fit the kernel arguments).
+int run_forests(ftte_ctx *c, hipStream_t stream, const std::vector<ForestDirHost> &dirs, int batch, size_t per_dir, AmrLevelRec A,
+                double *J_dev, bool zero_first, bool time_batches)
+{
+    const int ndir = (int)dirs.size(), nnu = c->nnu;
+    const int nbatch = (ndir + batch - 1) / batch;
+    int rc;
+    // tables of every batch, built and uploaded in one go
+    std::vector<AmrDirRec> recs((size_t)ndir);
+    std::vector<size_t> maxdepth((size_t)nbatch, 0), table_at((size_t)nbatch, 0);
+    std::vector<int64_t> tables, most_of;
+    std::vector<size_t> most_at((size_t)nbatch, 0);
+    for (int b = 0; b < nbatch; ++b) {
+        const int d0 = b * batch, nb = std::min(batch, ndir - d0);
+        for (int t = 0; t < nb; ++t) {
+            const ForestDirHost &D = dirs[(size_t)(d0 + t)];
+            AmrDirRec &R = recs[(size_t)(d0 + t)];
+            std::memset(&R, 0, sizeof R);
+            R.rec = D.rec; R.active = D.active; R.w = D.w;
+            R.Iout = c->amr_Iout + per_dir * t;
+            R.mean = c->amr_mean + per_dir * t;
+            R.faces = D.faces; R.exports = D.exports; R.nexports = D.nexports;
+            maxdepth[(size_t)b] = std::max(maxdepth[(size_t)b], D.depth_off->size() - 1);
+        }
+        table_at[(size_t)b] = tables.size();
+        most_at[(size_t)b] = most_of.size();
+        for (size_t depth = 0; depth < maxdepth[(size_t)b]; ++depth) {
+            int64_t most = 0;
+            const size_t at = tables.size();
+            tables.resize(at + 2 * (size_t)nb, 0);
+            for (int t = 0; t < nb; ++t) {
+                const std::vector<int64_t> &off = *dirs[(size_t)(d0 + t)].depth_off;
+                if (depth + 1 < off.size()) {
+                    tables[at + (size_t)t] = off[depth + 1] - off[depth];
+                    tables[at + (size_t)nb + (size_t)t] = off[depth];
+                    most = std::max(most, off[depth + 1] - off[depth]);
+                }
+            }
+            most_of.push_back(most);
+        }
+    }
+    if ((rc = ensure(c, &c->d_amr_dirs, &c->d_amr_dirs_cap, recs.size()))) return rc;
+    if ((rc = ensure(c, &c->d_amr_tables, &c->d_amr_tables_cap, tables.size()))) return rc;
+    if (!recs.empty()) FTTE_HIP(c, hipMemcpyAsync(c->d_amr_dirs, recs.data(), sizeof(AmrDirRec) * recs.size(), hipMemcpyHostToDevice, stream));
+    if (!tables.empty()) FTTE_HIP(c, hipMemcpyAsync(c->d_amr_tables, tables.data(), sizeof(int64_t) * tables.size(), hipMemcpyHostToDevice, stream));
+    FTTE_HIP(c, hipStreamSynchronize(stream)); // the host vectors leave scope; pageable copies are staged anyway
+
+    for (int b = 0; b < nbatch; ++b) {
+        const int d0 = b * batch, nb = std::min(batch, ndir - d0);
+        A.dir = c->d_amr_dirs + d0;
+        A.ndir = nb;
+        if (time_batches) {
+            c->timing[(size_t)b].updates = (int64_t)nb * c->ncell * nnu;
+            FTTE_HIP(c, hipEventRecord(c->timing[(size_t)b].start, stream));
+        }
+        for (size_t depth = 0; depth < maxdepth[(size_t)b]; ++depth) {
+            A.count = c->d_amr_tables + table_at[(size_t)b] + depth * 2 * (size_t)nb;
+            A.begin = A.count + nb;
+            A.most = most_of[most_at[(size_t)b] + depth];
+            if (launch_amr_level(A, stream)) return fail(c, FTTE_ERR_NO_DEVICE, "forest level kernel launch failed");
+        }
+        int64_t most_exports = 0;
+        for (int t = 0; t < nb; ++t) most_exports = std::max(most_exports, dirs[(size_t)(d0 + t)].nexports);
+        if (launch_amr_export(A, most_exports, stream)) return fail(c, FTTE_ERR_NO_DEVICE, "forest export kernel launch failed");
+        if (launch_amr_combine(A, J_dev, zero_first && b == 0, stream)) return fail(c, FTTE_ERR_NO_DEVICE, "forest combine kernel launch failed");
+        if (time_batches) {
+            FTTE_HIP(c, hipEventRecord(c->timing[(size_t)b].stop, stream));
+            c->timing_used = b + 1;
+        }
+    }
+    return FTTE_OK;
+}
+
 // The sweep on a refined cell array: per-direction segment forests (ftte_amr.h), processed depth by depth.
 int forest_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, const double *w, const double *uvb,
                  double *J_dev, hipStream_t stream)
@@ -764,7 +882,7 @@ int forest_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
                     rec[t].resize(std::max<size_t>(nact, 1));
                     for (size_t q = 0; q < nact; ++q) {
                         const int32_t sg = f.order[q];
-                        rec[t][q].seg = sg; rec[t][q].up = f.up[sg]; rec[t][q].up2 = f.up2[sg]; rec[t][q].pad = 0;
+                        rec[t][q].seg = sg; rec[t][q].up = f.up[sg]; rec[t][q].up2 = f.up2[sg]; rec[t][q].at = 0;
                         rec[t][q].dpath = f.dpath[sg];
                     }
                     active[t].resize((size_t)ncell);
@@ -846,8 +964,7 @@ int forest_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
     if (ndir == 0) FTTE_HIP(c, hipMemsetAsync(J_dev, 0, sizeof(double) * (size_t)nnu * ncell, stream));
 
     static const ftte_consts kMath = FTTE_CONSTS_INIT;
-    for (int b = 0; b < nbatch; ++b) {
-        const int d0 = b * batch, nb = std::min(batch, ndir - d0);
+    {
         AmrLevelRec A;
         std::memset(&A, 0, sizeof A);
         A.kappa = cell_major ? c->amr_kappa : c->kappa[0];
@@ -857,36 +974,14 @@ int forest_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
         A.emit = c->emit_mode;
         A.uvb = c->d_uvb;
         A.ncell = ncell;
-        A.ndir = nb;
         A.nnu = nnu;
         A.math = kMath;
-        size_t maxdepth = 0;
-        for (int t = 0; t < nb; ++t) {
-            const ftte_ctx::ForestDev &D = c->forests[d0 + t];
-            A.dir[t].rec = D.rec; A.dir[t].active = D.active;
-            A.dir[t].Iout = c->amr_Iout + per_dir * t;
-            A.dir[t].mean = c->amr_mean + per_dir * t;
-            A.dir[t].w = D.w;
-            maxdepth = std::max(maxdepth, D.depth_off.size() - 1);
+        std::vector<ForestDirHost> dirs((size_t)ndir);
+        for (int d = 0; d < ndir; ++d) {
+            const ftte_ctx::ForestDev &D = c->forests[(size_t)d];
+            dirs[(size_t)d] = ForestDirHost{D.rec, D.active, D.w, nullptr, nullptr, 0, &D.depth_off};
         }
-        LaunchTiming &T = c->timing[b];
-        T.updates = (int64_t)nb * ncell * nnu;
-        FTTE_HIP(c, hipEventRecord(T.start, stream));
-        for (size_t depth = 0; depth < maxdepth; ++depth) {
-            int64_t total = 0;
-            for (int t = 0; t < nb; ++t) {
-                const std::vector<int64_t> &off = c->forests[d0 + t].depth_off;
-                A.first[t] = total;
-                if (depth + 1 < off.size()) { A.begin[t] = off[depth]; total += off[depth + 1] - off[depth]; }
-                else A.begin[t] = 0;
-            }
-            for (int t = nb; t <= kAmrBatch; ++t) A.first[t] = total;
-            A.total = total;
-            if (launch_amr_level(A, stream)) return fail(c, FTTE_ERR_NO_DEVICE, "forest level kernel launch failed");
-        }
-        if (launch_amr_combine(A, J_dev, b == 0, stream)) return fail(c, FTTE_ERR_NO_DEVICE, "forest combine kernel launch failed");
-        FTTE_HIP(c, hipEventRecord(T.stop, stream));
-        c->timing_used = b + 1;
+        if ((rc = run_forests(c, stream, dirs, batch, per_dir, A, J_dev, true, true))) return rc;
     }
     return mark_sweep(c, stream);
 }
@@ -1033,7 +1128,7 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
             L.face_stride = P.face_elems;
             L.vface_off = P.vface_off; L.iface_off = P.iface_off;
             L.n = n; L.ntasks = (int)P.tasks.size(); L.nnu = nnu; L.nu0 = 0; L.chunk = P.chunk;
-            L.up = P.up; L.vp = P.vp; L.uw = P.uw; L.ut = P.ut;
+            L.up = P.up; L.vp = P.vp; L.uw = P.uw; L.ut = P.ut; L.nslot = P.nslot;
             L.emit = c->emit_mode;
             L.ticket = c->d_bsync; L.error = c->d_bsync + 1; L.done = c->d_bdone; L.deps = c->d_bdeps; L.epoch = ++c->bepoch; L.pad_ = c->dataflow == 2 ? 1 : 0;
             L.math = kMath;
@@ -1059,7 +1154,7 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
                 L.face_stride = P.face_elems;
                 L.vface_off = P.vface_off; L.iface_off = P.iface_off;
                 L.n = n; L.ntasks = (int)(off[st + 1] - off[st]); L.nnu = nu1 - nu0; L.nu0 = nu0; L.chunk = P.chunk;
-                L.up = P.up; L.vp = P.vp; L.uw = P.uw; L.ut = P.ut;
+                L.up = P.up; L.vp = P.vp; L.uw = P.uw; L.ut = P.ut; L.nslot = P.nslot;
                 L.emit = c->emit_mode;
                 L.math = kMath;
                 const int lrc = (c->team && !c->emit_mode) ? launch_brick_team(L, P.max_dirs, c->brick_waves, q) : launch_brick(L, P.max_dirs, c->brick_waves, q);
@@ -1084,6 +1179,391 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
                 return fail(c, FTTE_ERR_NO_DEVICE, "merge kernel launch failed");
         } else FTTE_HIP(c, hipMemsetAsync(J_dev, 0, sizeof(double) * (size_t)nnu * c->ncell, stream)); // no directions
     }
+    return mark_sweep(c, stream);
+}
+
+// ---- hybrid sweep of a refined cell array -----------------------------------------------------------------------------
+// The reference recurses into refined cells wherever they are (transport, transportRoutinesModule.f90:577-586) and walks the
+// tree for every upstream link of every cell of every direction.  Most of a cell array is plain base cells; here those are
+// swept by the brick kernel, and only a box around the refined cells -- widened by one brick, so that its surface separates
+// unrefined base cells, across which a ray is handed over exactly as between two bricks -- by the segment forest.  Per group of
+// directions: the bricks that do not lie behind the box, then the forest (rays entering it read from the bricks' face
+// buffers, rays leaving it written there), then the bricks behind it.  J of a cell = what the bricks stored for the
+// directions in whose box it does not lie + what the forest adds for the others.
+
+void free_hybrid(ftte_ctx *c)
+{
+    for (auto &d : c->hplan.dirs) {
+        if (d.rec) (void)hipFree(d.rec);
+        if (d.active) (void)hipFree(d.active);
+        if (d.exports) (void)hipFree(d.exports);
+    }
+    if (c->hplan.cells) (void)hipFree(c->hplan.cells);
+    c->hplan = ftte_ctx::HybridPlan();
+}
+
+// the box of izone `izone`, sweep frame, tile-aligned and widened by a brick; false if the tree has no refined cell
+bool hybrid_region(const ftte_ctx *c, const BrickPlan &P, int izone, ForestRegion *R, int tile_lo[3], int tile_hi[3])
+{
+    const AmrTree &T = c->tree;
+    const int n = T.n;
+    int clo[3] = {n + 1, n + 1, n + 1}, chi[3] = {0, 0, 0}; // storage coordinates of the refined base cells
+    for (int64_t b = 0; b < (int64_t)n * n * n; ++b)
+        if (T.child0[(size_t)b] >= 0) {
+            const int cc[3] = {(int)(b / ((int64_t)n * n)) + 1, (int)((b / n) % n) + 1, (int)(b % n) + 1};
+            for (int a = 0; a < 3; ++a) { clo[a] = std::min(clo[a], cc[a]); chi[a] = std::max(chi[a], cc[a]); }
+        }
+    if (chi[0] == 0) return false;
+    ZoneMap zm;
+    zone_map(izone, &zm);
+    int slo[3], shi[3]; // sweep frame: i, j, k
+    int march_c = 0;
+    for (int a = 0; a < 3; ++a) {
+        const int sa = zm.src[a];
+        slo[sa] = zm.mirror[a] ? n + 1 - chi[a] : clo[a];
+        shi[sa] = zm.mirror[a] ? n + 1 - clo[a] : chi[a];
+        if (sa == 0) march_c = a;
+    }
+    const int fast_c = (march_c == 2) ? 1 : 2;
+    const bool u_is_k = zm.src[fast_c] == 2;
+    const int ju = u_is_k ? 2 : 1, jv = u_is_k ? 1 : 2; // sweep axes of u and v
+    const int size[3] = {P.chunk, 0, 0};
+    (void)size;
+    const int tsize_i = P.chunk, tsize_u = 64, tsize_v = kBrickRows;
+    tile_lo[0] = std::max(0, (slo[ju] - 1) / tsize_u - 1); tile_hi[0] = std::min(P.ntu - 1, (shi[ju] - 1) / tsize_u + 1);
+    tile_lo[1] = std::max(0, (slo[jv] - 1) / tsize_v - 1); tile_hi[1] = std::min(P.ntv - 1, (shi[jv] - 1) / tsize_v + 1);
+    tile_lo[2] = std::max(0, (slo[0] - 1) / tsize_i - 1);  tile_hi[2] = std::min(P.nti - 1, (shi[0] - 1) / tsize_i + 1);
+    R->u_is_k = u_is_k;
+    R->lo[0] = tile_lo[2] * tsize_i + 1; R->hi[0] = std::min(n, (tile_hi[2] + 1) * tsize_i);
+    R->lo[ju] = tile_lo[0] * tsize_u + 1; R->hi[ju] = std::min(n, (tile_hi[0] + 1) * tsize_u);
+    R->lo[jv] = tile_lo[1] * tsize_v + 1; R->hi[jv] = std::min(n, (tile_hi[1] + 1) * tsize_v);
+    R->chunk = P.chunk; R->ut = P.ut; R->nslot = P.nslot; R->ntv = P.ntv; R->up = P.up; R->vp = P.vp;
+    R->vface_off = P.vface_off; R->iface_off = P.iface_off;
+    return true;
+}
+
+int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *theta, const double *w)
+{
+    ftte_ctx::HybridPlan &H = c->hplan;
+    const int n = c->n, nnu = c->nnu;
+    // short bricks: the box is widened by one brick on every side, and what lies inside it costs several times a brick's bytes
+    const int chunk = std::min(c->chunk > 0 ? c->chunk : 4, n);
+    const int gmax = c->group > 0 ? c->group : (nnu >= 2 ? 3 : 2);
+    std::vector<double> key = {c->box, (double)chunk, (double)gmax, (double)c->share};
+    key.insert(key.end(), phi, phi + ndir);
+    key.insert(key.end(), theta, theta + ndir);
+    key.insert(key.end(), w, w + ndir);
+    if (H.valid && H.key == key) return FTTE_OK;
+    free_hybrid(c);
+    int rc;
+    BrickPlan &P = H.bricks;
+    if ((rc = plan_brick_groups(c, P, ndir, phi, theta, w, chunk, gmax, 0, true))) return rc;
+    P.glanes = 1;
+
+    // the box of every group; is the part outside the boxes worth a brick sweep?
+    struct Box { ForestRegion R; int lo[3], hi[3]; bool any; };
+    std::vector<Box> box(P.groups.size());
+    int64_t inside_bricks = 0, all_bricks = 0;
+    for (size_t g = 0; g < P.groups.size(); ++g) {
+        box[g].any = hybrid_region(c, P, P.groups[g].izone, &box[g].R, box[g].lo, box[g].hi);
+        all_bricks += (int64_t)P.ntu * P.ntv * P.nti;
+        if (box[g].any) inside_bricks += (int64_t)(box[g].hi[0] - box[g].lo[0] + 1) * (box[g].hi[1] - box[g].lo[1] + 1) * (box[g].hi[2] - box[g].lo[2] + 1);
+    }
+    H.key = key;
+    H.valid = true;
+    H.worthwhile = !P.groups.empty() && inside_bricks * 2 <= all_bricks; // else: the forest path for the whole tree
+    if (!H.worthwhile) return FTTE_OK;
+
+    // tasks: the bricks outside the boxes.  Phase 1: those that do not lie behind their group's box (no tile index at or beyond
+    // the box's first one in all three directions); phase 3: the others.  Within a phase stage by stage as in a plain sweep.
+    int max_offset = 0;
+    for (const auto &G : P.groups) max_offset = std::max(max_offset, G.offset);
+    const int per_phase = P.ntu + P.ntv + P.nti - 2 + max_offset;
+    const size_t nlist = 2 * (size_t)per_phase;
+    H.phase1_stages = (size_t)per_phase;
+    auto list_of = [&](const Box &B, int tu, int tv, int ti, int offset) {
+        const bool behind = B.any && tu >= B.lo[0] && tv >= B.lo[1] && ti >= B.lo[2];
+        return (size_t)(behind ? per_phase : 0) + (size_t)(tu + tv + ti + offset);
+    };
+    auto in_box = [&](const Box &B, int tu, int tv, int ti) {
+        return B.any && tu >= B.lo[0] && tu <= B.hi[0] && tv >= B.lo[1] && tv <= B.hi[1] && ti >= B.lo[2] && ti <= B.hi[2];
+    };
+    const size_t nb = (size_t)P.ntu * P.ntv * P.nti;
+    std::vector<std::vector<size_t>> first(3 * (size_t)kMaxAcc);
+    auto brick_of = [&](const BrickPlan::Group &G, int tu, int tv, int ti) {
+        const DirPlan &D0 = P.dirs[G.dirs[0]];
+        const int bu = D0.su < 0 ? P.ntu - 1 - tu : tu, bv = D0.sv < 0 ? P.ntv - 1 - tv : tv, bi = D0.si < 0 ? P.nti - 1 - ti : ti;
+        return ((size_t)bi * P.ntv + bv) * P.ntu + bu;
+    };
+    H.stage_off.assign(nlist + 1, 0);
+    for (size_t g = 0; g < P.groups.size(); ++g) {
+        const BrickPlan::Group &G = P.groups[g];
+        std::vector<size_t> &F = first[(size_t)G.layout * kMaxAcc + G.acc];
+        if (F.empty()) F.assign(nb, ~(size_t)0);
+        for (int ti = 0; ti < P.nti; ++ti)
+            for (int tv = 0; tv < P.ntv; ++tv)
+                for (int tu = 0; tu < P.ntu; ++tu) {
+                    if (in_box(box[g], tu, tv, ti)) continue;
+                    const size_t l = list_of(box[g], tu, tv, ti, G.offset);
+                    ++H.stage_off[l + 1];
+                    size_t &f = F[brick_of(G, tu, tv, ti)];
+                    f = std::min(f, l);
+                }
+    }
+    for (size_t l = 0; l < nlist; ++l) H.stage_off[l + 1] += H.stage_off[l];
+    P.tasks.resize(H.stage_off[nlist]);
+    std::vector<size_t> fill(H.stage_off.begin(), H.stage_off.end() - 1);
+    H.brick_updates = 0;
+    for (size_t g = 0; g < P.groups.size(); ++g) {
+        const BrickPlan::Group &G = P.groups[g];
+        const std::vector<size_t> &F = first[(size_t)G.layout * kMaxAcc + G.acc];
+        for (int ti = 0; ti < P.nti; ++ti)
+            for (int tv = 0; tv < P.ntv; ++tv)
+                for (int tu = 0; tu < P.ntu; ++tu) {
+                    if (in_box(box[g], tu, tv, ti)) continue;
+                    const size_t l = list_of(box[g], tu, tv, ti, G.offset);
+                    BrickTask T;
+                    T.group = (int16_t)g; T.tu = (int16_t)tu; T.tv = (int16_t)tv;
+                    T.ti = (int16_t)(ti | (l > F[brick_of(G, tu, tv, ti)] ? kBrickAccumulate : 0));
+                    P.tasks[fill[l]++] = T;
+                    const int64_t cu = std::min(64, n - 64 * tu), cv = std::min(kBrickRows, n - kBrickRows * tv), ci = std::min(chunk, n - chunk * ti);
+                    H.brick_updates += cu * cv * ci * (int64_t)G.dirs.size();
+                }
+    }
+
+    // the forests, restricted to the boxes: linked on the host a few directions at a time, uploaded, the host copy dropped
+    std::vector<int> group_of((size_t)ndir, -1);
+    for (size_t g = 0; g < P.groups.size(); ++g) for (int d : P.groups[g].dirs) group_of[(size_t)d] = (int)g;
+    H.dirs.resize((size_t)ndir);
+    const int64_t ncell = c->ncell;
+    const int nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<uint8_t> in_any((size_t)ncell, 0);
+    ++c->n_forest_builds;
+    for (int d0 = 0; d0 < ndir; d0 += nthreads) {
+        const int nbt = std::min(nthreads, ndir - d0);
+        std::vector<AmrForest> F(nbt);
+        std::vector<std::vector<SegRec>> rec(nbt);
+        std::vector<std::vector<uint8_t>> active(nbt);
+        std::vector<int> st(nbt, 0);
+        std::vector<std::string> msg(nbt);
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nbt; ++t)
+            pool.emplace_back([&, t] {
+                const int d = d0 + t;
+                const DirPlan &D = P.dirs[(size_t)d];
+                const Box &B = box[(size_t)group_of[(size_t)d]];
+                st[t] = build_forest(c->tree, D.phi, D.theta, D.izone, c->box, &F[t], &msg[t], &B.R);
+                if (st[t]) return;
+                const AmrForest &f = F[t];
+                const size_t nact = f.order.size();
+                rec[t].resize(std::max<size_t>(nact, 1));
+                for (size_t q = 0; q < nact; ++q) {
+                    const int32_t sg = f.order[q];
+                    rec[t][q].seg = sg; rec[t][q].up = f.up[sg]; rec[t][q].up2 = f.up2[sg];
+                    rec[t][q].at = f.up[sg] == AmrForest::kImport ? f.import_at[sg] : 0;
+                    rec[t][q].dpath = f.dpath[sg];
+                }
+                active[t].resize((size_t)ncell);
+                for (int64_t q = 0; q < ncell; ++q)
+                    active[t][q] = (uint8_t)((f.up[3 * q + 1] != AmrForest::kInactive ? 1 : 0) | (f.up[3 * q + 2] != AmrForest::kInactive ? 2 : 0) |
+                                             (f.inside[(size_t)q] ? 0 : 4));
+            });
+        for (auto &th : pool) th.join();
+        for (int t = 0; t < nbt; ++t) {
+            if (st[t]) { const std::string m = msg[t]; const int code = st[t]; free_hybrid(c); return fail(c, code, "direction " + std::to_string(d0 + t) + ": " + m); }
+            ftte_ctx::HybridPlan::Dir &D = H.dirs[(size_t)(d0 + t)];
+            D.depth_off = F[t].depth_off;
+            D.nexports = (int64_t)F[t].exports.size();
+            for (int64_t q = 0; q < ncell; ++q) in_any[(size_t)q] |= F[t].inside[(size_t)q];
+            FTTE_HIP(c, hipMalloc((void **)&D.rec, sizeof(SegRec) * rec[t].size()));
+            FTTE_HIP(c, hipMalloc((void **)&D.active, (size_t)ncell));
+            FTTE_HIP(c, hipMalloc((void **)&D.exports, sizeof(AmrExport) * std::max<size_t>(F[t].exports.size(), 1)));
+            FTTE_HIP(c, hipMemcpy(D.rec, rec[t].data(), sizeof(SegRec) * rec[t].size(), hipMemcpyHostToDevice));
+            FTTE_HIP(c, hipMemcpy(D.active, active[t].data(), (size_t)ncell, hipMemcpyHostToDevice));
+            if (!F[t].exports.empty())
+                FTTE_HIP(c, hipMemcpy(D.exports, F[t].exports.data(), sizeof(AmrExport) * F[t].exports.size(), hipMemcpyHostToDevice));
+        }
+    }
+    {
+        std::vector<int32_t> cells;
+        for (int64_t q = 0; q < ncell; ++q) if (in_any[(size_t)q]) cells.push_back((int32_t)q);
+        H.ncells = (int64_t)cells.size();
+        FTTE_HIP(c, hipMalloc((void **)&H.cells, sizeof(int32_t) * std::max<size_t>(cells.size(), 1)));
+        if (!cells.empty()) FTTE_HIP(c, hipMemcpy(H.cells, cells.data(), sizeof(int32_t) * cells.size(), hipMemcpyHostToDevice));
+    }
+    H.uploaded = false;
+    return FTTE_OK;
+}
+
+int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, const double *w, const double *uvb, double *J_dev,
+                 hipStream_t stream, bool *done)
+{
+    *done = false;
+    int rc;
+    if ((rc = wait_sweep(c))) return rc;
+    FTTE_HIP(c, hipStreamSynchronize(stream));
+    if (stream != c->stream) FTTE_HIP(c, hipStreamSynchronize(c->stream));
+    if ((rc = build_hybrid_plan(c, ndir, phi, theta, w))) return rc;
+    ftte_ctx::HybridPlan &H = c->hplan;
+    if (!H.worthwhile) return FTTE_OK; // the caller takes the forest path for the whole tree
+    BrickPlan &P = H.bricks;
+    const int n = c->n, nnu = c->nnu;
+    const int64_t ncell = c->ncell, nbase = (int64_t)n * n * n, nseg = 3 * ncell;
+
+    // ---- device state that depends on the tree only
+    if (!c->d_leaf_of_base) {
+        std::vector<int32_t> map((size_t)nbase);
+        for (int64_t b = 0; b < nbase; ++b) map[(size_t)b] = c->tree.leaf[(size_t)b];
+        FTTE_HIP(c, hipMalloc((void **)&c->d_leaf_of_base, sizeof(int32_t) * (size_t)nbase));
+        FTTE_HIP(c, hipMemcpy(c->d_leaf_of_base, map.data(), sizeof(int32_t) * (size_t)nbase, hipMemcpyHostToDevice));
+    }
+    const size_t per_base = (size_t)nnu * (size_t)nbase;
+    if (c->base_kappa_cap < per_base) {
+        for (int l = 0; l < 3; ++l) if (c->base_kappa[l]) { FTTE_HIP(c, hipFree(c->base_kappa[l])); c->base_kappa[l] = nullptr; }
+        for (int l = 0; l < 3; ++l) FTTE_HIP(c, hipMalloc((void **)&c->base_kappa[l], sizeof(double) * per_base));
+        c->base_kappa_cap = per_base;
+    }
+    if (c->acc_cap < (size_t)nnu * (size_t)ncell) {
+        for (int l = 0; l < 3; ++l)
+            for (int s = 0; s < kMaxAcc; ++s)
+                if (c->acc[l][s]) { FTTE_HIP(c, hipFree(c->acc[l][s])); c->acc[l][s] = nullptr; }
+        c->acc_cap = (size_t)nnu * (size_t)ncell;
+    }
+    for (int l = 0; l < 3; ++l)
+        for (int s = 0; s < P.nacc[l]; ++s)
+            if (!c->acc[l][s]) FTTE_HIP(c, hipMalloc((void **)&c->acc[l][s], sizeof(double) * c->acc_cap));
+    const size_t face_need = (size_t)ndir * nnu * (size_t)P.face_elems;
+    if ((rc = ensure(c, &c->d_faces, &c->d_faces_cap, face_need))) return rc;
+    if (!H.uploaded) {
+        if ((rc = ensure(c, &c->d_blayers, &c->d_blayers_cap, P.layers.size()))) return rc;
+        if ((rc = ensure(c, &c->d_btasks, &c->d_btasks_cap, P.tasks.size()))) return rc;
+        if ((rc = ensure(c, &c->d_bgroups, &c->d_bgroups_cap, P.groups.size()))) return rc;
+        FTTE_HIP(c, hipMemcpy(c->d_blayers, P.layers.data(), sizeof(LayerRec) * P.layers.size(), hipMemcpyHostToDevice));
+        if (!P.tasks.empty()) FTTE_HIP(c, hipMemcpy(c->d_btasks, P.tasks.data(), sizeof(BrickTask) * P.tasks.size(), hipMemcpyHostToDevice));
+        H.uploaded = true;
+        c->bplan_uploaded = false; c->bplan.valid = false; // the uniform-grid plan shared these buffers
+    }
+    {
+        std::vector<BrickGroup> G(P.groups.size());
+        std::memset(G.data(), 0, sizeof(BrickGroup) * G.size());
+        for (size_t g = 0; g < P.groups.size(); ++g) {
+            const BrickPlan::Group &Hg = P.groups[g];
+            const DirPlan &D0 = P.dirs[Hg.dirs[0]];
+            G[g].kappa = c->base_kappa[Hg.layout];
+            G[g].J = c->acc[Hg.layout][Hg.acc];
+            G[g].org = D0.org; G[g].si = D0.si; G[g].sv = D0.sv; G[g].su = D0.su;
+            G[g].ndir = (int)Hg.dirs.size();
+            for (size_t q = 0; q < Hg.dirs.size(); ++q) {
+                const int d = Hg.dirs[q];
+                G[g].dir[q].layers = c->d_blayers + P.dirs[d].layer_off;
+                G[g].dir[q].faces = c->d_faces + (size_t)d * nnu * (size_t)P.face_elems;
+                G[g].dir[q].w = P.dirs[d].w;
+            }
+        }
+        FTTE_HIP(c, hipMemcpy(c->d_bgroups, G.data(), sizeof(BrickGroup) * G.size(), hipMemcpyHostToDevice));
+    }
+    if ((rc = ensure(c, &c->d_uvb, &c->d_uvb_cap, (size_t)nnu))) return rc;
+    FTTE_HIP(c, hipMemcpy(c->d_uvb, uvb, sizeof(double) * nnu, hipMemcpyHostToDevice));
+
+    // forest scratch: as forest_sweep
+    const size_t per_dir = (size_t)nseg * nnu;
+    int batch = std::max(1, std::min(ndir, kAmrBatch));
+    if (c->amr_scratch_cap < per_dir * (size_t)batch) {
+        if (c->amr_Iout) { FTTE_HIP(c, hipFree(c->amr_Iout)); c->amr_Iout = nullptr; }
+        if (c->amr_mean) { FTTE_HIP(c, hipFree(c->amr_mean)); c->amr_mean = nullptr; }
+        c->amr_scratch_cap = 0;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)batch, (size_t)(0.9 * (double)free_b) / (2 * sizeof(double) * per_dir)));
+        FTTE_HIP(c, hipMalloc((void **)&c->amr_Iout, sizeof(double) * per_dir * (size_t)batch));
+        FTTE_HIP(c, hipMalloc((void **)&c->amr_mean, sizeof(double) * per_dir * (size_t)batch));
+        c->amr_scratch_cap = per_dir * (size_t)batch;
+    } else batch = (int)std::min<size_t>((size_t)kAmrBatch, c->amr_scratch_cap / per_dir);
+    if (nnu > 96) return FTTE_OK; // the cell-major copy of kappa is what the level kernel reads here: leave it to the forest path
+    if ((rc = ensure(c, &c->amr_kappa, &c->amr_kappa_cap, (size_t)nnu * ncell))) return rc;
+    if (!c->kappa_ready[3]) {
+        if (launch_cell_major(c->kappa[0], c->amr_kappa, ncell, nnu, stream)) return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
+        c->kappa_ready[3] = true;
+    }
+
+    while (c->timing.size() < 1) {
+        LaunchTiming t;
+        FTTE_HIP(c, hipEventCreate(&t.start));
+        FTTE_HIP(c, hipEventCreate(&t.stop));
+        c->timing.push_back(t);
+    }
+    LaunchTiming &Tm = c->timing[0];
+    Tm.updates = (int64_t)ndir * ncell * nnu;
+    c->timing_used = 0;
+    FTTE_HIP(c, hipEventRecord(Tm.start, stream));
+
+    // ---- opacity of the base cells in the three layouts; accumulators and J start from zero
+    if (launch_base_cells(c->kappa[0], c->d_leaf_of_base, c->base_kappa[0], (long)nbase, (long)ncell, nnu, stream))
+        return fail(c, FTTE_ERR_NO_DEVICE, "base-cell kernel launch failed");
+    for (int l = 1; l < 3; ++l)
+        if (P.nacc[l] && launch_to_layout(l, c->base_kappa[0], c->base_kappa[l], n, nnu, (long)nbase, stream))
+            return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
+    for (int l = 0; l < 3; ++l)
+        for (int s = 0; s < P.nacc[l]; ++s) FTTE_HIP(c, hipMemsetAsync(c->acc[l][s], 0, sizeof(double) * per_base, stream));
+    FTTE_HIP(c, hipMemsetAsync(J_dev, 0, sizeof(double) * (size_t)nnu * ncell, stream));
+
+    static const ftte_consts kMath = FTTE_CONSTS_INIT;
+    auto brick_stages = [&](size_t from, size_t to) -> int {
+        for (size_t l = from; l < to; ++l) {
+            if (H.stage_off[l + 1] == H.stage_off[l]) continue;
+            BrickLaunch L;
+            std::memset(&L, 0, sizeof L);
+            L.groups = c->d_bgroups;
+            L.tasks = c->d_btasks + H.stage_off[l];
+            L.uvb = c->d_uvb;
+            L.group_stride = nbase;
+            L.face_stride = P.face_elems;
+            L.vface_off = P.vface_off; L.iface_off = P.iface_off;
+            L.n = n; L.ntasks = (int)(H.stage_off[l + 1] - H.stage_off[l]); L.nnu = nnu; L.nu0 = 0; L.chunk = P.chunk;
+            L.up = P.up; L.vp = P.vp; L.uw = P.uw; L.ut = P.ut; L.nslot = P.nslot;
+            L.math = kMath;
+            const int lrc = launch_brick(L, P.max_dirs, c->brick_waves, stream);
+            if (lrc) return fail(c, lrc == -1 ? FTTE_ERR_ARG : FTTE_ERR_NO_DEVICE, "brick kernel launch failed");
+        }
+        return FTTE_OK;
+    };
+    if ((rc = brick_stages(0, H.phase1_stages))) return rc;
+
+    // ---- the forests of the boxes, a batch of directions at a time, depth after depth
+    {
+        AmrLevelRec A;
+        std::memset(&A, 0, sizeof A);
+        A.kappa = c->amr_kappa; A.emis = nullptr;
+        A.group_stride = 1; A.cell_stride = nnu;
+        A.emit = 0;
+        A.uvb = c->d_uvb;
+        A.ncell = ncell; A.nnu = nnu;
+        A.cells = H.cells; A.ncells = H.ncells;
+        A.face_stride = P.face_elems;
+        A.math = kMath;
+        std::vector<ForestDirHost> dirs((size_t)ndir);
+        for (int d = 0; d < ndir; ++d) {
+            const ftte_ctx::HybridPlan::Dir &D = H.dirs[(size_t)d];
+            dirs[(size_t)d] = ForestDirHost{D.rec, D.active, P.dirs[(size_t)d].w, c->d_faces + (size_t)d * nnu * (size_t)P.face_elems, D.exports,
+                                            D.nexports, &D.depth_off};
+        }
+        if ((rc = run_forests(c, stream, dirs, batch, per_dir, A, J_dev, false, false))) return rc;
+    }
+
+    if ((rc = brick_stages(H.phase1_stages, H.stage_off.size() - 1))) return rc;
+
+    // ---- J of the unrefined base cells += what the bricks stored (layout after layout, accumulator after accumulator)
+    {
+        const double *accs[3 * kMaxAcc];
+        int layouts[3 * kMaxAcc], count = 0;
+        for (int l = 0; l < 3; ++l)
+            for (int s = 0; s < P.nacc[l]; ++s) { accs[count] = c->acc[l][s]; layouts[count++] = l; }
+        if (count && launch_merge(accs, layouts, count, J_dev, n, nnu, (long)nbase, true, stream, c->d_leaf_of_base, (long)ncell))
+            return fail(c, FTTE_ERR_NO_DEVICE, "merge kernel launch failed");
+    }
+    FTTE_HIP(c, hipEventRecord(Tm.stop, stream));
+    c->timing_used = 1;
+    *done = true;
     return mark_sweep(c, stream);
 }
 
@@ -1236,8 +1716,13 @@ int ftte_destroy(ftte_ctx *c)
     if (c->d_items) (void)hipFree(c->d_items);
     if (c->d_uvb) (void)hipFree(c->d_uvb);
     free_forests(c);
+    free_hybrid(c);
+    if (c->d_leaf_of_base) (void)hipFree(c->d_leaf_of_base);
+    for (int l = 0; l < 3; ++l) if (c->base_kappa[l]) (void)hipFree(c->base_kappa[l]);
     if (c->amr_Iout) (void)hipFree(c->amr_Iout);
     if (c->amr_mean) (void)hipFree(c->amr_mean);
+    if (c->d_amr_dirs) (void)hipFree(c->d_amr_dirs);
+    if (c->d_amr_tables) (void)hipFree(c->d_amr_tables);
     if (c->amr_kappa) (void)hipFree(c->amr_kappa);
     if (c->amr_emis) (void)hipFree(c->amr_emis);
     if (c->merge_stream) (void)hipStreamDestroy(c->merge_stream);
@@ -1310,6 +1795,8 @@ int ftte_set_grid(ftte_ctx *c, int nx, int ny, int nz, int64_t ncell, const int3
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     free_forests(c);
+    free_hybrid(c);
+    if (c->d_leaf_of_base) { (void)hipFree(c->d_leaf_of_base); c->d_leaf_of_base = nullptr; }
     c->point.drop_grid();
     c->drop_chem_grid();
     c->leaf_level.assign(level, level + ncell);
@@ -1431,6 +1918,10 @@ int ftte_set_option(ftte_ctx *c, const char *key, int value)
     } else if (!std::strcmp(key, "group")) {
         if (value < 0 || value > kBrickMaxDirs) return fail(c, FTTE_ERR_ARG, "group (directions sharing a brick pass) must be 1..8, or 0 for the default");
         c->group = value;
+    } else if (!std::strcmp(key, "hybrid")) {
+        if (value != 0 && value != 1) return fail(c, FTTE_ERR_ARG, "hybrid must be 0 (a refined cell array goes through the forest path as a whole) or 1 (bricks outside a box around the refined cells)");
+        c->hybrid = value;
+        c->hplan.valid = false;
     } else if (!std::strcmp(key, "dataflow")) {
         if (value < 0 || value > 2) return fail(c, FTTE_ERR_ARG, "dataflow must be 0 (a launch per stage), 1 (one launch, bricks wait for each other) or 2 (the same with write-through stores)");
         c->dataflow = value;
@@ -1452,6 +1943,7 @@ int ftte_set_option(ftte_ctx *c, const char *key, int value)
     } else return fail(c, FTTE_ERR_ARG, std::string("unknown option: ") + key);
     c->plan.valid = false;
     c->bplan.valid = false;
+    c->hplan.valid = false;
     return FTTE_OK;
 }
 
@@ -1467,7 +1959,13 @@ int ftte_diffuse_sweep_device(ftte_ctx *c, int ndir, const double *phi, const do
     const int n = c->n, nnu = c->nnu;
     const size_t per_acc = (size_t)nnu * c->ncell;
 
-    if (c->use_forest) return forest_sweep(c, ndir, phi, theta, w, uvb, J_dev, stream);
+    if (c->use_forest) {
+        if (c->hybrid && c->tree.refined() && !c->force_forest && !c->emit_mode && ndir > 0) {
+            bool done = false;
+            if ((rc = hybrid_sweep(c, ndir, phi, theta, w, uvb, J_dev, stream, &done)) || done) return rc;
+        }
+        return forest_sweep(c, ndir, phi, theta, w, uvb, J_dev, stream);
+    }
     if (c->engine != 1) return brick_sweep(c, ndir, phi, theta, w, uvb, J_dev, stream);
     // the emission variants of the tiled kernel are built for one shape
     const int rows = c->emit_mode ? 8 : c->rows, stack = c->emit_mode ? 1 : c->stack;

@@ -134,7 +134,7 @@ __device__ __forceinline__ void brick_step(const ftte_consts &K, double (&cur)[k
 }
 
 // grid: ntasks * nnu workgroups of one wavefront; dynamic LDS: 4 KB per direction of the largest group
-template <int WAVES, int EMIT>
+template <int WAVES, int EMIT, bool FLOW>
 __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
 {
     extern __shared__ double state[]; // [direction][row][lane]
@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
     const int nnu = L.nnu;
     const int lane = threadIdx.x;
     unsigned work = blockIdx.x;
-    if (L.ticket) { // dataflow: tasks are taken in list order, whatever order the workgroups start in
+    if (FLOW) { // dataflow: tasks are taken in list order, whatever order the workgroups start in
         unsigned t = 0;
         if (lane == 0) t = atomicAdd(L.ticket, 1u);
         work = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
     }
     // dataflow with write-through stores (sc1: the line goes to memory and leaves this XCD's L2) instead of an L2 write-back
     // before the flag
-    const bool through = L.ticket != nullptr && L.pad_ != 0;
+    const bool through = FLOW && L.pad_ != 0;
     const int nu = L.nu0 + (int)(work % (unsigned)nnu);
     const unsigned task_index = work / (unsigned)nnu;
     const BrickTask T = L.tasks[task_index];
@@ -186,14 +186,15 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
     const long fnu = (long)nu * L.face_stride;
     // element offsets inside a direction's face block (ftte_internal.h)
     const int uw = L.uw, ut = L.ut;
-    const long u_out = ((long)(tu * 2 + (ti & 1)) * chunk) * uw + ut * tv;
-    const long u_in = ((long)((tu - 1) * 2 + (ti & 1)) * chunk) * uw + ut * tv;
-    const long v_out = L.vface_off + ((long)(tv * 2 + (ti & 1)) * chunk) * up + 64 * tu;
-    const long v_in = L.vface_off + ((long)((tv - 1) * 2 + (ti & 1)) * chunk) * up + 64 * tu;
-    const long i_in = L.iface_off + ((long)(ti & 1) * vp + R * tv) * up + 64 * tu + lane;
-    const long i_out = L.iface_off + ((long)((ti + 1) & 1) * vp + R * tv) * up + 64 * tu + lane;
+    const int ns = L.nslot, sl = ti % ns;
+    const long u_out = ((long)(tu * ns + sl) * chunk) * uw + ut * tv;
+    const long u_in = ((long)((tu - 1) * ns + sl) * chunk) * uw + ut * tv;
+    const long v_out = L.vface_off + ((long)(tv * ns + sl) * chunk) * up + 64 * tu;
+    const long v_in = L.vface_off + ((long)((tv - 1) * ns + sl) * chunk) * up + 64 * tu;
+    const long i_in = L.iface_off + ((long)sl * vp + R * tv) * up + 64 * tu + lane;
+    const long i_out = L.iface_off + ((long)((ti + 1) % ns) * vp + R * tv) * up + 64 * tu + lane;
 
-    if (L.ticket) {
+    if (FLOW) {
         // Wait for the bricks this one depends on.  They come earlier in the list, so workgroups that started before this one
         // hold them: no waiting cycle.  Bounded all the same: after about a second without progress the sweep is given up
         // (error flag; every later brick gives up too) rather than left hanging.
@@ -309,7 +310,7 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
             }
         }
     }
-    if (L.ticket) {
+    if (FLOW) {
         // publish: every store of this wavefront drained, the XCD's L2 written back, then the flag
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!through) {
@@ -369,12 +370,13 @@ __global__ void __launch_bounds__(64 * kBrickMaxDirs, WAVES) brick_team_kernel(c
     clayer *layers = (clayer *)(G->dir[d].layers);
     const double w = G->dir[d].w;
     const int uw = L.uw, ut = L.ut;
-    const long u_out = ((long)(tu * 2 + (ti & 1)) * chunk) * uw + ut * tv;
-    const long u_in = ((long)((tu - 1) * 2 + (ti & 1)) * chunk) * uw + ut * tv;
-    const long v_out = L.vface_off + ((long)(tv * 2 + (ti & 1)) * chunk) * up + 64 * tu;
-    const long v_in = L.vface_off + ((long)((tv - 1) * 2 + (ti & 1)) * chunk) * up + 64 * tu;
-    const long i_in = L.iface_off + ((long)(ti & 1) * vp + R * tv) * up + 64 * tu + lane;
-    const long i_out = L.iface_off + ((long)((ti + 1) & 1) * vp + R * tv) * up + 64 * tu + lane;
+    const int ns = L.nslot, sl = ti % ns;
+    const long u_out = ((long)(tu * ns + sl) * chunk) * uw + ut * tv;
+    const long u_in = ((long)((tu - 1) * ns + sl) * chunk) * uw + ut * tv;
+    const long v_out = L.vface_off + ((long)(tv * ns + sl) * chunk) * up + 64 * tu;
+    const long v_in = L.vface_off + ((long)((tv - 1) * ns + sl) * chunk) * up + 64 * tu;
+    const long i_in = L.iface_off + ((long)sl * vp + R * tv) * up + 64 * tu + lane;
+    const long i_out = L.iface_off + ((long)((ti + 1) % ns) * vp + R * tv) * up + 64 * tu + lane;
 
     // this direction's rays entering the brick's bottom: the inflow, or what the chunk below left
     double cur[R];
@@ -484,13 +486,16 @@ int launch_brick(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stre
     if (max_dirs < 1 || max_dirs > kBrickMaxDirs) return -1;
     const dim3 grid((unsigned)L.ntasks * (unsigned)L.nnu);
     const size_t lds = (size_t)max_dirs * kBrickRows * 64 * sizeof(double);
+    const bool flow = L.ticket != nullptr;
     // emission: the log-mean's own division and polynomials need more registers than three waves per SIMD leave
-    if (L.emit == 1) hipLaunchKernelGGL((brick_kernel<2, 1>), grid, dim3(64), lds, stream, L);
-    else if (L.emit == 2) hipLaunchKernelGGL((brick_kernel<2, 2>), grid, dim3(64), lds, stream, L);
+    if (L.emit == 1 && !flow) hipLaunchKernelGGL((brick_kernel<2, 1, false>), grid, dim3(64), lds, stream, L);
+    else if (L.emit == 2 && !flow) hipLaunchKernelGGL((brick_kernel<2, 2, false>), grid, dim3(64), lds, stream, L);
+    else if (L.emit) return -1; // the dataflow form is built without emission
+    else if (flow) hipLaunchKernelGGL((brick_kernel<4, 0, true>), grid, dim3(64), lds, stream, L);
     else switch (waves) {
-    case 2: hipLaunchKernelGGL((brick_kernel<2, 0>), grid, dim3(64), lds, stream, L); break;
-    case 3: hipLaunchKernelGGL((brick_kernel<3, 0>), grid, dim3(64), lds, stream, L); break;
-    case 4: hipLaunchKernelGGL((brick_kernel<4, 0>), grid, dim3(64), lds, stream, L); break;
+    case 2: hipLaunchKernelGGL((brick_kernel<2, 0, false>), grid, dim3(64), lds, stream, L); break;
+    case 3: hipLaunchKernelGGL((brick_kernel<3, 0, false>), grid, dim3(64), lds, stream, L); break;
+    case 4: hipLaunchKernelGGL((brick_kernel<4, 0, false>), grid, dim3(64), lds, stream, L); break;
     default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;

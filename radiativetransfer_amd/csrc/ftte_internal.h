@@ -118,6 +118,8 @@ struct BrickLaunch {
     int32_t nu0;
     int32_t emit;             // 0 none, 1 BrickGroup::emis is the reference's eta, 2 a source function (LaunchRec::emit)
     int32_t up, vp;           // padded extents: 64 * ntu, kBrickRows * ntv
+    int32_t nslot;            // face slots along the march: 2 = rings over two chunks (a brick's consumers run one stage later), or the
+                              // number of chunks (hybrid sweep of a refined cell array: the forest pass reads faces written many stages earlier)
     int32_t uw, ut;           // u-face ring: doubles per layer (ntv * ut) and per brick (ut = kBrickRows, or 16 = one 128-byte line
                               // of its own per brick and layer when bricks of one launch hand rays to each other)
     // Dataflow form (ticket != nullptr): ONE launch holds every brick of the sweep; a workgroup draws the next task of the
@@ -131,31 +133,40 @@ struct BrickLaunch {
 };
 
 // ---- refined cell arrays (ftte_amr.h) ------------------------------------------------------------------
-constexpr int kAmrBatch = 48; // directions in flight in the forest path
+constexpr int kAmrBatch = 96; // most directions in flight in the forest path (what fits the device memory decides)
 
 // One active segment of a direction's forest, in processing order (sorted by depth)
 struct SegRec {
     int32_t seg;     // 3 * leaf + slot: where its outgoing intensity and mean are stored
-    int32_t up, up2; // upstream segment (AmrForest::kInflow: the boundary), second one of the mean-of-two rule or -1
-    int32_t pad;
+    int32_t up, up2; // upstream segment (AmrForest::kInflow: the boundary; kImport: a face buffer), second one of the mean-of-two rule or -1
+    int32_t at;      // kImport: element of the direction's face block where the ray waits
     double dpath;    // cell size * segment length
 };
 
+struct AmrExport { int32_t at, seg; }; // face element <- outgoing intensity of a segment (a ray leaving the forest's region)
+
 struct AmrDirRec {
     const SegRec *rec;       // [active segments], depth after depth
-    const uint8_t *active;   // [ncell] bit 0: the leaf has an xz segment, bit 1: a yz segment
+    const uint8_t *active;   // [ncell] bit 0: the leaf has an xz segment, bit 1: a yz segment, bit 2: the leaf lies outside the
+                             // region this direction's forest is restricted to (hybrid sweep: a brick computed its J)
+    double *faces;           // hybrid sweep: this direction's face block (BrickDir::faces), else nullptr
+    const AmrExport *exports;
+    int64_t nexports;
     double *Iout, *mean;     // [3 ncell][nnu] scratch of this direction's slot
     double w;
 };
 
 struct AmrLevelRec {
-    AmrDirRec dir[kAmrBatch];
-    int64_t first[kAmrBatch + 1]; // prefix of the per-direction element counts of this depth
-    int64_t begin[kAmrBatch];     // where this depth starts in each direction's `order`
-    int64_t total;                // first[ndir]
+    const AmrDirRec *dir;         // [ndir], device memory
+    const int64_t *count;         // [ndir] segments of this depth per direction, device memory
+    const int64_t *begin;         // [ndir] where this depth starts in each direction's `rec`, device memory
+    int64_t most;                 // largest count[] of this depth (sizes the launch)
     const double *kappa, *uvb, *emis; // element (group g, cell c) at g * group_stride + c * cell_stride
     int64_t group_stride, cell_stride;
     int64_t ncell;
+    const int32_t *cells;    // hybrid sweep: the leaves that lie in the region of at least one direction (the combine visits only
+    int64_t ncells;          // these), else nullptr: every leaf
+    int64_t face_stride;     // elements between frequency groups in a direction's face block
     int32_t ndir, nnu, emit;
     ftte_consts math;
 };

@@ -18,7 +18,11 @@ int launch_brick_team(const BrickLaunch &L, int max_dirs, int waves, hipStream_t
 int launch_to_layout(int layout, const double *src, double *dst, int n, int nnu, long group_stride, hipStream_t stream);
 // J (cell-array order) = acc[0] + acc[1] + ... in list order; layout[a] in {0,1,2}
 int launch_merge(const double *const *acc, const int *layout, int count, double *J, int n, int nnu, long group_stride,
-                 bool accumulate, hipStream_t stream);
+                 bool accumulate, hipStream_t stream, const int32_t *leaf_of_base = nullptr, long j_stride = 0);
+// hybrid sweep of a refined cell array: leaf-ordered values -> values of the base cells; the rays leaving the forest's region
+int launch_base_cells(const double *leaf_values, const int32_t *leaf_of_base, double *base_values, long nbase, long ncell, int nnu,
+                      hipStream_t stream);
+int launch_amr_export(const AmrLevelRec &A, int64_t most_exports, hipStream_t stream);
 int launch_opacity(const double *HI, const double *HeI, const double *HeII, const double *beta, double *kappa, long ncell,
                    int nnu, hipStream_t stream);
 

@@ -441,7 +441,10 @@ struct MergeRec {
 };
 
 // accumulate != 0: J += the accumulators (the additions continue the sequence of an earlier partial merge)
-__global__ void __launch_bounds__(256) merge_kernel(const MergeRec M, double *__restrict__ J, int n, long group_stride, int accumulate)
+// leaf_of_base != nullptr (hybrid sweep of a refined cell array): the accumulators are arrays over the BASE cells (group stride
+// n^3) and J is in cell-array order (group stride j_stride): element (ic, jc, kc) goes to its leaf, refined base cells are skipped.
+__global__ void __launch_bounds__(256) merge_kernel(const MergeRec M, double *__restrict__ J, int n, long group_stride, int accumulate,
+                                                    const int32_t *__restrict__ leaf_of_base, long j_stride)
 {
     __shared__ double tile[32][33];
     const long g = blockIdx.z / n;
@@ -450,7 +453,7 @@ __global__ void __launch_bounds__(256) merge_kernel(const MergeRec M, double *__
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     double sum[4] = {0.0, 0.0, 0.0, 0.0};
     bool have = false;
-    if (accumulate) {
+    if (accumulate && !leaf_of_base) {
         for (int q = 0; q < 4; ++q) {
             const int jc = j0 + ty + 8 * q, kc = k0 + tx;
             if (jc < n && kc < n) sum[q] = __builtin_nontemporal_load(&J[g * group_stride + ((long)ic * n + jc) * n + kc]);
@@ -482,19 +485,25 @@ __global__ void __launch_bounds__(256) merge_kernel(const MergeRec M, double *__
     }
     for (int q = 0; q < 4; ++q) {
         const int jc = j0 + ty + 8 * q, kc = k0 + tx;
-        if (jc < n && kc < n) __builtin_nontemporal_store(sum[q], &J[g * group_stride + ((long)ic * n + jc) * n + kc]);
+        if (jc >= n || kc >= n) continue;
+        const long b = ((long)ic * n + jc) * n + kc;
+        if (!leaf_of_base) __builtin_nontemporal_store(sum[q], &J[g * group_stride + b]);
+        else if (leaf_of_base[b] >= 0) { // += : the forest has already added the directions in whose box this cell lies
+            double *dst = &J[g * j_stride + leaf_of_base[b]];
+            *dst = accumulate ? *dst + sum[q] : sum[q];
+        }
     }
 }
 
 int launch_merge(const double *const *acc, const int *layout, int count, double *J, int n, int nnu, long group_stride,
-                 bool accumulate, hipStream_t stream)
+                 bool accumulate, hipStream_t stream, const int32_t *leaf_of_base, long j_stride)
 {
     if (count > 3 * kMaxAcc) return -1;
     MergeRec M;
     M.count = count;
     for (int a = 0; a < count; ++a) { M.acc[a] = acc[a]; M.layout[a] = layout[a]; }
     const dim3 grid((n + 31) / 32, (n + 31) / 32, n * nnu);
-    hipLaunchKernelGGL(merge_kernel, grid, dim3(256), 0, stream, M, J, n, group_stride, accumulate ? 1 : 0);
+    hipLaunchKernelGGL(merge_kernel, grid, dim3(256), 0, stream, M, J, n, group_stride, accumulate ? 1 : 0, leaf_of_base, j_stride);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -511,7 +520,7 @@ template <int NNU_SHIFT>
 __global__ void __launch_bounds__(256) amr_level_kernel(const AmrLevelRec A)
 {
     const int d = blockIdx.y;
-    const unsigned count = (unsigned)(A.first[d + 1] - A.first[d]);
+    const unsigned count = (unsigned)A.count[d];
     const unsigned nnu = (unsigned)A.nnu;
     const unsigned t = blockIdx.x * 256u + threadIdx.x;
     const unsigned e = NNU_SHIFT >= 0 ? t >> (NNU_SHIFT >= 0 ? NNU_SHIFT : 0) : t / nnu;
@@ -522,7 +531,8 @@ __global__ void __launch_bounds__(256) amr_level_kernel(const AmrLevelRec A)
     const int seg = R.seg, up = R.up, up2 = R.up2;
     const size_t at = (size_t)(unsigned)seg * nnu + nu;
     double I;
-    if (up < 0) I = A.uvb[nu];
+    if (up == -3) I = D.faces[(size_t)nu * A.face_stride + (size_t)R.at]; // a ray handed over by a brick (hybrid sweep)
+    else if (up < 0) I = A.uvb[nu];
     else {
         I = D.Iout[(size_t)(unsigned)up * nnu + nu];
         if (up2 >= 0) I = 0.5 * (I + D.Iout[(size_t)(unsigned)up2 * nnu + nu]);
@@ -547,20 +557,63 @@ __global__ void __launch_bounds__(256) amr_combine_kernel(const AmrLevelRec A, d
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int nnu = A.nnu;
     const bool pow2 = (nnu & (nnu - 1)) == 0; // wave-uniform: a shift instead of a 64-bit division
-    const long cell = pow2 ? tid >> (31 - __builtin_clz(nnu)) : tid / nnu;
-    const int nu = (int)(tid - cell * nnu);
-    if (cell >= A.ncell) return;
+    const long slot = pow2 ? tid >> (31 - __builtin_clz(nnu)) : tid / nnu;
+    const int nu = (int)(tid - slot * nnu);
+    if (slot >= (A.cells ? A.ncells : A.ncell)) return;
+    const long cell = A.cells ? A.cells[slot] : slot;
     double acc_J = zero_first ? 0.0 : J[(long)nu * A.ncell + cell];
     for (int d = 0; d < A.ndir; ++d) {
         const AmrDirRec &D = A.dir[d];
+        const int active = D.active[cell];
+        if (active & 4) continue; // outside this direction's region: a brick holds the cell's contribution
         double acc = __builtin_nontemporal_load(&D.mean[(3 * cell) * nnu + nu]);
         int nseg = 1;
-        const int active = D.active[cell];
         if (active & 1) { acc += __builtin_nontemporal_load(&D.mean[(3 * cell + 1) * nnu + nu]); ++nseg; }
         if (active & 2) { acc += __builtin_nontemporal_load(&D.mean[(3 * cell + 2) * nnu + nu]); ++nseg; }
         acc_J += ftte_cell_mean(acc, nseg, D.w);
     }
     J[(long)nu * A.ncell + cell] = acc_J;
+}
+
+// the rays that leave the forest's region: into the face buffers the bricks behind it read (hybrid sweep)
+__global__ void __launch_bounds__(256) amr_export_kernel(const AmrLevelRec A)
+{
+    const AmrDirRec &D = A.dir[blockIdx.y];
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nnu = A.nnu;
+    const long e = t / nnu;
+    const int nu = (int)(t - e * nnu);
+    if (e >= D.nexports) return;
+    const AmrExport X = D.exports[e];
+    D.faces[(size_t)nu * A.face_stride + (size_t)X.at] = D.Iout[(size_t)(unsigned)X.seg * nnu + nu];
+}
+
+int launch_amr_export(const AmrLevelRec &A, int64_t most, hipStream_t stream)
+{
+    if (most <= 0) return 0;
+    const dim3 grid((unsigned)((most * A.nnu + 255) / 256), (unsigned)A.ndir);
+    hipLaunchKernelGGL(amr_export_kernel, grid, dim3(256), 0, stream, A);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// kappa of the base cells of a refined cell array, storage order [ic][jc][kc], from the leaf-ordered array (a refined base cell,
+// which no brick reads, gets 0): what the bricks of the hybrid sweep march through
+__global__ void __launch_bounds__(256) base_cells_kernel(const double *__restrict__ leaf_values, const int32_t *__restrict__ leaf_of_base,
+                                                         double *__restrict__ base_values, long nbase, long ncell)
+{
+    const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbase) return;
+    const int32_t leaf = leaf_of_base[b];
+    const long g = blockIdx.y;
+    base_values[g * nbase + b] = leaf >= 0 ? leaf_values[g * ncell + leaf] : 0.0;
+}
+
+int launch_base_cells(const double *leaf_values, const int32_t *leaf_of_base, double *base_values, long nbase, long ncell, int nnu,
+                      hipStream_t stream)
+{
+    hipLaunchKernelGGL(base_cells_kernel, dim3((unsigned)((nbase + 255) / 256), (unsigned)nnu), dim3(256), 0, stream, leaf_values,
+                       leaf_of_base, base_values, nbase, ncell);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 // dst[cell][g] = src[g][cell]: the forest path reads all groups of a cell together, one 8 * nnu byte run per segment
@@ -588,10 +641,8 @@ int launch_cell_major(const double *src, double *dst, long ncell, int nnu, hipSt
 
 int launch_amr_level(const AmrLevelRec &A, hipStream_t stream)
 {
-    if (A.total <= 0) return 0;
-    int64_t most = 0;
-    for (int d = 0; d < A.ndir; ++d) most = A.first[d + 1] - A.first[d] > most ? A.first[d + 1] - A.first[d] : most;
-    const int64_t threads = most * A.nnu;
+    if (A.most <= 0) return 0;
+    const int64_t threads = A.most * A.nnu;
     if (threads >= ((int64_t)1 << 32)) return -1;
     const dim3 grid((unsigned)((threads + 255) / 256), (unsigned)A.ndir);
     switch (A.nnu) {
@@ -607,7 +658,8 @@ int launch_amr_level(const AmrLevelRec &A, hipStream_t stream)
 
 int launch_amr_combine(const AmrLevelRec &A, double *J, bool zero_first, hipStream_t stream)
 {
-    const long threads = A.ncell * A.nnu;
+    const long threads = (A.cells ? A.ncells : A.ncell) * A.nnu;
+    if (threads <= 0) return 0;
     hipLaunchKernelGGL(amr_combine_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, A, J,
                        zero_first ? 1 : 0);
     return hipGetLastError() == hipSuccess ? 0 : -2;

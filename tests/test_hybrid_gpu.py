@@ -1,0 +1,78 @@
+"""Hybrid sweep of a refined cell array (csrc/ftte_api.cpp: hybrid_sweep): the brick kernel outside a box around the refined cells,
+the segment forest inside it, rays handed over through the bricks' face buffers.  Against the oracle's tree sweep (the reference's
+setRaysRefined / findNeighbours / transport restated, pinned by the AMR goldens) with the device arithmetic -- bit for bit for a
+single direction, to summation order for several -- and against the forest path for the whole tree (option "hybrid" = 0)."""
+import numpy as np
+import pytest
+
+import _oracle as O
+import radiativetransfer_amd as rt
+from radiativetransfer_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+EPS = np.finfo(np.float64).eps
+SUM_RTOL = 64 * EPS
+
+
+def one_per_izone():
+    phi, theta, _ = O.healpix_directions(3)
+    pick = {}
+    for p, t in zip(phi, theta):
+        pick.setdefault(O.fold_direction(p, t)[2], (p, t))
+    return [pick[z] for z in range(1, 25)]
+
+
+def patch_case(n, blocks, depth, nnu, seed):
+    level = synthetic.refine_levels(n, blocks, depth=depth)
+    rho = synthetic.lognormal_density(len(level), seed=seed)
+    _, s_nu, uvb = synthetic.frequency_groups(nnu)
+    kappa = (0.15 * n) * s_nu[:, None] * rho[None, :] * (2.0 ** level)[None, :]
+    return level, kappa, uvb
+
+
+@pytest.mark.parametrize("n,blocks,depth", [
+    (64, [(30 + a, 31 + b, 33 + c) for a in range(3) for b in range(2) for c in range(4)], 1),   # one level, off-centre block
+    (72, [(40, 41, 20), (41, 41, 20), (40, 42, 21)], 2),                                           # two levels, ragged grid (72 = 64 + 8)
+])
+def test_hybrid_every_izone_bitwise(n, blocks, depth):
+    level, kappa, uvb = patch_case(n, blocks, depth, 2, seed=n)
+    with rt.DiffuseTransfer() as e:
+        e.set_grid(n, level, 1.0)
+        e.set_opacity(kappa)
+        for p, t in one_per_izone():
+            phi, theta, w = np.array([p]), np.array([t]), np.array([0.37])
+            J = e.transport(phi, theta, w, uvb)
+            ref = O.sweep_tree(n, level, kappa, 1.0, phi, theta, w, uvb, arith=O.ARITH_DEVICE)
+            assert np.array_equal(J, ref), f"izone {O.fold_direction(p, t)[2]}"
+        assert e.counter("forest_builds") >= 24          # the hybrid plan was taken (a restricted forest per direction list)
+
+
+def test_hybrid_equals_whole_tree_forest_path():
+    n = 64
+    blocks = [(28 + a, 30 + b, 31 + c) for a in range(4) for b in range(4) for c in range(3)]
+    level, kappa, uvb = patch_case(n, blocks, 1, 3, seed=5)
+    phi, theta, w = O.healpix_directions(2)
+    with rt.DiffuseTransfer() as e:
+        e.set_grid(n, level, 1.0)
+        e.set_opacity(kappa)
+        J_hybrid = e.transport(phi, theta, w, uvb)
+        J_again = e.transport(phi, theta, w, uvb)
+        e.set_option("hybrid", 0)
+        J_forest = e.transport(phi, theta, w, uvb)
+    assert np.array_equal(J_hybrid, J_again)
+    assert np.array_equal(J_forest, O.sweep_tree(n, level, kappa, 1.0, phi, theta, w, uvb, arith=O.ARITH_DEVICE))
+    assert np.allclose(J_hybrid, J_forest, rtol=SUM_RTOL, atol=0)
+    assert np.all(J_hybrid > 0) and np.all(J_hybrid <= uvb[:, None] * (1 + 1e-12))
+
+
+def test_small_trees_stay_on_the_forest_path(golden):
+    """Where the box around the refined cells takes up most of the grid (the AMR goldens: 8^3 and 6^3) nothing is left for the bricks:
+    the whole tree goes through the forest, bit for bit as before."""
+    g = golden("amr8_block_level1")
+    with rt.DiffuseTransfer() as e:
+        e.set_grid(int(g["n"]), g["level"], float(g["box"]))
+        e.set_opacity(g["kappa"])
+        J = e.transport(g["phi"], g["theta"], g["w"], g["uvb"])
+    assert np.array_equal(J, O.sweep_tree(int(g["n"]), g["level"], g["kappa"], float(g["box"]), g["phi"], g["theta"], g["w"], g["uvb"],
+                                          arith=O.ARITH_DEVICE))

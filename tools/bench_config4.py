@@ -14,7 +14,14 @@ import torch
 import radiativetransfer_amd as rt
 from radiativetransfer_amd import synthetic
 
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
+def flag(name, default=None):
+    if name in sys.argv:
+        return int(sys.argv[sys.argv.index(name) + 1])
+    return default
+
+
+skip = {sys.argv.index(k) + 1 for k in ("--chunk", "--group", "--hybrid", "--save") if k in sys.argv}
+args = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and i not in skip]
 n = int(args[0]) if args else 128
 q = n // 4
 blocks = [(n // 2 - q // 2 + a, n // 2 - q // 2 + b, n // 2 - q // 2 + c) for a in range(q) for b in range(q) for c in range(q)]
@@ -24,6 +31,9 @@ ncell = len(level)
 print(f"{ncell} leaves ({n}^3 base, central {q}^3 block refined once); levels built in {time.perf_counter() - t0:.1f} s", flush=True)
 eng = rt.StellarTransfer(device=0)
 t0 = time.perf_counter(); eng.set_grid(n, level, 3.0e22); print(f"set_grid (tree rebuild): {time.perf_counter() - t0:.2f} s", flush=True)
+for key in ("chunk", "group", "hybrid"):
+    if flag("--" + key) is not None:
+        eng.set_option(key, flag("--" + key))
 
 if "--no-diffuse" not in sys.argv:
     nnu, ndir = 8, 96
@@ -49,6 +59,8 @@ if "--no-diffuse" not in sys.argv:
     print("J range", float(J.min()), float(J.max()), "uvb", uvb[0], uvb[-1])
     del kappa, J
 
+if "--no-point" in sys.argv:
+    sys.exit(0)
 # ---- the point source
 box = 3.0e22
 pop = synthetic.stellar_population()
