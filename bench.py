@@ -17,9 +17,13 @@ log-normal opacity field (sigma_ln = 1, seed 12345), zero emissivity.  --ndir 19
 Multi-GPU is STRONG scaling: the same 96 (or 192) directions x 8 groups whatever N (north_star: "96 directions, 8
 frequency bins at 1/2/4/8 MI355X").  Ranks form a (frequency slice) x (direction slice) grid, frequency groups first
 (radiativetransfer_amd/distributed.py: Shard2D): at N = 2, 4, 8 with 8 groups every rank owns 8/N groups for all
-directions, its J_nu is complete where it is computed and the only exchange is an all-gather of the slices; where N does
-not divide the groups the directions are split as well and the partial J is all-reduced first.  The line reports the time
-of the sweep and of the collective separately (config.compute_ms_per_step, config.collective_ms_per_step).
+directions and its J_nu is complete where it is computed.  What follows the sweep in the reference's loop is the per-cell
+equilibrium update (equiSources.f90:3459-3677), which needs every J_nu of a cell and nothing of other cells, so the
+exchange that closes a step hands every rank ALL groups for 1/N of the cells (Shard2D.exchange: an all-to-all between the
+frequency slices, 1/N of J leaves each rank; where N does not divide the groups the directions are split as well and a
+reduce-scatter over the direction slices comes first).  --exchange gather assembles the whole J on every rank instead
+(all-gather, N-1 times the traffic).  The line reports the time of the sweep and of the collective separately
+(config.compute_ms_per_step, config.collective_ms_per_step).
 --weak restores round 1's mode (96 directions per GPU, 96 N in all, all-reduce).
 
 The JSON line also carries
@@ -56,6 +60,8 @@ def parse():
     ap.add_argument("--nnu", type=int, default=8)
     ap.add_argument("--ndir", type=int, default=96, help="directions in all (per GPU with --weak)")
     ap.add_argument("--weak", action="store_true", help="96 directions per GPU instead of 96 in all")
+    ap.add_argument("--exchange", choices=["slabs", "gather"], default="slabs",
+                    help="N > 1: every rank ends with all groups for 1/N of the cells (all-to-all), or with the whole J (all-gather)")
     ap.add_argument("--rows", type=int, default=0, help="rays per lane (4/8/16); 0 = library default")
     ap.add_argument("--slots", type=int, default=0, help="directions in flight per launch; 0 = library default")
     ap.add_argument("--waves", type=int, default=0, help="waves per SIMD the kernel is compiled for; 0 = library default")
@@ -229,7 +235,7 @@ def main():
     uvb = uvb_all[nu_lo:nu_hi].copy()
     kappa = torch.from_numpy(np.ascontiguousarray(kappa_host[nu_lo:nu_hi])).to(dev)
     J = torch.empty((nnu_local, ncell), dtype=torch.float64, device=dev)
-    J_full = torch.empty((nnu, ncell), dtype=torch.float64, device=dev) if (shard and shard.r_nu > 1) else None
+    J_full = torch.empty((nnu, ncell), dtype=torch.float64, device=dev) if (shard and shard.r_nu > 1 and a.exchange == "gather") else None
 
     eng = rt.DiffuseTransfer(device=local)
     eng.set_uniform_grid(n, box)
@@ -269,8 +275,10 @@ def main():
         if world > 1:
             if shard is None:
                 dist.all_reduce(J)
-            else:
+            elif a.exchange == "gather":
                 shard.combine(J, out=J_full)
+            else:
+                shard.exchange(J)
         if timed:
             ev[2].record()
 
@@ -311,7 +319,7 @@ def main():
     elif shard is None:
         parallelism = f"weak: {a.ndir} directions per rank, RCCL all-reduce of J"
     else:
-        parallelism = f"{world} ranks = " + shard.describe() + " (RCCL)"
+        parallelism = f"{world} ranks = " + shard.describe("combine" if a.exchange == "gather" else "exchange") + " (RCCL)"
     kernel = "ftte::brick_kernel (all stage launches of a sweep, two streams)" if len(eng.launch_records()) == 1 else "ftte::sweep_kernel"
     traffic = pmc_traffic(n, nnu) if (world == 1 and total_dirs == 96 and len(eng.launch_records()) == 1) else None
     avg_launch_ms = launch_ms / nlaunch if nlaunch else None

@@ -92,6 +92,7 @@ class Shard2D:
         nu_lo, nu_hi = sh.groups            # this rank's frequency groups
         phi, theta, w = sh.directions(phi, theta, w)
         J_full = sh.combine(J_local)        # J_local[nu_hi - nu_lo][ncell] -> J[nnu][ncell] on every rank
+        J_slab = sh.exchange(J_local)       # ... or -> J[nnu][cells lo:hi of sh.slab(ncell)]: all groups, 1/world of the cells
 
     combine = sum over the ranks that hold the same groups for other directions (all-reduce, only if directions are split),
     then all-gather of the group slices.  Works on any torch.distributed backend (nccl = RCCL on the GPUs, gloo in the
@@ -108,9 +109,13 @@ class Shard2D:
     def directions(self, phi, theta, weight):
         return shard_directions(phi, theta, weight, self.i_dir, self.r_dir)
 
-    def describe(self) -> str:
-        return (f"{self.r_nu} frequency slice(s) x {self.r_dir} direction slice(s): "
-                + ("no reduction, " if self.r_dir == 1 else "all-reduce over the direction slices, ")
+    def describe(self, mode: str = "combine") -> str:
+        head = f"{self.r_nu} frequency slice(s) x {self.r_dir} direction slice(s): "
+        if mode == "exchange":
+            return (head + ("no reduction, " if self.r_dir == 1 else "reduce-scatter over the direction slices, ")
+                    + ("nothing to exchange" if self.r_nu == 1 else "all-to-all between the frequency slices")
+                    + f" -> every rank holds all groups for 1/{self.world} of the cells")
+        return (head + ("no reduction, " if self.r_dir == 1 else "all-reduce over the direction slices, ")
                 + ("nothing to gather" if self.r_nu == 1 else "all-gather of the frequency slices"))
 
     def _groups(self):
@@ -129,6 +134,50 @@ class Shard2D:
             if i_dir == self.i_dir:
                 self._nu_group = g
         self._made = True
+
+    def slab(self, ncell: int) -> Tuple[int, int]:
+        """Cells [lo, hi) this rank holds after `exchange`: `world` slabs of equal length (the last one shorter), slab
+        index = rank."""
+        length = -(-ncell // self.world)
+        return min(self.rank * length, ncell), min((self.rank + 1) * length, ncell)
+
+    def exchange(self, J_local):
+        """J_local[groups of this rank][ncell] -> J[nnu][cells of this rank's slab]: every rank ends up with ALL frequency
+        groups, summed over all directions, for 1/world of the cells -- what a per-cell consumer (the equilibrium update,
+        equiSources.f90:3459-3677, needs every J_nu of a cell and nothing of other cells) wants, at 1/world of the
+        traffic of `combine`: a reduce-scatter over the direction slices (only if directions are split), then an
+        all-to-all between the frequency slices, every pair of ranks exchanging one (groups x slab) block directly --
+        the pattern xGMI's point-to-point links carry best.  The slab is slab(ncell); nothing is padded in the result."""
+        import torch
+        import torch.distributed as dist
+        nloc, ncell = J_local.shape
+        if self.world == 1:
+            return J_local
+        if self.nnu % self.r_nu:
+            raise ValueError("exchange needs equal frequency slices")
+        self._groups()
+        length = -(-ncell // self.world)
+        padded = length * self.world
+        src = J_local
+        if padded != ncell:
+            src = torch.zeros((nloc, padded), dtype=J_local.dtype, device=J_local.device)
+            src[:, :ncell] = J_local
+        # cells = [direction slice b][frequency slice a][length]: slab index b * r_nu + a = rank of (a, b)
+        if self.r_dir > 1:
+            blocks = src.view(nloc, self.r_dir, self.r_nu * length).permute(1, 0, 2).contiguous()
+            mine = torch.empty((nloc, self.r_nu * length), dtype=src.dtype, device=src.device)
+            dist.reduce_scatter_tensor(mine.view(-1), blocks.view(-1), op=dist.ReduceOp.SUM, group=self._dir_group)
+        else:
+            mine = src
+        if self.r_nu > 1:
+            send = mine.view(nloc, self.r_nu, length).permute(1, 0, 2).contiguous()
+            recv = torch.empty_like(send)
+            dist.all_to_all_single(recv.view(-1), send.view(-1), group=self._nu_group)
+            out = recv.view(self.nnu, length)       # frequency slices are contiguous ranges in slice order
+        else:
+            out = mine.view(self.nnu, length)
+        lo, hi = self.slab(ncell)
+        return out[:, :hi - lo]
 
     def combine(self, J_local, out=None):
         """J_local: torch tensor [groups of this rank][ncell] (partial over directions if they are split).  Returns

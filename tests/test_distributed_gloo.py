@@ -133,6 +133,8 @@ def _worker_2d(rank, world, port, n, nnu, out_dir, use_gpu):
             J_local = eng.transport(p, t, ww, uvb[lo:hi])
     else:
         J_local = O.sweep_uniform(n, kappa[lo:hi], box, p, t, ww, uvb[lo:hi], arith=O.ARITH_DEVICE)
+    J_slab = sh.exchange(torch.from_numpy(np.ascontiguousarray(J_local)).clone())
+    np.save(os.path.join(out_dir, f"slab{rank}.npy"), J_slab.numpy())
     J = sh.combine(torch.from_numpy(np.ascontiguousarray(J_local)))
     np.save(os.path.join(out_dir, f"J{rank}.npy"), J.numpy())
     if rank == 0:
@@ -157,6 +159,16 @@ def _check_2d(tmp_path, world, nnu, n, use_gpu):
         J = np.load(tmp_path / f"J{rank}.npy")
         assert J.shape == ref.shape
         assert np.allclose(J, ref, rtol=64 * np.finfo(float).eps, atol=0)
+    # ... or, after `exchange`, with all groups for its slab of the cells: the slabs tile the grid exactly once
+    from radiativetransfer_amd.distributed import Shard2D
+    covered = 0
+    for rank in range(world):
+        lo, hi = Shard2D(rank, world, nnu).slab(ref.shape[1])
+        slab = np.load(tmp_path / f"slab{rank}.npy")
+        assert slab.shape == (nnu, hi - lo) and lo == covered
+        assert np.allclose(slab, ref[:, lo:hi], rtol=64 * np.finfo(float).eps, atol=0)
+        covered = hi
+    assert covered == ref.shape[1]
     r_nu, r_dir = decompose(world, nnu)
     assert r_nu * r_dir == world and nnu % r_nu == 0
     return open(tmp_path / "layout.txt").read()
