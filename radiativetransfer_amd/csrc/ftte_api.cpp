@@ -179,12 +179,18 @@ struct ftte_ctx {
 
     // Hybrid sweep of a refined cell array: bricks outside a box around the refined cells, the segment forest inside it
     int hybrid = 1;                       // option: 0 = the whole tree through the forest path
+    int halves = 3;                       // option "pipelines": the hybrid sweep as this many independent pipelines on streams of their own (1..kMaxPipes)
+    static constexpr int kMaxPipes = 4;
+    hipEvent_t ev_combine[kMaxPipes] = {nullptr, nullptr, nullptr, nullptr}; // hybrid sweep: pipeline k's forest means are in J
     struct HybridPlan {
         bool valid = false, worthwhile = false;
         std::vector<double> key;          // box, chunk, group, share, then phi, theta, w
         BrickPlan bricks;                 // groups, tasks of the bricks outside the regions (phase 1, then phase 3)
-        size_t phase1_stages = 0;         // stage lists [0, phase1_stages) come before the forest pass, the rest after it
-        std::vector<size_t> stage_off;    // into bricks.tasks
+        size_t phase1_stages = 0;         // per half: stage lists [0, phase1_stages) come before the forest pass, the rest after it
+        size_t nlist = 0;                 // stage lists per half (2 x phase1_stages)
+        int nhalves = 1;                  // the groups of an accumulator stay in one half; halves share nothing but kappa and J
+        std::vector<std::vector<int>> half_dirs; // directions of each half, list order
+        std::vector<size_t> stage_off;    // into bricks.tasks: [half][list]
         int64_t brick_updates = 0;        // cell.direction updates the bricks perform (per frequency group)
         struct Dir { SegRec *rec = nullptr; uint8_t *active = nullptr; AmrExport *exports = nullptr; int64_t nexports = 0;
                      std::vector<int64_t> depth_off; };
@@ -756,47 +762,61 @@ struct ForestDirHost {
     const std::vector<int64_t> *depth_off;
 };
 
-// The forests of `dirs`, `batch` directions at a time: depth after depth (one launch per depth for the whole batch), then the
-// rays that leave the region (hybrid), then the per-leaf means into J in list order.  A.dir / A.count / A.begin are filled here:
-// the per-direction records and the per-depth tables live in device memory (a batch of 96 would not fit the kernel arguments).
-int run_forests(ftte_ctx *c, hipStream_t stream, const std::vector<ForestDirHost> &dirs, int batch, size_t per_dir, AmrLevelRec A,
-                double *J_dev, bool zero_first, bool time_batches)
+// A forest pass made ready: the per-direction records and the per-depth tables are in device memory (a batch of 96 would not
+// fit the kernel arguments), what is left is a list of launches.
+struct ForestRun {
+    struct Batch { int d0, nb; size_t table_at, most_at, maxdepth; int64_t most_exports; };
+    std::vector<Batch> batches;
+    std::vector<int64_t> most_of;
+    size_t dir_at = 0;
+};
+
+// Tables of several independent passes (`sets`: direction lists that may run side by side on different streams, set q using the
+// scratch slots from slot0[q] on), `batch` directions at a time each; built and uploaded in one go on `stream`.
+int prepare_forests(ftte_ctx *c, hipStream_t stream, const std::vector<std::vector<ForestDirHost>> &sets, const std::vector<int> &slot0,
+                    int batch, size_t per_dir, std::vector<ForestRun> *runs)
 {
-    const int ndir = (int)dirs.size(), nnu = c->nnu;
-    const int nbatch = (ndir + batch - 1) / batch;
     int rc;
-    // tables of every batch, built and uploaded in one go
-    std::vector<AmrDirRec> recs((size_t)ndir);
-    std::vector<size_t> maxdepth((size_t)nbatch, 0), table_at((size_t)nbatch, 0);
-    std::vector<int64_t> tables, most_of;
-    std::vector<size_t> most_at((size_t)nbatch, 0);
-    for (int b = 0; b < nbatch; ++b) {
-        const int d0 = b * batch, nb = std::min(batch, ndir - d0);
-        for (int t = 0; t < nb; ++t) {
-            const ForestDirHost &D = dirs[(size_t)(d0 + t)];
-            AmrDirRec &R = recs[(size_t)(d0 + t)];
-            std::memset(&R, 0, sizeof R);
-            R.rec = D.rec; R.active = D.active; R.w = D.w;
-            R.Iout = c->amr_Iout + per_dir * t;
-            R.mean = c->amr_mean + per_dir * t;
-            R.faces = D.faces; R.exports = D.exports; R.nexports = D.nexports;
-            maxdepth[(size_t)b] = std::max(maxdepth[(size_t)b], D.depth_off->size() - 1);
-        }
-        table_at[(size_t)b] = tables.size();
-        most_at[(size_t)b] = most_of.size();
-        for (size_t depth = 0; depth < maxdepth[(size_t)b]; ++depth) {
-            int64_t most = 0;
-            const size_t at = tables.size();
-            tables.resize(at + 2 * (size_t)nb, 0);
+    std::vector<AmrDirRec> recs;
+    std::vector<int64_t> tables;
+    runs->assign(sets.size(), ForestRun());
+    for (size_t q = 0; q < sets.size(); ++q) {
+        const std::vector<ForestDirHost> &dirs = sets[q];
+        ForestRun &R = (*runs)[q];
+        const int ndir = (int)dirs.size();
+        R.dir_at = recs.size();
+        for (int d0 = 0; d0 < ndir; d0 += batch) {
+            const int nb = std::min(batch, ndir - d0);
+            ForestRun::Batch B{d0, nb, 0, 0, 0, 0};
             for (int t = 0; t < nb; ++t) {
-                const std::vector<int64_t> &off = *dirs[(size_t)(d0 + t)].depth_off;
-                if (depth + 1 < off.size()) {
-                    tables[at + (size_t)t] = off[depth + 1] - off[depth];
-                    tables[at + (size_t)nb + (size_t)t] = off[depth];
-                    most = std::max(most, off[depth + 1] - off[depth]);
-                }
+                const ForestDirHost &D = dirs[(size_t)(d0 + t)];
+                AmrDirRec rec;
+                std::memset(&rec, 0, sizeof rec);
+                rec.rec = D.rec; rec.active = D.active; rec.w = D.w;
+                rec.Iout = c->amr_Iout + per_dir * (size_t)(slot0[q] + t);
+                rec.mean = c->amr_mean + per_dir * (size_t)(slot0[q] + t);
+                rec.faces = D.faces; rec.exports = D.exports; rec.nexports = D.nexports;
+                recs.push_back(rec);
+                B.maxdepth = std::max(B.maxdepth, D.depth_off->size() - 1);
+                B.most_exports = std::max(B.most_exports, D.nexports);
             }
-            most_of.push_back(most);
+            B.table_at = tables.size();
+            B.most_at = R.most_of.size();
+            for (size_t depth = 0; depth < B.maxdepth; ++depth) {
+                int64_t most = 0;
+                const size_t at = tables.size();
+                tables.resize(at + 2 * (size_t)nb, 0);
+                for (int t = 0; t < nb; ++t) {
+                    const std::vector<int64_t> &off = *dirs[(size_t)(d0 + t)].depth_off;
+                    if (depth + 1 < off.size()) {
+                        tables[at + (size_t)t] = off[depth + 1] - off[depth];
+                        tables[at + (size_t)nb + (size_t)t] = off[depth];
+                        most = std::max(most, off[depth + 1] - off[depth]);
+                    }
+                }
+                R.most_of.push_back(most);
+            }
+            R.batches.push_back(B);
         }
     }
     if ((rc = ensure(c, &c->d_amr_dirs, &c->d_amr_dirs_cap, recs.size()))) return rc;
@@ -804,31 +824,51 @@ int run_forests(ftte_ctx *c, hipStream_t stream, const std::vector<ForestDirHost
     if (!recs.empty()) FTTE_HIP(c, hipMemcpyAsync(c->d_amr_dirs, recs.data(), sizeof(AmrDirRec) * recs.size(), hipMemcpyHostToDevice, stream));
     if (!tables.empty()) FTTE_HIP(c, hipMemcpyAsync(c->d_amr_tables, tables.data(), sizeof(int64_t) * tables.size(), hipMemcpyHostToDevice, stream));
     FTTE_HIP(c, hipStreamSynchronize(stream)); // the host vectors leave scope; pageable copies are staged anyway
+    return FTTE_OK;
+}
 
-    for (int b = 0; b < nbatch; ++b) {
-        const int d0 = b * batch, nb = std::min(batch, ndir - d0);
-        A.dir = c->d_amr_dirs + d0;
-        A.ndir = nb;
+// One prepared pass on `stream`: depth after depth (one launch per depth for the whole batch), then the rays that leave the region
+// (hybrid), then the per-leaf means into J in list order.  The combine launches read-modify-write J: `before_combine` (if any) is
+// waited for in front of the first one, `after_combine` (if any) recorded behind the last, which is how two passes on two streams
+// keep a fixed order of additions.
+int launch_forests(ftte_ctx *c, hipStream_t stream, const ForestRun &R, AmrLevelRec A, double *J_dev, bool zero_first, bool time_batches,
+                   hipEvent_t before_combine, hipEvent_t after_combine)
+{
+    const int nnu = c->nnu;
+    for (size_t b = 0; b < R.batches.size(); ++b) {
+        const ForestRun::Batch &B = R.batches[b];
+        A.dir = c->d_amr_dirs + R.dir_at + (size_t)B.d0;
+        A.ndir = B.nb;
         if (time_batches) {
-            c->timing[(size_t)b].updates = (int64_t)nb * c->ncell * nnu;
-            FTTE_HIP(c, hipEventRecord(c->timing[(size_t)b].start, stream));
+            c->timing[b].updates = (int64_t)B.nb * c->ncell * nnu;
+            FTTE_HIP(c, hipEventRecord(c->timing[b].start, stream));
         }
-        for (size_t depth = 0; depth < maxdepth[(size_t)b]; ++depth) {
-            A.count = c->d_amr_tables + table_at[(size_t)b] + depth * 2 * (size_t)nb;
-            A.begin = A.count + nb;
-            A.most = most_of[most_at[(size_t)b] + depth];
+        for (size_t depth = 0; depth < B.maxdepth; ++depth) {
+            A.count = c->d_amr_tables + B.table_at + depth * 2 * (size_t)B.nb;
+            A.begin = A.count + B.nb;
+            A.most = R.most_of[B.most_at + depth];
             if (launch_amr_level(A, stream)) return fail(c, FTTE_ERR_NO_DEVICE, "forest level kernel launch failed");
         }
-        int64_t most_exports = 0;
-        for (int t = 0; t < nb; ++t) most_exports = std::max(most_exports, dirs[(size_t)(d0 + t)].nexports);
-        if (launch_amr_export(A, most_exports, stream)) return fail(c, FTTE_ERR_NO_DEVICE, "forest export kernel launch failed");
+        if (launch_amr_export(A, B.most_exports, stream)) return fail(c, FTTE_ERR_NO_DEVICE, "forest export kernel launch failed");
+        if (b == 0 && before_combine) FTTE_HIP(c, hipStreamWaitEvent(stream, before_combine, 0));
         if (launch_amr_combine(A, J_dev, zero_first && b == 0, stream)) return fail(c, FTTE_ERR_NO_DEVICE, "forest combine kernel launch failed");
         if (time_batches) {
-            FTTE_HIP(c, hipEventRecord(c->timing[(size_t)b].stop, stream));
-            c->timing_used = b + 1;
+            FTTE_HIP(c, hipEventRecord(c->timing[b].stop, stream));
+            c->timing_used = (int)b + 1;
         }
     }
+    if (after_combine) FTTE_HIP(c, hipEventRecord(after_combine, stream));
     return FTTE_OK;
+}
+
+// The forests of `dirs`, `batch` directions at a time (A.dir / A.count / A.begin are filled here).
+int run_forests(ftte_ctx *c, hipStream_t stream, const std::vector<ForestDirHost> &dirs, int batch, size_t per_dir, AmrLevelRec A,
+                double *J_dev, bool zero_first, bool time_batches)
+{
+    std::vector<ForestRun> runs;
+    int rc;
+    if ((rc = prepare_forests(c, stream, {dirs}, {0}, batch, per_dir, &runs))) return rc;
+    return launch_forests(c, stream, runs[0], A, J_dev, zero_first, time_batches, nullptr, nullptr);
 }
 
 // The sweep on a refined cell array: per-direction segment forests (ftte_amr.h), processed depth by depth.
@@ -1249,7 +1289,7 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
     // short bricks: the box is widened by one brick on every side, and what lies inside it costs several times a brick's bytes
     const int chunk = std::min(c->chunk > 0 ? c->chunk : 4, n);
     const int gmax = c->group > 0 ? c->group : (nnu >= 2 ? 3 : 2);
-    std::vector<double> key = {c->box, (double)chunk, (double)gmax, (double)c->share};
+    std::vector<double> key = {c->box, (double)chunk, (double)gmax, (double)c->share, (double)c->halves};
     key.insert(key.end(), phi, phi + ndir);
     key.insert(key.end(), theta, theta + ndir);
     key.insert(key.end(), w, w + ndir);
@@ -1274,16 +1314,45 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
     H.worthwhile = !P.groups.empty() && inside_bricks * 2 <= all_bricks; // else: the forest path for the whole tree
     if (!H.worthwhile) return FTTE_OK;
 
+    // Halves: the forests stream records at the memory system's rate while the brick stages of a 128^3 grid are short launches
+    // that leave most of it idle, so the sweep runs as two pipelines (bricks - forests - bricks each) on two streams.  What the
+    // groups of one accumulator write is ordered by their launches, so an accumulator's groups stay together; halves are
+    // balanced by direction count.
+    std::vector<int> half_of_group(P.groups.size(), 0);
+    H.nhalves = 1;
+    if (c->halves > 1 && P.nacc[0] + P.nacc[1] + P.nacc[2] >= 2) {
+        H.nhalves = std::min(c->halves, P.nacc[0] + P.nacc[1] + P.nacc[2]);
+        std::vector<int> weight(3 * (size_t)kMaxAcc, 0), order;
+        for (const auto &G : P.groups) weight[(size_t)G.layout * kMaxAcc + G.acc] += (int)G.dirs.size();
+        for (int a = 0; a < 3 * kMaxAcc; ++a) if (weight[(size_t)a]) order.push_back(a);
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return weight[(size_t)x] > weight[(size_t)y]; });
+        std::vector<int> half_of_acc(3 * (size_t)kMaxAcc, 0);
+        int load[ftte_ctx::kMaxPipes] = {0, 0, 0, 0};
+        for (int a : order) {
+            int h = 0;
+            for (int q = 1; q < H.nhalves; ++q) if (load[q] < load[h]) h = q;
+            half_of_acc[(size_t)a] = h; load[h] += weight[(size_t)a];
+        }
+        for (size_t g = 0; g < P.groups.size(); ++g) half_of_group[g] = half_of_acc[(size_t)P.groups[g].layout * kMaxAcc + P.groups[g].acc];
+    }
+    H.half_dirs.assign((size_t)H.nhalves, std::vector<int>());
+    {
+        std::vector<int> half_of_dir((size_t)ndir, 0);
+        for (size_t g = 0; g < P.groups.size(); ++g) for (int d : P.groups[g].dirs) half_of_dir[(size_t)d] = half_of_group[g];
+        for (int d = 0; d < ndir; ++d) H.half_dirs[(size_t)half_of_dir[(size_t)d]].push_back(d);
+    }
+
     // tasks: the bricks outside the boxes.  Phase 1: those that do not lie behind their group's box (no tile index at or beyond
     // the box's first one in all three directions); phase 3: the others.  Within a phase stage by stage as in a plain sweep.
     int max_offset = 0;
     for (const auto &G : P.groups) max_offset = std::max(max_offset, G.offset);
     const int per_phase = P.ntu + P.ntv + P.nti - 2 + max_offset;
-    const size_t nlist = 2 * (size_t)per_phase;
+    H.nlist = 2 * (size_t)per_phase;
+    const size_t nlist = (size_t)H.nhalves * H.nlist;
     H.phase1_stages = (size_t)per_phase;
-    auto list_of = [&](const Box &B, int tu, int tv, int ti, int offset) {
+    auto list_of = [&](size_t g, const Box &B, int tu, int tv, int ti, int offset) {
         const bool behind = B.any && tu >= B.lo[0] && tv >= B.lo[1] && ti >= B.lo[2];
-        return (size_t)(behind ? per_phase : 0) + (size_t)(tu + tv + ti + offset);
+        return (size_t)half_of_group[g] * H.nlist + (size_t)(behind ? per_phase : 0) + (size_t)(tu + tv + ti + offset);
     };
     auto in_box = [&](const Box &B, int tu, int tv, int ti) {
         return B.any && tu >= B.lo[0] && tu <= B.hi[0] && tv >= B.lo[1] && tv <= B.hi[1] && ti >= B.lo[2] && ti <= B.hi[2];
@@ -1304,7 +1373,7 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
             for (int tv = 0; tv < P.ntv; ++tv)
                 for (int tu = 0; tu < P.ntu; ++tu) {
                     if (in_box(box[g], tu, tv, ti)) continue;
-                    const size_t l = list_of(box[g], tu, tv, ti, G.offset);
+                    const size_t l = list_of(g, box[g], tu, tv, ti, G.offset);
                     ++H.stage_off[l + 1];
                     size_t &f = F[brick_of(G, tu, tv, ti)];
                     f = std::min(f, l);
@@ -1321,7 +1390,7 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
             for (int tv = 0; tv < P.ntv; ++tv)
                 for (int tu = 0; tu < P.ntu; ++tu) {
                     if (in_box(box[g], tu, tv, ti)) continue;
-                    const size_t l = list_of(box[g], tu, tv, ti, G.offset);
+                    const size_t l = list_of(g, box[g], tu, tv, ti, G.offset);
                     BrickTask T;
                     T.group = (int16_t)g; T.tu = (int16_t)tu; T.tv = (int16_t)tv;
                     T.ti = (int16_t)(ti | (l > F[brick_of(G, tu, tv, ti)] ? kBrickAccumulate : 0));
@@ -1508,49 +1577,87 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
     FTTE_HIP(c, hipMemsetAsync(J_dev, 0, sizeof(double) * (size_t)nnu * ncell, stream));
 
     static const ftte_consts kMath = FTTE_CONSTS_INIT;
-    auto brick_stages = [&](size_t from, size_t to) -> int {
+    auto brick_stages = [&](int half, size_t from, size_t to, hipStream_t q) -> int {
+        const size_t *off = &H.stage_off[(size_t)half * H.nlist];
         for (size_t l = from; l < to; ++l) {
-            if (H.stage_off[l + 1] == H.stage_off[l]) continue;
+            if (off[l + 1] == off[l]) continue;
             BrickLaunch L;
             std::memset(&L, 0, sizeof L);
             L.groups = c->d_bgroups;
-            L.tasks = c->d_btasks + H.stage_off[l];
+            L.tasks = c->d_btasks + off[l];
             L.uvb = c->d_uvb;
             L.group_stride = nbase;
             L.face_stride = P.face_elems;
             L.vface_off = P.vface_off; L.iface_off = P.iface_off;
-            L.n = n; L.ntasks = (int)(H.stage_off[l + 1] - H.stage_off[l]); L.nnu = nnu; L.nu0 = 0; L.chunk = P.chunk;
+            L.n = n; L.ntasks = (int)(off[l + 1] - off[l]); L.nnu = nnu; L.nu0 = 0; L.chunk = P.chunk;
             L.up = P.up; L.vp = P.vp; L.uw = P.uw; L.ut = P.ut; L.nslot = P.nslot;
             L.math = kMath;
-            const int lrc = launch_brick(L, P.max_dirs, c->brick_waves, stream);
+            const int lrc = launch_brick(L, P.max_dirs, c->brick_waves, q);
             if (lrc) return fail(c, lrc == -1 ? FTTE_ERR_ARG : FTTE_ERR_NO_DEVICE, "brick kernel launch failed");
         }
         return FTTE_OK;
     };
-    if ((rc = brick_stages(0, H.phase1_stages))) return rc;
 
-    // ---- the forests of the boxes, a batch of directions at a time, depth after depth
-    {
-        AmrLevelRec A;
-        std::memset(&A, 0, sizeof A);
-        A.kappa = c->amr_kappa; A.emis = nullptr;
-        A.group_stride = 1; A.cell_stride = nnu;
-        A.emit = 0;
-        A.uvb = c->d_uvb;
-        A.ncell = ncell; A.nnu = nnu;
-        A.cells = H.cells; A.ncells = H.ncells;
-        A.face_stride = P.face_elems;
-        A.math = kMath;
-        std::vector<ForestDirHost> dirs((size_t)ndir);
-        for (int d = 0; d < ndir; ++d) {
-            const ftte_ctx::HybridPlan::Dir &D = H.dirs[(size_t)d];
-            dirs[(size_t)d] = ForestDirHost{D.rec, D.active, P.dirs[(size_t)d].w, c->d_faces + (size_t)d * nnu * (size_t)P.face_elems, D.exports,
-                                            D.nexports, &D.depth_off};
+    // ---- per half: bricks not behind the boxes, the forests of the boxes (all directions of the half per depth launch), the
+    // bricks behind them.  The halves run side by side on two streams and meet only in J: the second half's means are added
+    // after the first half's (an event), the bricks' accumulators after both.
+    const int nh = (H.nhalves > 1 && batch >= ndir) ? H.nhalves : 1; // scratch for every direction at once, or one pipeline
+    hipStream_t qs[ftte_ctx::kMaxPipes] = {stream, stream, stream, stream};
+    if (nh > 1) {
+        while ((int)c->lane_stream.size() < nh - 1) {
+            hipStream_t q; hipEvent_t e;
+            FTTE_HIP(c, hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+            FTTE_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c->lane_stream.push_back(q); c->lane_done.push_back(e);
         }
-        if ((rc = run_forests(c, stream, dirs, batch, per_dir, A, J_dev, false, false))) return rc;
+        if (!c->ev_fork) FTTE_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        for (int r = 0; r < nh; ++r) {
+            if (!c->ev_combine[r]) FTTE_HIP(c, hipEventCreateWithFlags(&c->ev_combine[r], hipEventDisableTiming));
+            if (r) qs[r] = c->lane_stream[(size_t)r - 1];
+        }
     }
-
-    if ((rc = brick_stages(H.phase1_stages, H.stage_off.size() - 1))) return rc;
+    AmrLevelRec A;
+    std::memset(&A, 0, sizeof A);
+    A.kappa = c->amr_kappa; A.emis = nullptr;
+    A.group_stride = 1; A.cell_stride = nnu;
+    A.emit = 0;
+    A.uvb = c->d_uvb;
+    A.ncell = ncell; A.nnu = nnu;
+    A.cells = H.cells; A.ncells = H.ncells;
+    A.face_stride = P.face_elems;
+    A.math = kMath;
+    std::vector<ForestRun> runs;
+    {
+        std::vector<std::vector<ForestDirHost>> sets((size_t)nh);
+        std::vector<int> slot0((size_t)nh, 0);
+        for (int h = 0; h < H.nhalves; ++h) {
+            const int to = nh > 1 ? h : 0;
+            for (int d : H.half_dirs[(size_t)h]) {
+                const ftte_ctx::HybridPlan::Dir &D = H.dirs[(size_t)d];
+                sets[(size_t)to].push_back(ForestDirHost{D.rec, D.active, P.dirs[(size_t)d].w, c->d_faces + (size_t)d * nnu * (size_t)P.face_elems,
+                                                         D.exports, D.nexports, &D.depth_off});
+            }
+        }
+        for (int r = 1; r < nh; ++r) slot0[(size_t)r] = slot0[(size_t)r - 1] + (int)sets[(size_t)r - 1].size();
+        // one batch per pipeline when they run side by side (their scratch must not overlap), else `batch` directions at a time
+        if ((rc = prepare_forests(c, stream, sets, slot0, nh > 1 ? ndir : batch, per_dir, &runs))) return rc;
+    }
+    if (nh > 1) {
+        FTTE_HIP(c, hipEventRecord(c->ev_fork, stream));
+        for (int r = 1; r < nh; ++r) FTTE_HIP(c, hipStreamWaitEvent(qs[r], c->ev_fork, 0));
+    }
+    // issued phase by phase, alternating between the streams, so that none waits for the host to finish with the others
+    for (int h = 0; h < H.nhalves; ++h)
+        if ((rc = brick_stages(h, 0, H.phase1_stages, qs[nh > 1 ? h : 0]))) return rc;
+    for (int r = 0; r < nh; ++r)
+        if ((rc = launch_forests(c, qs[r], runs[(size_t)r], A, J_dev, false, false, (nh > 1 && r > 0) ? c->ev_combine[r - 1] : nullptr,
+                                 (nh > 1 && r + 1 < nh) ? c->ev_combine[r] : nullptr))) return rc;
+    for (int h = 0; h < H.nhalves; ++h)
+        if ((rc = brick_stages(h, H.phase1_stages, H.nlist, qs[nh > 1 ? h : 0]))) return rc;
+    for (int r = 1; r < nh; ++r) {
+        FTTE_HIP(c, hipEventRecord(c->lane_done[(size_t)r - 1], qs[r]));
+        FTTE_HIP(c, hipStreamWaitEvent(stream, c->lane_done[(size_t)r - 1], 0));
+    }
 
     // ---- J of the unrefined base cells += what the bricks stored (layout after layout, accumulator after accumulator)
     {
@@ -1733,6 +1840,7 @@ int ftte_destroy(ftte_ctx *c)
     for (auto &q : c->lane_stream) (void)hipStreamDestroy(q);
     for (auto &e : c->lane_done) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (auto &e : c->ev_combine) if (e) (void)hipEventDestroy(e);
     if (c->host_J_dev) (void)hipFree(c->host_J_dev);
     for (int q = 0; q < 2; ++q) {
         if (c->stage[q]) (void)hipHostFree(c->stage[q]);
@@ -1921,6 +2029,10 @@ int ftte_set_option(ftte_ctx *c, const char *key, int value)
     } else if (!std::strcmp(key, "hybrid")) {
         if (value != 0 && value != 1) return fail(c, FTTE_ERR_ARG, "hybrid must be 0 (a refined cell array goes through the forest path as a whole) or 1 (bricks outside a box around the refined cells)");
         c->hybrid = value;
+        c->hplan.valid = false;
+    } else if (!std::strcmp(key, "pipelines")) {
+        if (value < 1 || value > ftte_ctx::kMaxPipes) return fail(c, FTTE_ERR_ARG, "pipelines (independent bricks-forests-bricks sequences of the hybrid sweep, each on a stream of its own) must be 1..4");
+        c->halves = value;
         c->hplan.valid = false;
     } else if (!std::strcmp(key, "dataflow")) {
         if (value < 0 || value > 2) return fail(c, FTTE_ERR_ARG, "dataflow must be 0 (a launch per stage), 1 (one launch, bricks wait for each other) or 2 (the same with write-through stores)");

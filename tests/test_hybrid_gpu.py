@@ -66,6 +66,26 @@ def test_hybrid_equals_whole_tree_forest_path():
     assert np.all(J_hybrid > 0) and np.all(J_hybrid <= uvb[:, None] * (1 + 1e-12))
 
 
+@pytest.mark.parametrize("pipelines", [1, 2, 4])
+def test_hybrid_pipelines_agree(pipelines):
+    """The hybrid sweep runs as independent bricks - forests - bricks sequences on streams of their own (option "pipelines",
+    default 3), meeting only in J through a fixed chain of events: whatever their number, J is reproducible run to run and the
+    same to the rounding of the sum over directions."""
+    n = 64
+    blocks = [(20 + a, 30 + b, 31 + c) for a in range(3) for b in range(4) for c in range(3)]
+    level, kappa, uvb = patch_case(n, blocks, 1, 2, seed=11)
+    phi, theta, w = O.healpix_directions(2)
+    with rt.DiffuseTransfer() as e:
+        e.set_grid(n, level, 1.0)
+        e.set_opacity(kappa)
+        J_default = e.transport(phi, theta, w, uvb)
+        e.set_option("pipelines", pipelines)
+        J_a = e.transport(phi, theta, w, uvb)
+        J_b = e.transport(phi, theta, w, uvb)
+    assert np.array_equal(J_a, J_b)
+    assert np.allclose(J_a, J_default, rtol=SUM_RTOL, atol=0)
+
+
 def test_small_trees_stay_on_the_forest_path(golden):
     """Where the box around the refined cells takes up most of the grid (the AMR goldens: 8^3 and 6^3) nothing is left for the bricks:
     the whole tree goes through the forest, bit for bit as before."""
