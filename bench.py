@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--share", type=int, default=-1, help="bricks: accumulator sharing 0/1/2")
     ap.add_argument("--dataflow", type=int, default=-1, help="bricks: 1 one launch with flags (default where the grid allows), 0 a launch per stage")
     ap.add_argument("--lanes", type=int, default=0, help="bricks: streams the frequency groups are spread over")
+    ap.add_argument("--ldspad", type=int, default=0, help="diagnostic: extra dynamic LDS per workgroup (bytes), to cap residency")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=0, help="grid size of the CPU sample (default: --n)")
     return ap.parse_args()
@@ -261,6 +262,8 @@ def main():
         eng.set_option("lanes", a.lanes)
     if a.dataflow >= 0:
         eng.set_option("dataflow", a.dataflow)
+    if a.ldspad:
+        eng.set_option("ldspad", a.ldspad)
     stream = torch.cuda.current_stream().cuda_stream
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]

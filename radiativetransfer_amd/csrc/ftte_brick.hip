@@ -32,8 +32,8 @@ __device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirs
 //     over by the brick to the left, lane 63 hands its ray to the brick to the right), one whose next segment lies in
 //     the next row moves one register up (row 0 takes it from the brick below, the top row hands it on): every segment
 //     is computed by the lane that owns its cell, so a cell's mean needs no exchange and nothing is computed twice;
-//   * the ray state of the group's other directions waits in LDS (8 doubles per lane and direction) while one
-//     direction crosses the layer: one code path, no barrier, one wavefront per workgroup.
+//   * the ray state of the group's other directions waits in LDS (8 doubles per lane and direction, one slot fewer than
+//     there are directions) while one direction crosses the layer: one code path, no barrier, one wavefront per workgroup.
 // Faces in memory are rings over two chunks (a brick's consumers run exactly one stage later).
 // Arithmetic, segment order and the order of a cell's sum are those of the tile kernel (ftte_math.h): same bits.
 // ------------------------------------------------------------------------------------------------
@@ -137,7 +137,7 @@ __device__ __forceinline__ void brick_step(const ftte_consts &K, double (&cur)[k
 template <int WAVES, int EMIT, bool FLOW>
 __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
 {
-    extern __shared__ double state[]; // [direction][row][lane]
+    extern __shared__ double state[]; // [slot][row][lane]: the rays of the directions that are not in registers
     constexpr int R = kBrickRows;
     using cgroup = const __attribute__((address_space(4))) BrickGroup;
     using clayer = const __attribute__((address_space(4))) LayerRec;
@@ -222,11 +222,26 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
+    // The rays of one direction are in registers (`cur`), those of the group's other directions wait in LDS: ndir - 1 slots of
+    // 4 KB.  Layer i starts with direction p(i) = -(i - 1) mod ndir in registers and direction p + 1 + k in slot k, crosses
+    // p, p + 1, ..., each time taking the next direction out of its slot and parking the one just done there, and so ends with
+    // p - 1 = p(i + 1) in registers and p + k in slot k: the arrangement layer i + 1 starts from.  (A slot per direction would be
+    // simpler and costs a quarter of the wavefronts a CU can hold at three directions.)  The order in which a layer's
+    // directions are added into a cell's J follows p(i): fixed by the layer, the same for every chunk length.
+    int p0 = (ndir - (i0 - 1) % ndir) % ndir;
+    double cur[R];
     // rays entering the brick's bottom: the inflow, or what the chunk below left
-    for (int d = 0; d < ndir; ++d) {
+    {
+        gcdouble *f = (gcdouble *)(G->dir[p0].faces + fnu);
+#pragma unroll
+        for (int r = 0; r < R; ++r) cur[r] = has_i_in ? f[i_in + (long)r * up] : uvb;
+    }
+    for (int k = 0; k + 1 < ndir; ++k) {
+        int d = p0 + 1 + k;
+        d = d >= ndir ? d - ndir : d;
         gcdouble *f = (gcdouble *)(G->dir[d].faces + fnu);
 #pragma unroll
-        for (int r = 0; r < R; ++r) state[(d * R + r) * 64 + lane] = has_i_in ? f[i_in + (long)r * up] : uvb;
+        for (int r = 0; r < R; ++r) state[(k * R + r) * 64 + lane] = has_i_in ? f[i_in + (long)r * up] : uvb;
     }
 
     // the opacity of the brick's cells, one layer ahead of the layer being crossed
@@ -260,7 +275,17 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
                 if (EMIT) xs_next[r] = *(gcdouble *)(xbase + 8l * (i + 1) * si + row * row_bytes + off0);
             }
         }
-        for (int d = 0; d < ndir; ++d) {
+        for (int j = 0; j < ndir; ++j) {
+            int d = p0 + j;
+            d = d >= ndir ? d - ndir : d;
+            if (j) { // direction d leaves slot j - 1, the one just done takes its place
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const double parked = state[((j - 1) * R + r) * 64 + lane];
+                    state[((j - 1) * R + r) * 64 + lane] = cur[r];
+                    cur[r] = parked;
+                }
+            }
             clayer *rp = (clayer *)(G->dir[d].layers) + (i - 1);
             const double d0 = rp->dpath[0], d1 = rp->dpath[1], d2 = rp->dpath[2];
             const int rc = rp->info & 7;
@@ -270,9 +295,6 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
             gbyte *uout = has_u_out ? f + 8 * (u_out + (long)il * uw) : nullptr;
             gcbyte *vin = has_v_in ? (gcbyte *)f + 8 * (v_in + (long)il * up) : nullptr;
             gbyte *vout = has_v_out ? f + 8 * (v_out + (long)il * up) : nullptr;
-            double cur[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) cur[r] = state[(d * R + r) * 64 + lane];
             const bool third_first = rc == RC_THREE_U_SWAP || rc == RC_THREE_V_SWAP;
             switch (rc) {
             case RC_ONE: brick_step<RC_ONE, EMIT>(L.math, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through); break;
@@ -286,9 +308,8 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
                 brick_step<RC_THREE_V, EMIT>(L.math, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through);
                 break;
             }
-#pragma unroll
-            for (int r = 0; r < R; ++r) state[(d * R + r) * 64 + lane] = cur[r];
         }
+        p0 = p0 ? p0 - 1 : ndir - 1;
         // the group's contribution to J of this layer's cells: stored once, read only by the merge
         if (own_lane) {
 #pragma unroll
@@ -300,13 +321,16 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
         }
     }
 
-    if (has_i_out) {
-        for (int d = 0; d < ndir; ++d) {
+    if (has_i_out) { // p0 is in registers, p0 + 1 + k in slot k
+        for (int j = 0; j < ndir; ++j) {
+            int d = p0 + j;
+            d = d >= ndir ? d - ndir : d;
             gdouble *f = (gdouble *)(G->dir[d].faces + fnu);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                if (through) __hip_atomic_store((double *)&f[i_out + (long)r * up], state[(d * R + r) * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else f[i_out + (long)r * up] = state[(d * R + r) * 64 + lane];
+                const double leaving = j ? state[((j - 1) * R + r) * 64 + lane] : cur[r];
+                if (through) __hip_atomic_store((double *)&f[i_out + (long)r * up], leaving, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else f[i_out + (long)r * up] = leaving;
             }
         }
     }
@@ -485,7 +509,7 @@ int launch_brick(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stre
     if (L.ntasks <= 0) return 0;
     if (max_dirs < 1 || max_dirs > kBrickMaxDirs) return -1;
     const dim3 grid((unsigned)L.ntasks * (unsigned)L.nnu);
-    const size_t lds = (size_t)max_dirs * kBrickRows * 64 * sizeof(double);
+    const size_t lds = (size_t)(max_dirs - 1) * kBrickRows * 64 * sizeof(double) + (size_t)lds_pad(); // pad: diagnostic knob "ldspad"
     const bool flow = L.ticket != nullptr;
     // emission: the log-mean's own division and polynomials need more registers than three waves per SIMD leave
     if (L.emit == 1 && !flow) hipLaunchKernelGGL((brick_kernel<2, 1, false>), grid, dim3(64), lds, stream, L);

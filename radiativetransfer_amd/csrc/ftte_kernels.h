@@ -9,6 +9,7 @@ namespace ftte {
 
 // rows x stack: 4x{1,4,8}, 8x{1,2,4}, 16x1; waves: 2, 3, 4, 6
 void set_lds_pad(int bytes); // diagnostic: dynamic LDS per workgroup, to cap residency
+int lds_pad();
 int launch_sweep(const LaunchRec &L, int rows, int waves, int stack, int nnu, hipStream_t stream);
 // one stage of the cell-fixed brick sweep; max_dirs: directions of the launch's largest group (sizes the LDS); waves 2..4
 int launch_brick(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stream);

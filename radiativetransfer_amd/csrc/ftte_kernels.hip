@@ -347,6 +347,7 @@ __global__ void __launch_bounds__(64 * STACK, WAVES) sweep_kernel(const LaunchRe
 // WAVES = waves per SIMD the register allocation is held to (512 / WAVES VGPRs per lane)
 static int g_lds_pad = 0; // bytes of dynamic LDS per workgroup (diagnostic knob "ldspad")
 void set_lds_pad(int bytes) { g_lds_pad = bytes; }
+int lds_pad() { return g_lds_pad; }
 
 template <int ROWS, int STACK>
 static int launch_variant(const LaunchRec &L, int waves, dim3 grid, hipStream_t stream)
