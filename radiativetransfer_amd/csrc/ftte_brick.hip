@@ -63,7 +63,8 @@ template <int SHAPE, int EMIT>
 __device__ __forceinline__ void brick_step(const ftte_consts &K, double (&cur)[kBrickRows], const double (&kap)[kBrickRows],
                                            const double (&xs)[EMIT ? kBrickRows : 1],
                                            double (&Jacc)[kBrickRows], bool third_first, double d0, double d1, double d2,
-                                           double w, double uvb, gcbyte *uin, gbyte *uout, gcbyte *vin, gbyte *vout, int lane, bool through = false)
+                                           double w, double uvb, gcbyte *uin, gbyte *uout, gcbyte *vin, gbyte *vout, int lane, bool through = false,
+                                           bool same_launch = false)
 {
     constexpr bool HAS_U = SHAPE == RC_TWO_U || SHAPE == RC_THREE_U || SHAPE == RC_THREE_V;
     constexpr bool HAS_V = SHAPE == RC_TWO_V || SHAPE == RC_THREE_U || SHAPE == RC_THREE_V;
@@ -72,9 +73,15 @@ __device__ __forceinline__ void brick_step(const ftte_consts &K, double (&cur)[k
     if (HAS_U) {
 #pragma unroll
         for (int r = 0; r < kBrickRows; ++r) ui[r] = uvb;
-        if (uin) {
+        if (uin) { // one address for the whole wave
+            if (same_launch) { // dataflow: written by a brick of this launch, so not through the scalar cache
 #pragma unroll
-            for (int r = 0; r < kBrickRows; ++r) ui[r] = *(gcdouble *)(uin + 8 * r); // one address for the whole wave
+                for (int r = 0; r < kBrickRows; ++r) ui[r] = *(gcdouble *)(uin + 8 * r);
+            } else { // written by an earlier launch: scalar loads, the values wait in scalar registers
+                const __attribute__((address_space(4))) double *us = (const __attribute__((address_space(4))) double *)(unsigned long)uin;
+#pragma unroll
+                for (int r = 0; r < kBrickRows; ++r) ui[r] = us[r];
+            }
         }
     }
     if (HAS_V && vin) carry = *(gcdouble *)(vin + 8 * lane);
@@ -297,15 +304,15 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
             gbyte *vout = has_v_out ? f + 8 * (v_out + (long)il * up) : nullptr;
             const bool third_first = rc == RC_THREE_U_SWAP || rc == RC_THREE_V_SWAP;
             switch (rc) {
-            case RC_ONE: brick_step<RC_ONE, EMIT>(L.math, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through); break;
-            case RC_TWO_U: brick_step<RC_TWO_U, EMIT>(L.math, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through); break;
-            case RC_TWO_V: brick_step<RC_TWO_V, EMIT>(L.math, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through); break;
+            case RC_ONE: brick_step<RC_ONE, EMIT>(L.math, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW); break;
+            case RC_TWO_U: brick_step<RC_TWO_U, EMIT>(L.math, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW); break;
+            case RC_TWO_V: brick_step<RC_TWO_V, EMIT>(L.math, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW); break;
             case RC_THREE_U:
             case RC_THREE_U_SWAP:
-                brick_step<RC_THREE_U, EMIT>(L.math, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through);
+                brick_step<RC_THREE_U, EMIT>(L.math, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW);
                 break;
             default:
-                brick_step<RC_THREE_V, EMIT>(L.math, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through);
+                brick_step<RC_THREE_V, EMIT>(L.math, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW);
                 break;
             }
         }
