@@ -259,14 +259,14 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
         for (int r = 0; r < R; ++r) {
             const int row = (cv0 + r < n) ? cv0 + r : n;
             kap_next[r] = *(gcdouble *)(kplane + row * row_bytes + off0);
-            if (EMIT) xs_next[r] = *(gcdouble *)(xbase + 8l * i0 * si + row * row_bytes + off0);
+
         }
     }
     for (int i = i0; i <= i1; ++i) {
         const int il = i - i0;
         double kap[R], xs[EMIT ? R : 1], Jacc[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) { kap[r] = kap_next[r]; Jacc[r] = 0.0; if (EMIT) xs[r] = xs_next[r]; }
+        for (int r = 0; r < R; ++r) { kap[r] = kap_next[r]; Jacc[r] = 0.0; if (EMIT) { const int row = (cv0 + r < n) ? cv0 + r : n; xs[r] = *(gcdouble *)(xbase + 8l * i * si + row * row_bytes + off0); } }
         gbyte *jplane = jbase + 8l * i * si;
         if (accumulate && own_lane) { // what the groups before this one left in these cells
 #pragma unroll
@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
             for (int r = 0; r < R; ++r) {
                 const int row = (cv0 + r < n) ? cv0 + r : n;
                 kap_next[r] = *(gcdouble *)(kplane + row * row_bytes + off0);
-                if (EMIT) xs_next[r] = *(gcdouble *)(xbase + 8l * (i + 1) * si + row * row_bytes + off0);
+
             }
         }
         for (int j = 0; j < ndir; ++j) {
@@ -519,8 +519,8 @@ int launch_brick(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stre
     const size_t lds = (size_t)(max_dirs - 1) * kBrickRows * 64 * sizeof(double) + (size_t)lds_pad(); // pad: diagnostic knob "ldspad"
     const bool flow = L.ticket != nullptr;
     // emission: the log-mean's own division and polynomials need more registers than three waves per SIMD leave
-    if (L.emit == 1 && !flow) hipLaunchKernelGGL((brick_kernel<2, 1, false>), grid, dim3(64), lds, stream, L);
-    else if (L.emit == 2 && !flow) hipLaunchKernelGGL((brick_kernel<2, 2, false>), grid, dim3(64), lds, stream, L);
+    if (L.emit == 1 && !flow) hipLaunchKernelGGL((brick_kernel<3, 1, false>), grid, dim3(64), lds, stream, L);
+    else if (L.emit == 2 && !flow) hipLaunchKernelGGL((brick_kernel<3, 2, false>), grid, dim3(64), lds, stream, L);
     else if (L.emit) return -1; // the dataflow form is built without emission
     else if (flow) hipLaunchKernelGGL((brick_kernel<4, 0, true>), grid, dim3(64), lds, stream, L);
     else switch (waves) {
