@@ -108,6 +108,7 @@ struct ftte_ctx {
     int nnu = 0;
     double *kappa[3] = {nullptr, nullptr, nullptr}; // layouts 0,1,2
     bool kappa_ready[4] = {false, false, false, false}; // [3]: the cell-major copy of the forest path
+    int amr_kappa_form = 0;  // what that copy holds: 0 every leaf in cell-array order, 1 the leaves of the hybrid plan's list
     size_t kappa_cap = 0; // elements per layout buffer
 
     // emissivity (mode 1: the reference's eta) or source function (mode 2), same three layouts as kappa
@@ -980,9 +981,9 @@ int forest_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
     const bool cell_major = nnu <= 96;
     if (cell_major) {
     if ((rc = ensure(c, &c->amr_kappa, &c->amr_kappa_cap, (size_t)nnu * ncell))) return rc;
-    if (!c->kappa_ready[3]) {
+    if (!c->kappa_ready[3] || c->amr_kappa_form != 0) {
         if (launch_cell_major(c->kappa[0], c->amr_kappa, ncell, nnu, stream)) return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
-        c->kappa_ready[3] = true;
+        c->kappa_ready[3] = true; c->amr_kappa_form = 0;
     }
     if (c->emit_mode) {
         if ((rc = ensure(c, &c->amr_emis, &c->amr_emis_cap, (size_t)nnu * ncell))) return rc;
@@ -1400,19 +1401,22 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
                 }
     }
 
-    // the forests, restricted to the boxes: linked on the host a few directions at a time, uploaded, the host copy dropped
+    // The forests, restricted to the boxes: linked on the host a few directions at a time.  Once the leaves that lie in any box are
+    // known they are numbered by their place in that list, and segments (3 * place + piece), activity bytes, opacities and scratch
+    // use those numbers: what the forests need of memory follows the boxes, not the tree.
     std::vector<int> group_of((size_t)ndir, -1);
     for (size_t g = 0; g < P.groups.size(); ++g) for (int d : P.groups[g].dirs) group_of[(size_t)d] = (int)g;
     H.dirs.resize((size_t)ndir);
     const int64_t ncell = c->ncell;
     const int nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     std::vector<uint8_t> in_any((size_t)ncell, 0);
+    std::vector<std::vector<SegRec>> rec((size_t)ndir);
+    std::vector<std::vector<uint8_t>> active((size_t)ndir);  // per leaf, until the list is known
+    std::vector<std::vector<AmrExport>> exports((size_t)ndir);
     ++c->n_forest_builds;
     for (int d0 = 0; d0 < ndir; d0 += nthreads) {
         const int nbt = std::min(nthreads, ndir - d0);
         std::vector<AmrForest> F(nbt);
-        std::vector<std::vector<SegRec>> rec(nbt);
-        std::vector<std::vector<uint8_t>> active(nbt);
         std::vector<int> st(nbt, 0);
         std::vector<std::string> msg(nbt);
         std::vector<std::thread> pool;
@@ -1425,17 +1429,18 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
                 if (st[t]) return;
                 const AmrForest &f = F[t];
                 const size_t nact = f.order.size();
-                rec[t].resize(std::max<size_t>(nact, 1));
+                rec[(size_t)d].resize(std::max<size_t>(nact, 1));
                 for (size_t q = 0; q < nact; ++q) {
                     const int32_t sg = f.order[q];
-                    rec[t][q].seg = sg; rec[t][q].up = f.up[sg]; rec[t][q].up2 = f.up2[sg];
-                    rec[t][q].at = f.up[sg] == AmrForest::kImport ? f.import_at[sg] : 0;
-                    rec[t][q].dpath = f.dpath[sg];
+                    SegRec &R = rec[(size_t)d][q];
+                    R.seg = sg; R.up = f.up[sg]; R.up2 = f.up2[sg];
+                    R.at = f.up[sg] == AmrForest::kImport ? f.import_at[sg] : 0;
+                    R.dpath = f.dpath[sg];
                 }
-                active[t].resize((size_t)ncell);
+                active[(size_t)d].resize((size_t)ncell);
                 for (int64_t q = 0; q < ncell; ++q)
-                    active[t][q] = (uint8_t)((f.up[3 * q + 1] != AmrForest::kInactive ? 1 : 0) | (f.up[3 * q + 2] != AmrForest::kInactive ? 2 : 0) |
-                                             (f.inside[(size_t)q] ? 0 : 4));
+                    active[(size_t)d][(size_t)q] = (uint8_t)((f.up[3 * q + 1] != AmrForest::kInactive ? 1 : 0) | (f.up[3 * q + 2] != AmrForest::kInactive ? 2 : 0) |
+                                                             (f.inside[(size_t)q] ? 0 : 4));
             });
         for (auto &th : pool) th.join();
         for (int t = 0; t < nbt; ++t) {
@@ -1443,23 +1448,55 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
             ftte_ctx::HybridPlan::Dir &D = H.dirs[(size_t)(d0 + t)];
             D.depth_off = F[t].depth_off;
             D.nexports = (int64_t)F[t].exports.size();
+            static_assert(sizeof(AmrForest::Export) == sizeof(AmrExport), "export records: host and device forms must agree");
+            exports[(size_t)(d0 + t)].resize(F[t].exports.size());
+            if (!F[t].exports.empty()) std::memcpy(exports[(size_t)(d0 + t)].data(), F[t].exports.data(), sizeof(AmrExport) * F[t].exports.size());
             for (int64_t q = 0; q < ncell; ++q) in_any[(size_t)q] |= F[t].inside[(size_t)q];
-            FTTE_HIP(c, hipMalloc((void **)&D.rec, sizeof(SegRec) * rec[t].size()));
-            FTTE_HIP(c, hipMalloc((void **)&D.active, (size_t)ncell));
-            FTTE_HIP(c, hipMalloc((void **)&D.exports, sizeof(AmrExport) * std::max<size_t>(F[t].exports.size(), 1)));
-            FTTE_HIP(c, hipMemcpy(D.rec, rec[t].data(), sizeof(SegRec) * rec[t].size(), hipMemcpyHostToDevice));
-            FTTE_HIP(c, hipMemcpy(D.active, active[t].data(), (size_t)ncell, hipMemcpyHostToDevice));
-            if (!F[t].exports.empty())
-                FTTE_HIP(c, hipMemcpy(D.exports, F[t].exports.data(), sizeof(AmrExport) * F[t].exports.size(), hipMemcpyHostToDevice));
         }
     }
+    std::vector<int32_t> cells, place((size_t)ncell, -1);
+    for (int64_t q = 0; q < ncell; ++q)
+        if (in_any[(size_t)q]) { place[(size_t)q] = (int32_t)cells.size(); cells.push_back((int32_t)q); }
+    H.ncells = (int64_t)cells.size();
+    FTTE_HIP(c, hipMalloc((void **)&H.cells, sizeof(int32_t) * std::max<size_t>(cells.size(), 1)));
+    if (!cells.empty()) FTTE_HIP(c, hipMemcpy(H.cells, cells.data(), sizeof(int32_t) * cells.size(), hipMemcpyHostToDevice));
     {
-        std::vector<int32_t> cells;
-        for (int64_t q = 0; q < ncell; ++q) if (in_any[(size_t)q]) cells.push_back((int32_t)q);
-        H.ncells = (int64_t)cells.size();
-        FTTE_HIP(c, hipMalloc((void **)&H.cells, sizeof(int32_t) * std::max<size_t>(cells.size(), 1)));
-        if (!cells.empty()) FTTE_HIP(c, hipMemcpy(H.cells, cells.data(), sizeof(int32_t) * cells.size(), hipMemcpyHostToDevice));
+        auto renumber = [&](int32_t sg) { return sg < 0 ? sg : 3 * place[(size_t)(sg / 3)] + sg % 3; }; // negative: inflow / import marks
+        std::vector<int> bad((size_t)ndir, 0);
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; ++t)
+            pool.emplace_back([&, t] {
+                std::vector<uint8_t> compact(cells.size());
+                for (int d = t; d < ndir; d += nthreads) {
+                    for (SegRec &R : rec[(size_t)d]) {
+                        if (place[(size_t)(R.seg / 3)] < 0 || (R.up >= 0 && place[(size_t)(R.up / 3)] < 0) || (R.up2 >= 0 && place[(size_t)(R.up2 / 3)] < 0)) { bad[(size_t)d] = 1; break; }
+                        R.seg = renumber(R.seg); R.up = renumber(R.up); R.up2 = renumber(R.up2);
+                    }
+                    for (AmrExport &X : exports[(size_t)d]) {
+                        if (place[(size_t)(X.seg / 3)] < 0) { bad[(size_t)d] = 1; break; }
+                        X.seg = renumber(X.seg);
+                    }
+                    for (size_t q = 0; q < cells.size(); ++q) compact[q] = active[(size_t)d][(size_t)cells[q]];
+                    active[(size_t)d].assign(compact.begin(), compact.end());
+                }
+            });
+        for (auto &th : pool) th.join();
+        for (int d = 0; d < ndir; ++d)
+            if (bad[(size_t)d]) { free_hybrid(c); return fail(c, FTTE_ERR_STATE, "hybrid plan: a forest segment lies outside every box"); }
     }
+    for (int d = 0; d < ndir; ++d) {
+        ftte_ctx::HybridPlan::Dir &D = H.dirs[(size_t)d];
+        FTTE_HIP(c, hipMalloc((void **)&D.rec, sizeof(SegRec) * rec[(size_t)d].size()));
+        FTTE_HIP(c, hipMalloc((void **)&D.active, std::max<size_t>(active[(size_t)d].size(), 1)));
+        FTTE_HIP(c, hipMalloc((void **)&D.exports, sizeof(AmrExport) * std::max<size_t>(exports[(size_t)d].size(), 1)));
+        FTTE_HIP(c, hipMemcpy(D.rec, rec[(size_t)d].data(), sizeof(SegRec) * rec[(size_t)d].size(), hipMemcpyHostToDevice));
+        if (!active[(size_t)d].empty()) FTTE_HIP(c, hipMemcpy(D.active, active[(size_t)d].data(), active[(size_t)d].size(), hipMemcpyHostToDevice));
+        if (!exports[(size_t)d].empty())
+            FTTE_HIP(c, hipMemcpy(D.exports, exports[(size_t)d].data(), sizeof(AmrExport) * exports[(size_t)d].size(), hipMemcpyHostToDevice));
+        std::vector<SegRec>().swap(rec[(size_t)d]);
+        std::vector<uint8_t>().swap(active[(size_t)d]);
+    }
+    c->kappa_ready[3] = false; // the forests' copy of the opacities follows the list
     H.uploaded = false;
     return FTTE_OK;
 }
@@ -1477,7 +1514,7 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
     if (!H.worthwhile) return FTTE_OK; // the caller takes the forest path for the whole tree
     BrickPlan &P = H.bricks;
     const int n = c->n, nnu = c->nnu;
-    const int64_t ncell = c->ncell, nbase = (int64_t)n * n * n, nseg = 3 * ncell;
+    const int64_t ncell = c->ncell, nbase = (int64_t)n * n * n;
 
     // ---- device state that depends on the tree only
     if (!c->d_leaf_of_base) {
@@ -1534,8 +1571,8 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
     if ((rc = ensure(c, &c->d_uvb, &c->d_uvb_cap, (size_t)nnu))) return rc;
     FTTE_HIP(c, hipMemcpy(c->d_uvb, uvb, sizeof(double) * nnu, hipMemcpyHostToDevice));
 
-    // forest scratch: as forest_sweep
-    const size_t per_dir = (size_t)nseg * nnu;
+    // forest scratch: as forest_sweep, for the leaves of the plan's list only
+    const size_t per_dir = (size_t)3 * (size_t)std::max<int64_t>(H.ncells, 1) * nnu;
     int batch = std::max(1, std::min(ndir, kAmrBatch));
     if (c->amr_scratch_cap < per_dir * (size_t)batch) {
         if (c->amr_Iout) { FTTE_HIP(c, hipFree(c->amr_Iout)); c->amr_Iout = nullptr; }
@@ -1549,10 +1586,10 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
         c->amr_scratch_cap = per_dir * (size_t)batch;
     } else batch = (int)std::min<size_t>((size_t)kAmrBatch, c->amr_scratch_cap / per_dir);
     if (nnu > 96) return FTTE_OK; // the cell-major copy of kappa is what the level kernel reads here: leave it to the forest path
-    if ((rc = ensure(c, &c->amr_kappa, &c->amr_kappa_cap, (size_t)nnu * ncell))) return rc;
-    if (!c->kappa_ready[3]) {
-        if (launch_cell_major(c->kappa[0], c->amr_kappa, ncell, nnu, stream)) return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
-        c->kappa_ready[3] = true;
+    if ((rc = ensure(c, &c->amr_kappa, &c->amr_kappa_cap, (size_t)nnu * (size_t)std::max<int64_t>(H.ncells, 1)))) return rc;
+    if (!c->kappa_ready[3] || c->amr_kappa_form != 1) {
+        if (launch_cell_major(c->kappa[0], c->amr_kappa, ncell, nnu, stream, H.cells, (long)H.ncells)) return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
+        c->kappa_ready[3] = true; c->amr_kappa_form = 1;
     }
 
     while (c->timing.size() < 1) {

@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
     }
 
     // the opacity of the brick's cells, one layer ahead of the layer being crossed
-    double kap_next[R], xs_next[EMIT ? R : 1];
+    double kap_next[R];
     {
         gcbyte *kplane = kbase + 8l * i0 * si;
 #pragma unroll

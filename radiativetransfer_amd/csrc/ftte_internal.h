@@ -164,8 +164,9 @@ struct AmrLevelRec {
     const double *kappa, *uvb, *emis; // element (group g, cell c) at g * group_stride + c * cell_stride
     int64_t group_stride, cell_stride;
     int64_t ncell;
-    const int32_t *cells;    // hybrid sweep: the leaves that lie in the region of at least one direction (the combine visits only
-    int64_t ncells;          // these), else nullptr: every leaf
+    const int32_t *cells;    // hybrid sweep: the leaves that lie in the region of at least one direction, else nullptr: every leaf.
+    int64_t ncells;          // With a list, segments, opacities, activity bytes and scratch are numbered by POSITION in the list
+                             // (segment 3 * position + piece): plan and scratch memory follow the regions, not the tree
     int64_t face_stride;     // elements between frequency groups in a direction's face block
     int32_t ndir, nnu, emit;
     ftte_consts math;

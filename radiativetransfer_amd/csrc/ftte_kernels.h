@@ -28,7 +28,7 @@ int launch_opacity(const double *HI, const double *HeI, const double *HeII, cons
                    int nnu, hipStream_t stream);
 
 // refined cell arrays: one depth of the segment forest of up to kAmrBatch directions; then the per-leaf means into J
-int launch_cell_major(const double *src, double *dst, long ncell, int nnu, hipStream_t stream);
+int launch_cell_major(const double *src, double *dst, long ncell, int nnu, hipStream_t stream, const int32_t *cells = nullptr, long count = 0);
 int launch_amr_level(const AmrLevelRec &A, hipStream_t stream);
 int launch_amr_combine(const AmrLevelRec &A, double *J, bool zero_first, hipStream_t stream);
 

@@ -561,16 +561,16 @@ __global__ void __launch_bounds__(256) amr_combine_kernel(const AmrLevelRec A, d
     const long slot = pow2 ? tid >> (31 - __builtin_clz(nnu)) : tid / nnu;
     const int nu = (int)(tid - slot * nnu);
     if (slot >= (A.cells ? A.ncells : A.ncell)) return;
-    const long cell = A.cells ? A.cells[slot] : slot;
+    const long cell = A.cells ? A.cells[slot] : slot; // where the leaf sits in J; everything of the forest is numbered by `slot`
     double acc_J = zero_first ? 0.0 : J[(long)nu * A.ncell + cell];
     for (int d = 0; d < A.ndir; ++d) {
         const AmrDirRec &D = A.dir[d];
-        const int active = D.active[cell];
+        const int active = D.active[slot];
         if (active & 4) continue; // outside this direction's region: a brick holds the cell's contribution
-        double acc = __builtin_nontemporal_load(&D.mean[(3 * cell) * nnu + nu]);
+        double acc = __builtin_nontemporal_load(&D.mean[(3 * slot) * nnu + nu]);
         int nseg = 1;
-        if (active & 1) { acc += __builtin_nontemporal_load(&D.mean[(3 * cell + 1) * nnu + nu]); ++nseg; }
-        if (active & 2) { acc += __builtin_nontemporal_load(&D.mean[(3 * cell + 2) * nnu + nu]); ++nseg; }
+        if (active & 1) { acc += __builtin_nontemporal_load(&D.mean[(3 * slot + 1) * nnu + nu]); ++nseg; }
+        if (active & 2) { acc += __builtin_nontemporal_load(&D.mean[(3 * slot + 2) * nnu + nu]); ++nseg; }
         acc_J += ftte_cell_mean(acc, nseg, D.w);
     }
     J[(long)nu * A.ncell + cell] = acc_J;
@@ -617,26 +617,30 @@ int launch_base_cells(const double *leaf_values, const int32_t *leaf_of_base, do
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-// dst[cell][g] = src[g][cell]: the forest path reads all groups of a cell together, one 8 * nnu byte run per segment
-__global__ void __launch_bounds__(256) cell_major_kernel(const double *__restrict__ src, double *__restrict__ dst, long ncell, int nnu)
+// dst[cell][g] = src[g][cell]: the forest path reads all groups of a cell together, one 8 * nnu byte run per segment.
+// cells != nullptr: dst[position][g] = src[g][cells[position]] for the `count` leaves of the list (src has `ncell` per group)
+__global__ void __launch_bounds__(256) cell_major_kernel(const double *__restrict__ src, double *__restrict__ dst, long ncell, int nnu,
+                                                         const int32_t *__restrict__ cells, long count)
 {
     extern __shared__ double tile[]; // [nnu][64 + 1]
     const long c0 = (long)blockIdx.x * 64;
     for (int i = threadIdx.x; i < nnu * 64; i += 256) {
         const int g = i >> 6, c = i & 63;
-        if (c0 + c < ncell) tile[g * 65 + c] = src[(long)g * ncell + c0 + c];
+        if (c0 + c < count) tile[g * 65 + c] = src[(long)g * ncell + (cells ? (long)cells[c0 + c] : c0 + c)];
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nnu * 64; i += 256) {
         const int c = i / nnu, g = i - c * nnu;
-        if (c0 + c < ncell) dst[(c0 + c) * nnu + g] = tile[g * 65 + c];
+        if (c0 + c < count) dst[(c0 + c) * nnu + g] = tile[g * 65 + c];
     }
 }
 
-int launch_cell_major(const double *src, double *dst, long ncell, int nnu, hipStream_t stream)
+int launch_cell_major(const double *src, double *dst, long ncell, int nnu, hipStream_t stream, const int32_t *cells, long count)
 {
-    hipLaunchKernelGGL(cell_major_kernel, dim3((unsigned)((ncell + 63) / 64)), dim3(256), (size_t)nnu * 65 * sizeof(double), stream, src, dst,
-                       ncell, nnu);
+    if (!cells) count = ncell;
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(cell_major_kernel, dim3((unsigned)((count + 63) / 64)), dim3(256), (size_t)nnu * 65 * sizeof(double), stream, src, dst,
+                       ncell, nnu, cells, count);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
