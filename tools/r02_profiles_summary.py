@@ -69,6 +69,10 @@ if sq:
     rec["valu_busy_fraction"] = sq["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / cycles
     rec["mean_waves_per_simd"] = sq["SQ_WAVE_CYCLES"] * 4 / 1024 / cycles
     rec["gpu_cycles_per_sweep"] = cycles
+    if sq.get("SQ_WAVE_CYCLES"):  # of the time a wavefront is resident: waiting on a counter, waiting to issue, issuing
+        rec["wave_time_in_waitcnt"] = sq.get("SQ_WAIT_ANY", 0.0) / sq["SQ_WAVE_CYCLES"]
+        rec["wave_time_waiting_to_issue"] = sq.get("SQ_WAIT_INST_ANY", 0.0) / sq["SQ_WAVE_CYCLES"]
+        rec["wave_time_issuing"] = sq.get("SQ_ACTIVE_INST_ANY", 0.0) / sq["SQ_WAVE_CYCLES"]
 if sq2:
     rec["sq2_per_sweep"] = sq2
     rec["salu_instructions_per_update"] = sq2.get("SQ_INSTS_SALU", 0) * 64 / updates
