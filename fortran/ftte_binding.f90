@@ -74,6 +74,16 @@ module ftte_binding
        real(c_double), intent(out) :: J(*)      ! (ncell, nnu)
      end function ftte_diffuse_sweep
 
+     ! ftte_set_opacity + ftte_diffuse_sweep in one call; on a uniform grid the groups cross PCIe and are swept in overlapping lanes
+     integer(c_int) function ftte_diffuse_iteration(ctx, nnu, kappa, ndir, phi, theta, w, uvb, J) bind(C, name='ftte_diffuse_iteration')
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: nnu, ndir
+       real(c_double), intent(in) :: kappa(*)   ! (ncell, nnu)
+       real(c_double), intent(in) :: phi(*), theta(*), w(*), uvb(*)
+       real(c_double), intent(out) :: J(*)      ! (ncell, nnu)
+     end function ftte_diffuse_iteration
+
      ! pins a host array the caller keeps (kappa, J): moved by DMA without a staging copy while it stays registered
      integer(c_int) function ftte_host_register(ctx, ptr, bytes) bind(C, name='ftte_host_register')
        import :: c_ptr, c_int, c_size_t

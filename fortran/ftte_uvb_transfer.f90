@@ -76,8 +76,7 @@ contains
     uvb = (/ uvb1, uvb2, uvb3 /)
 
     call ftteCheck(ctx, ftte_set_grid(ctx, nx, nx, nx, ncell, lev, physicalBoxSize), 'ftte_set_grid')
-    call ftteCheck(ctx, ftte_set_opacity(ctx, 3, kap), 'ftte_set_opacity')
-    call ftteCheck(ctx, ftte_diffuse_sweep(ctx, ndir, phi, theta, w, uvb, Jflat), 'ftte_diffuse_sweep')
+    call ftteCheck(ctx, ftte_diffuse_iteration(ctx, 3, kap, ndir, phi, theta, w, uvb, Jflat), 'ftte_diffuse_iteration')
 
     cursor = 0
     do i = 1, nx

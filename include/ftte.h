@@ -112,6 +112,13 @@ int ftte_set_source_function_device(ftte_ctx *ctx, const double *S_dev);
  * definitionsModule.f90:55-56), J[nnu][ncell] host memory, overwritten. */
 int ftte_diffuse_sweep(ftte_ctx *ctx, int ndir, const double *phi, const double *theta, const double *w,
                        const double *uvb, double *J);
+/* ftte_set_opacity + ftte_diffuse_sweep in one call (the pair the drop-in for the reference's runUVBTransfer block makes on
+ * every outer iteration), and faster than the two: on a uniform grid the frequency groups travel in lanes --
+ * the first lane is swept while the second one's opacities are still crossing PCIe, and its J goes back while the second is
+ * swept.  Same J as the two calls; refined cell arrays and the options that exclude lanes take the two calls internally.
+ * kappa[nnu][ncell], J[nnu][ncell] host memory (pageable, or registered with ftte_host_register: DMA in place). */
+int ftte_diffuse_iteration(ftte_ctx *ctx, int nnu, const double *kappa, int ndir, const double *phi, const double *theta,
+                           const double *w, const double *uvb, double *J);
 /* Same with J in device memory.  `stream` is a hipStream_t; NULL = the context's own stream, a blocking stream,
  * i.e. one that is implicitly ordered with the legacy default stream.  The call is asynchronous with respect to the
  * host, ordered on that stream. */

@@ -46,6 +46,7 @@ SIGNATURES = {
     "ftte_set_source_function": (C.c_int, [_vp, _dp]),
     "ftte_set_source_function_device": (C.c_int, [_vp, _vp]),
     "ftte_diffuse_sweep": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, _dp]),
+    "ftte_diffuse_iteration": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, _dp, _dp, _dp, _dp]),
     "ftte_diffuse_sweep_device": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, _vp, _vp]),
     "ftte_stellar_beta_table": (C.c_int, [_vp, _dp, C.c_int, _dp, C.c_int, C.c_int, _dp, C.c_int, C.c_double, C.c_int,
                                           C.c_double, _dp]),

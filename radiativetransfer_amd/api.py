@@ -207,6 +207,20 @@ class DiffuseTransfer:
         self._ok(self._lib.ftte_diffuse_sweep(self._ctx, len(phi), _dp(phi), _dp(theta), _dp(weight), _dp(uvb), _dp(J)))
         return J
 
+    def iterate_into(self, kappa: np.ndarray, phi, theta, weight, uvb, J: np.ndarray) -> np.ndarray:
+        """set_opacity(kappa) + transport_into(..., J) as one call (ftte_diffuse_iteration): on a uniform grid the frequency
+        groups cross PCIe and are swept in overlapping lanes."""
+        phi, theta, weight, uvb = map(_f64, (phi, theta, weight, uvb))
+        kappa = _f64(kappa)
+        if kappa.ndim != 2 or kappa.shape[1] != self.ncell:
+            raise ValueError("kappa must have shape [nnu][ncell]")
+        if J.dtype != np.float64 or not J.flags.c_contiguous or J.shape != kappa.shape:
+            raise ValueError("J must be a C-contiguous float64 array of kappa's shape")
+        self._ok(self._lib.ftte_diffuse_iteration(self._ctx, kappa.shape[0], _dp(kappa), len(phi), _dp(phi), _dp(theta), _dp(weight),
+                                                  _dp(uvb), _dp(J)))
+        self.nnu = kappa.shape[0]
+        return J
+
     def host_register(self, a: np.ndarray):
         """Pin a host array the caller keeps (kappa, J): the library then moves it by DMA without a staging copy."""
         self._ok(self._lib.ftte_host_register(self._ctx, C.c_void_p(a.ctypes.data), a.nbytes))

@@ -125,6 +125,8 @@ struct ftte_ctx {
     // (sweep_kernel)
     int engine = 0, chunk = 0, group = 0, brick_waves = 4, share = 2, team = 0, lanes = 2; // chunk, group: 0 = by the parallelism (build_brick_plan)
     std::vector<hipStream_t> lane_stream;   // extra streams of the brick sweep (frequency groups are independent)
+    std::vector<hipEvent_t> pipe_up;        // ftte_diffuse_iteration: lane k's opacities have arrived
+    bool stage_used[2] = {false, false};    // the pinned staging block has a transfer recorded on stage_ev
     std::vector<hipEvent_t> lane_done;
     hipEvent_t ev_fork = nullptr;
     // option: 0 = a launch per stage (default); 1, 2 = the bricks of a sweep in ONE launch where the grid allows it, waiting for each
@@ -1030,8 +1032,16 @@ int forest_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
 
 // The sweep of a uniform grid by cell-fixed bricks (ftte_brick.hip): one launch per stage, then one merge of the groups'
 // accumulators (layout after layout, group after group: a fixed order) into J.
+// Host arrays handed over with the sweep (ftte_diffuse_iteration): the opacities go up and J comes back one lane of frequency
+// groups at a time, on the lane's own stream, so that the first lane is swept while the second one's opacities are still on the
+// PCIe link and its J travels back while the second is swept.
+struct HostPipe { const double *kappa; double *J; };
+int upload_on(ftte_ctx *c, hipStream_t q, void *dst_dev, const void *src_host, size_t bytes);
+int download_on(ftte_ctx *c, hipStream_t q, void *dst_host, const void *src_dev, size_t bytes);
+bool is_registered(const ftte_ctx *c, const void *p, size_t bytes);
+
 int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, const double *w, const double *uvb, double *J_dev,
-                hipStream_t stream)
+                hipStream_t stream, const HostPipe *pipe = nullptr)
 {
     int rc;
     if ((rc = build_brick_plan(c, ndir, phi, theta, w))) return rc;
@@ -1065,9 +1075,11 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
             if (!c->acc[l][s]) FTTE_HIP(c, hipMalloc((void **)&c->acc[l][s], sizeof(double) * c->acc_cap));
         if (P.nacc[l] && !c->kappa_ready[l]) {
             if (!c->kappa[l]) FTTE_HIP(c, hipMalloc((void **)&c->kappa[l], sizeof(double) * c->kappa_cap));
-            if (launch_to_layout(l, c->kappa[0], c->kappa[l], n, nnu, (long)c->ncell, stream))
-                return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
-            c->kappa_ready[l] = true;
+            if (!pipe) { // (with host arrays in flight every lane transposes its own groups once they have arrived)
+                if (launch_to_layout(l, c->kappa[0], c->kappa[l], n, nnu, (long)c->ncell, stream))
+                    return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
+                c->kappa_ready[l] = true;
+            }
             transposed = true;
         }
         if (P.nacc[l] && c->emit_mode && !c->emis_ready[l]) {
@@ -1184,6 +1196,21 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
             const int gl = P.glanes > 1 ? lane : 0, nl = P.glanes > 1 ? 0 : lane;
             const int nu0 = (int)((int64_t)nnu * nl / nulanes), nu1 = (int)((int64_t)nnu * (nl + 1) / nulanes);
             const size_t *off = &P.stage_off[(size_t)gl * per_lane];
+            const size_t slice0 = (size_t)nu0 * c->ncell, slice_bytes = sizeof(double) * (size_t)(nu1 - nu0) * c->ncell;
+            if (pipe) {
+                // this lane's opacities: after the lane before (one transfer at a time has the link to itself), then its layouts
+                while (c->pipe_up.size() < (size_t)nlanes) {
+                    hipEvent_t e;
+                    FTTE_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                    c->pipe_up.push_back(e);
+                }
+                if (lane) FTTE_HIP(c, hipStreamWaitEvent(q, c->pipe_up[(size_t)lane - 1], 0));
+                if ((rc = upload_on(c, q, c->kappa[0] + slice0, pipe->kappa + slice0, slice_bytes))) return rc;
+                FTTE_HIP(c, hipEventRecord(c->pipe_up[(size_t)lane], q));
+                for (int l = 1; l < 3; ++l)
+                    if (P.nacc[l] && launch_to_layout(l, c->kappa[0] + slice0, c->kappa[l] + slice0, n, nu1 - nu0, (long)c->ncell, q))
+                        return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
+            }
             for (size_t st = 0; st < nstages; ++st) {
                 if (off[st + 1] == off[st]) continue;
                 BrickLaunch L;
@@ -1201,16 +1228,36 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
                 const int lrc = (c->team && !c->emit_mode) ? launch_brick_team(L, P.max_dirs, c->brick_waves, q) : launch_brick(L, P.max_dirs, c->brick_waves, q);
                 if (lrc) return fail(c, lrc == -1 ? FTTE_ERR_ARG : FTTE_ERR_NO_DEVICE, "brick kernel launch failed");
             }
+            if (pipe) { // this lane's J: merged as soon as its stages are done, and on its way back (pinned arrays) behind that
+                const double *accs[3 * kMaxAcc];
+                int layouts[3 * kMaxAcc], count = 0;
+                for (int l = 0; l < 3; ++l)
+                    for (int s2 = 0; s2 < P.nacc[l]; ++s2) { accs[count] = c->acc[l][s2] + slice0; layouts[count++] = l; }
+                if (launch_merge(accs, layouts, count, J_dev + slice0, n, nu1 - nu0, (long)c->ncell, false, q))
+                    return fail(c, FTTE_ERR_NO_DEVICE, "merge kernel launch failed");
+                if (is_registered(c, pipe->J + slice0, slice_bytes))
+                    FTTE_HIP(c, hipMemcpyAsync(pipe->J + slice0, J_dev + slice0, slice_bytes, hipMemcpyDeviceToHost, q));
+            }
             if (lane) {
                 FTTE_HIP(c, hipEventRecord(c->lane_done[(size_t)lane - 1], q));
                 FTTE_HIP(c, hipStreamWaitEvent(stream, c->lane_done[(size_t)lane - 1], 0));
             }
         }
+        if (pipe) { // pageable J: through the staging blocks, lane after lane (the later lanes are still being swept)
+            for (int lane = 0; lane < nlanes; ++lane) {
+                const int nu0 = (int)((int64_t)nnu * lane / nulanes), nu1 = (int)((int64_t)nnu * (lane + 1) / nulanes);
+                const size_t slice0 = (size_t)nu0 * c->ncell, slice_bytes = sizeof(double) * (size_t)(nu1 - nu0) * c->ncell;
+                if (is_registered(c, pipe->J + slice0, slice_bytes)) continue;
+                hipStream_t q = lane == 0 ? stream : c->lane_stream[(size_t)lane - 1];
+                if ((rc = download_on(c, q, pipe->J + slice0, J_dev + slice0, slice_bytes))) return rc;
+            }
+            c->kappa_ready[0] = c->kappa_ready[1] = c->kappa_ready[2] = true; // every lane has brought and transposed its groups
+        }
         FTTE_HIP(c, hipEventRecord(T.stop, stream));
         c->timing_used = 1;
     }
     // J = the groups' accumulators, layout after layout
-    {
+    if (!pipe) {
         const double *accs[3 * kMaxAcc];
         int layouts[3 * kMaxAcc], count = 0;
         for (int l = 0; l < 3; ++l)
@@ -1802,6 +1849,54 @@ int download(ftte_ctx *c, void *dst_host, const void *src_dev, size_t bytes)
     return FTTE_OK;
 }
 
+// host -> device on stream q; returns when the last piece has been handed to the DMA engine (not when it has arrived)
+int upload_on(ftte_ctx *c, hipStream_t q, void *dst_dev, const void *src_host, size_t bytes)
+{
+    if (is_registered(c, src_host, bytes)) {
+        FTTE_HIP(c, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, q));
+        return FTTE_OK;
+    }
+    int rc = ensure_stage(c);
+    if (rc) return rc;
+    int b = 0;
+    for (size_t off = 0; off < bytes; off += kStageBytes, b ^= 1) {
+        const size_t len = std::min(kStageBytes, bytes - off);
+        if (c->stage_used[b]) FTTE_HIP(c, hipEventSynchronize(c->stage_ev[b]));
+        parallel_copy(c->stage[b], (const char *)src_host + off, len);
+        FTTE_HIP(c, hipMemcpyAsync((char *)dst_dev + off, c->stage[b], len, hipMemcpyHostToDevice, q));
+        FTTE_HIP(c, hipEventRecord(c->stage_ev[b], q));
+        c->stage_used[b] = true;
+    }
+    return FTTE_OK;
+}
+
+// device -> pageable host memory behind whatever is queued on stream q; returns with the copy complete
+int download_on(ftte_ctx *c, hipStream_t q, void *dst_host, const void *src_dev, size_t bytes)
+{
+    int rc = ensure_stage(c);
+    if (rc) return rc;
+    for (int b = 0; b < 2; ++b)
+        if (c->stage_used[b]) { FTTE_HIP(c, hipEventSynchronize(c->stage_ev[b])); c->stage_used[b] = false; }
+    size_t off_prev = 0, len_prev = 0;
+    bool have_prev = false;
+    int b = 0;
+    for (size_t off = 0; off < bytes; off += kStageBytes, b ^= 1) {
+        const size_t len = std::min(kStageBytes, bytes - off);
+        FTTE_HIP(c, hipMemcpyAsync(c->stage[b], (const char *)src_dev + off, len, hipMemcpyDeviceToHost, q));
+        FTTE_HIP(c, hipEventRecord(c->stage_ev[b], q));
+        if (have_prev) {
+            FTTE_HIP(c, hipEventSynchronize(c->stage_ev[b ^ 1]));
+            parallel_copy((char *)dst_host + off_prev, c->stage[b ^ 1], len_prev);
+        }
+        off_prev = off; len_prev = len; have_prev = true;
+    }
+    if (have_prev) {
+        FTTE_HIP(c, hipEventSynchronize(c->stage_ev[b ^ 1]));
+        parallel_copy((char *)dst_host + off_prev, c->stage[b ^ 1], len_prev);
+    }
+    return FTTE_OK;
+}
+
 } // namespace
 
 // =================================================================================================
@@ -1875,6 +1970,7 @@ int ftte_destroy(ftte_ctx *c)
     if (c->ev_layouts_ready) (void)hipEventDestroy(c->ev_layouts_ready);
     if (c->ev_sweep_done) (void)hipEventDestroy(c->ev_sweep_done);
     for (auto &q : c->lane_stream) (void)hipStreamDestroy(q);
+    for (auto &e : c->pipe_up) (void)hipEventDestroy(e);
     for (auto &e : c->lane_done) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     for (auto &e : c->ev_combine) if (e) (void)hipEventDestroy(e);
@@ -2272,6 +2368,38 @@ int ftte_diffuse_sweep(ftte_ctx *c, int ndir, const double *phi, const double *t
     if ((rc = ftte_diffuse_sweep_device(c, ndir, phi, theta, w, uvb, c->host_J_dev, nullptr))) return rc;
     if ((rc = download(c, J, c->host_J_dev, sizeof(double) * elems))) return rc;
     return wait_sweep(c); // the sweep has drained: report a dataflow sweep that gave up now rather than at the next call
+}
+
+/* ftte_set_opacity + ftte_diffuse_sweep in one call, and faster than the two: on a uniform grid swept by the brick engine the
+ * frequency groups travel in lanes (option "lanes") -- the first lane is swept while the second one's opacities are still
+ * crossing PCIe, and its J goes back while the second is swept.  Same results; elsewhere the two calls one after the other. */
+int ftte_diffuse_iteration(ftte_ctx *c, int nnu, const double *kappa, int ndir, const double *phi, const double *theta, const double *w,
+                           const double *uvb, double *J)
+{
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (nnu < 1 || !kappa || !J || ndir < 0 || (ndir > 0 && (!phi || !theta || !w)) || !uvb)
+        return fail(c, FTTE_ERR_ARG, "ftte_diffuse_iteration: bad argument");
+    const bool lanes_apply = !c->use_forest && c->engine != 1 && !c->emit_mode && !c->team && !c->dataflow && ndir > 0 && c->lanes >= 2 &&
+                             nnu >= c->lanes;
+    if (!lanes_apply) {
+        if ((rc = ftte_set_opacity(c, nnu, kappa))) return rc;
+        return ftte_diffuse_sweep(c, ndir, phi, theta, w, uvb, J);
+    }
+    FTTE_HIP(c, hipSetDevice(c->device));
+    if ((rc = wait_sweep(c))) return rc;
+    FTTE_HIP(c, hipStreamSynchronize(c->stream));
+    if ((rc = ensure_kappa(c, nnu))) return rc;
+    c->nnu = nnu;
+    c->kappa_ready[0] = c->kappa_ready[1] = c->kappa_ready[2] = c->kappa_ready[3] = false;
+    const size_t elems = (size_t)nnu * c->ncell;
+    if ((rc = ensure(c, &c->host_J_dev, &c->host_J_cap, elems))) return rc;
+    const HostPipe pipe{kappa, J};
+    if ((rc = brick_sweep(c, ndir, phi, theta, w, uvb, c->host_J_dev, c->stream, &pipe))) {
+        c->kappa_ready[0] = c->kappa_ready[1] = c->kappa_ready[2] = false;
+        return rc;
+    }
+    return wait_sweep(c); // J is in the caller's array on return
 }
 
 /* Pins a caller-owned host array for as long as it stays registered: ftte_set_opacity / ftte_diffuse_sweep then move

@@ -84,3 +84,41 @@ def test_registered_and_pageable_host_arrays_give_the_same_bits():
             # twelve directions: the device adds them group by group, the oracle in list order
             assert np.allclose(J_pageable, O.sweep_uniform(n, kappa, box, phi, theta, w, uvb, arith=O.ARITH_DEVICE),
                                rtol=64 * np.finfo(float).eps, atol=0)
+
+
+@pytest.mark.parametrize("n,nnu", [(70, 3), (64, 8), (33, 2)])
+def test_iteration_in_one_call_equals_the_two_calls(n, nnu):
+    """ftte_diffuse_iteration = ftte_set_opacity + ftte_diffuse_sweep with the frequency groups crossing PCIe and being swept in
+    overlapping lanes: the same bits, with pageable arrays (through the staging blocks) and with registered ones (DMA in place),
+    and a later device-side sweep finds the opacities the call left behind."""
+    kappa, uvb, box = synthetic.uniform_workload(n, nnu, seed=n, tau_median=0.3)
+    phi, theta, w = O.healpix_directions(2)
+    with rt.DiffuseTransfer() as e:
+        e.set_uniform_grid(n, box)
+        e.set_opacity(kappa)
+        J_two = e.transport(phi, theta, w, uvb)
+        e.set_opacity(0.5 * kappa)                      # something else in between
+        J_one = np.full_like(J_two, np.nan)
+        e.iterate_into(kappa, phi, theta, w, uvb, J_one)
+        assert np.array_equal(J_one, J_two)
+        assert np.array_equal(e.transport(phi, theta, w, uvb), J_two)   # kappa and its layouts are in place
+        k2, J_reg = np.ascontiguousarray(2.0 * kappa), np.empty_like(J_two)
+        e.host_register(k2); e.host_register(J_reg)
+        e.iterate_into(k2, phi, theta, w, uvb, J_reg)
+        e.set_opacity(k2)
+        assert np.array_equal(J_reg, e.transport(phi, theta, w, uvb))
+        e.host_unregister(k2); e.host_unregister(J_reg)
+        e.set_option("lanes", 1)                        # no lanes: the two calls internally
+        J_seq = np.empty_like(J_two)
+        e.iterate_into(kappa, phi, theta, w, uvb, J_seq)
+        assert np.array_equal(J_seq, J_two)
+
+
+def test_iteration_in_one_call_on_a_refined_cell_array(golden):
+    g = golden("amr8_block_level1")
+    with rt.DiffuseTransfer() as e:
+        e.set_grid(int(g["n"]), g["level"], float(g["box"]))
+        J = np.empty_like(g["kappa"])
+        e.iterate_into(g["kappa"], g["phi"], g["theta"], g["w"], g["uvb"], J)
+        e.set_opacity(g["kappa"])
+        assert np.array_equal(J, e.transport(g["phi"], g["theta"], g["w"], g["uvb"]))

@@ -30,6 +30,20 @@ for mode in ("pageable", "registered"):
         t3 = time.perf_counter()
         print(f"{mode:10s} iteration {rep}: {(t3 - t0) * 1e3:7.1f} ms = set_grid {(t1 - t0) * 1e3:6.1f} + set_opacity {(t2 - t1) * 1e3:6.1f} + sweep and J back "
               f"{(t3 - t2) * 1e3:6.1f}  -> {n ** 3 * nnu * ndir / (t3 - t0):.3e} updates/s PCIe-inclusive", flush=True)
+# the same as ONE call (ftte_diffuse_iteration): the frequency groups cross PCIe and are swept in overlapping lanes
+for rep in range(4):
+    t0 = time.perf_counter()
+    eng.set_grid(n, level, box)
+    eng.iterate_into(kappa, phi, theta, w, uvb, J)
+    t3 = time.perf_counter()
+    print(f"registered, one call, iteration {rep}: {(t3 - t0) * 1e3:7.1f} ms -> {n ** 3 * nnu * ndir / (t3 - t0):.3e} updates/s PCIe-inclusive", flush=True)
+eng.host_unregister(kappa); eng.host_unregister(J)
+for rep in range(3):
+    t0 = time.perf_counter()
+    eng.set_grid(n, level, box)
+    eng.iterate_into(kappa, phi, theta, w, uvb, J)
+    t3 = time.perf_counter()
+    print(f"pageable,   one call, iteration {rep}: {(t3 - t0) * 1e3:7.1f} ms -> {n ** 3 * nnu * ndir / (t3 - t0):.3e} updates/s PCIe-inclusive", flush=True)
 eng.close()
 
 # BASELINE configs[3] tree through the same call sequence: set_grid + set_opacity + sweep per outer iteration
