@@ -152,6 +152,8 @@ struct ftte_ctx {
     LayerRec *d_layers = nullptr; size_t d_layers_cap = 0;
     WorkItem *d_items = nullptr;  size_t d_items_cap = 0;
     double *d_uvb = nullptr;      size_t d_uvb_cap = 0;
+    std::vector<char> bgroups_sent;   // the bytes d_bgroups holds (brick_sweep), empty: unknown
+    std::vector<double> uvb_sent;     // the values d_uvb holds (brick_sweep), empty: unknown
     bool plan_uploaded = false;
 
     std::vector<LaunchTiming> timing;
@@ -980,7 +982,7 @@ int forest_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
     } else batch = (int)std::min<size_t>((size_t)kAmrBatch, c->amr_scratch_cap / per_dir);
     FTTE_HIP(c, hipStreamSynchronize(stream)); // d_uvb below may still be read by the previous sweep
     if ((rc = ensure(c, &c->d_uvb, &c->d_uvb_cap, (size_t)nnu))) return rc;
-    FTTE_HIP(c, hipMemcpy(c->d_uvb, uvb, sizeof(double) * nnu, hipMemcpyHostToDevice));
+    FTTE_HIP(c, hipMemcpy(c->d_uvb, uvb, sizeof(double) * nnu, hipMemcpyHostToDevice)); c->uvb_sent.clear();
 
     // the forest path gathers by cell: all groups of a cell side by side (beyond 96 groups the transposing kernel's
     // tile no longer fits the LDS of a workgroup; the strided layout is read as it is)
@@ -1103,6 +1105,7 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
     (void)transposed;
 
     if (!c->bplan_uploaded) {
+        c->bgroups_sent.clear();
         if ((rc = ensure(c, &c->d_blayers, &c->d_blayers_cap, P.layers.size()))) return rc;
         if ((rc = ensure(c, &c->d_btasks, &c->d_btasks_cap, P.tasks.size()))) return rc;
         if ((rc = ensure(c, &c->d_bgroups, &c->d_bgroups_cap, P.groups.size()))) return rc;
@@ -1135,10 +1138,18 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
                 G[g].dir[q].w = P.dirs[d].w;
             }
         }
-        if (!G.empty()) FTTE_HIP(c, hipMemcpy(c->d_bgroups, G.data(), sizeof(BrickGroup) * G.size(), hipMemcpyHostToDevice));
+        // (a blocking copy each: skipped when the device already holds exactly these bytes, which is every iteration after the first)
+        const size_t bytes = sizeof(BrickGroup) * G.size();
+        if (bytes && (c->bgroups_sent.size() != bytes || std::memcmp(c->bgroups_sent.data(), G.data(), bytes) != 0)) {
+            FTTE_HIP(c, hipMemcpy(c->d_bgroups, G.data(), bytes, hipMemcpyHostToDevice));
+            c->bgroups_sent.assign((const char *)G.data(), (const char *)G.data() + bytes);
+        }
     }
     if ((rc = ensure(c, &c->d_uvb, &c->d_uvb_cap, (size_t)nnu))) return rc;
-    FTTE_HIP(c, hipMemcpy(c->d_uvb, uvb, sizeof(double) * nnu, hipMemcpyHostToDevice));
+    if (c->uvb_sent.size() != (size_t)nnu || std::memcmp(c->uvb_sent.data(), uvb, sizeof(double) * nnu) != 0) {
+        FTTE_HIP(c, hipMemcpy(c->d_uvb, uvb, sizeof(double) * nnu, hipMemcpyHostToDevice));
+        c->uvb_sent.assign(uvb, uvb + nnu);
+    }
 
     // The frequency groups never touch each other's data (own slices of the accumulators and of the face rings), and a
     // stage is a launch that drains before the next one starts: the stage sequence is therefore issued once per "lane"
@@ -1641,10 +1652,10 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
                 G[g].dir[q].w = P.dirs[d].w;
             }
         }
-        FTTE_HIP(c, hipMemcpy(c->d_bgroups, G.data(), sizeof(BrickGroup) * G.size(), hipMemcpyHostToDevice));
+        FTTE_HIP(c, hipMemcpy(c->d_bgroups, G.data(), sizeof(BrickGroup) * G.size(), hipMemcpyHostToDevice)); c->bgroups_sent.clear();
     }
     if ((rc = ensure(c, &c->d_uvb, &c->d_uvb_cap, (size_t)nnu))) return rc;
-    FTTE_HIP(c, hipMemcpy(c->d_uvb, uvb, sizeof(double) * nnu, hipMemcpyHostToDevice));
+    FTTE_HIP(c, hipMemcpy(c->d_uvb, uvb, sizeof(double) * nnu, hipMemcpyHostToDevice)); c->uvb_sent.clear();
 
     // forest scratch: as forest_sweep, for the leaves of the plan's list only
     const size_t per_dir = (size_t)3 * (size_t)std::max<int64_t>(H.ncells, 1) * nnu;
@@ -2264,7 +2275,7 @@ int ftte_diffuse_sweep_device(ftte_ctx *c, int ndir, const double *phi, const do
         c->plan_uploaded = true;
     }
     if ((rc = ensure(c, &c->d_uvb, &c->d_uvb_cap, (size_t)nnu))) return rc;
-    FTTE_HIP(c, hipMemcpy(c->d_uvb, uvb, sizeof(double) * nnu, hipMemcpyHostToDevice));
+    FTTE_HIP(c, hipMemcpy(c->d_uvb, uvb, sizeof(double) * nnu, hipMemcpyHostToDevice)); c->uvb_sent.clear();
 
     // accumulators sized for this nnu
     if (c->acc_cap < per_acc) {
