@@ -16,8 +16,9 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libftte.so")
-SOURCES = ["ftte_kernels.hip", "ftte_brick.hip", "ftte_api.cpp", "ftte_geometry.cpp", "ftte_amr.cpp", "ftte_point.cpp", "ftte_ingest.cpp"]
-HEADERS = ["ftte_internal.h", "ftte_kernels.h", "ftte_geometry.h", "ftte_math.h", "ftte_amr.h", "ftte_point.h", os.path.join("..", "..", "include", "ftte.h")]
+SOURCES = ["ftte_kernels.hip", "ftte_brick.hip", "ftte_api.cpp", "ftte_plan.cpp", "ftte_sweeps.cpp", "ftte_hybrid.cpp", "ftte_host_arrays.cpp",
+           "ftte_geometry.cpp", "ftte_amr.cpp", "ftte_point.cpp", "ftte_ingest.cpp"]
+HEADERS = ["ftte.map", "ftte_context.h", "ftte_internal.h", "ftte_kernels.h", "ftte_geometry.h", "ftte_math.h", "ftte_amr.h", "ftte_point.h", os.path.join("..", "..", "include", "ftte.h")]
 # -ffp-contract=off: the sweep arithmetic spells out its fused multiply-adds (ftte_math.h); nothing else may be fused,
 # so that the device rounds exactly like the host evaluation the parity tests compare against.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-gpu-rdc", "-Wall"]
@@ -72,7 +73,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as pool:
         list(pool.map(run, jobs))
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    # the version script keeps the C++ behind the ABI out of the dynamic symbol table: only ftte_* is exported
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "ftte.map"), "-o", LIB, *objs]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -1,0 +1,495 @@
+// ftte_hybrid.cpp -- the hybrid sweep of a refined cell array: bricks outside a box around the refined cells, segment forests inside.
+#include "ftte_context.h"
+
+namespace ftte {
+
+// ---- hybrid sweep of a refined cell array -----------------------------------------------------------------------------
+// The reference recurses into refined cells wherever they are (transport, transportRoutinesModule.f90:577-586) and walks the
+// tree for every upstream link of every cell of every direction.  Most of a cell array is plain base cells; here those are
+// swept by the brick kernel, and only a box around the refined cells -- widened by one brick, so that its surface separates
+// unrefined base cells, across which a ray is handed over exactly as between two bricks -- by the segment forest.  Per group of
+// directions: the bricks that do not lie behind the box, then the forest (rays entering it read from the bricks' face
+// buffers, rays leaving it written there), then the bricks behind it.  J of a cell = what the bricks stored for the
+// directions in whose box it does not lie + what the forest adds for the others.
+
+void free_hybrid(ftte_ctx *c)
+{
+    for (auto &d : c->hplan.dirs) {
+        if (d.rec) (void)hipFree(d.rec);
+        if (d.active) (void)hipFree(d.active);
+        if (d.exports) (void)hipFree(d.exports);
+    }
+    if (c->hplan.cells) (void)hipFree(c->hplan.cells);
+    c->hplan = ftte_ctx::HybridPlan();
+}
+
+// the box of izone `izone`, sweep frame, tile-aligned and widened by a brick; false if the tree has no refined cell
+bool hybrid_region(const ftte_ctx *c, const BrickPlan &P, int izone, ForestRegion *R, int tile_lo[3], int tile_hi[3])
+{
+    const AmrTree &T = c->tree;
+    const int n = T.n;
+    int clo[3] = {n + 1, n + 1, n + 1}, chi[3] = {0, 0, 0}; // storage coordinates of the refined base cells
+    for (int64_t b = 0; b < (int64_t)n * n * n; ++b)
+        if (T.child0[(size_t)b] >= 0) {
+            const int cc[3] = {(int)(b / ((int64_t)n * n)) + 1, (int)((b / n) % n) + 1, (int)(b % n) + 1};
+            for (int a = 0; a < 3; ++a) { clo[a] = std::min(clo[a], cc[a]); chi[a] = std::max(chi[a], cc[a]); }
+        }
+    if (chi[0] == 0) return false;
+    ZoneMap zm;
+    zone_map(izone, &zm);
+    int slo[3], shi[3]; // sweep frame: i, j, k
+    int march_c = 0;
+    for (int a = 0; a < 3; ++a) {
+        const int sa = zm.src[a];
+        slo[sa] = zm.mirror[a] ? n + 1 - chi[a] : clo[a];
+        shi[sa] = zm.mirror[a] ? n + 1 - clo[a] : chi[a];
+        if (sa == 0) march_c = a;
+    }
+    const int fast_c = (march_c == 2) ? 1 : 2;
+    const bool u_is_k = zm.src[fast_c] == 2;
+    const int ju = u_is_k ? 2 : 1, jv = u_is_k ? 1 : 2; // sweep axes of u and v
+    const int size[3] = {P.chunk, 0, 0};
+    (void)size;
+    const int tsize_i = P.chunk, tsize_u = 64, tsize_v = kBrickRows;
+    tile_lo[0] = std::max(0, (slo[ju] - 1) / tsize_u - 1); tile_hi[0] = std::min(P.ntu - 1, (shi[ju] - 1) / tsize_u + 1);
+    tile_lo[1] = std::max(0, (slo[jv] - 1) / tsize_v - 1); tile_hi[1] = std::min(P.ntv - 1, (shi[jv] - 1) / tsize_v + 1);
+    tile_lo[2] = std::max(0, (slo[0] - 1) / tsize_i - 1);  tile_hi[2] = std::min(P.nti - 1, (shi[0] - 1) / tsize_i + 1);
+    R->u_is_k = u_is_k;
+    R->lo[0] = tile_lo[2] * tsize_i + 1; R->hi[0] = std::min(n, (tile_hi[2] + 1) * tsize_i);
+    R->lo[ju] = tile_lo[0] * tsize_u + 1; R->hi[ju] = std::min(n, (tile_hi[0] + 1) * tsize_u);
+    R->lo[jv] = tile_lo[1] * tsize_v + 1; R->hi[jv] = std::min(n, (tile_hi[1] + 1) * tsize_v);
+    R->chunk = P.chunk; R->ut = P.ut; R->nslot = P.nslot; R->ntv = P.ntv; R->up = P.up; R->vp = P.vp;
+    R->vface_off = P.vface_off; R->iface_off = P.iface_off;
+    return true;
+}
+
+int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *theta, const double *w)
+{
+    ftte_ctx::HybridPlan &H = c->hplan;
+    const int n = c->n, nnu = c->nnu;
+    // short bricks: the box is widened by one brick on every side, and what lies inside it costs several times a brick's bytes
+    const int chunk = std::min(c->chunk > 0 ? c->chunk : 4, n);
+    const int gmax = c->group > 0 ? c->group : (nnu >= 2 ? 3 : 2);
+    std::vector<double> key = {c->box, (double)chunk, (double)gmax, (double)c->share, (double)c->halves};
+    key.insert(key.end(), phi, phi + ndir);
+    key.insert(key.end(), theta, theta + ndir);
+    key.insert(key.end(), w, w + ndir);
+    if (H.valid && H.key == key) return FTTE_OK;
+    free_hybrid(c);
+    int rc;
+    BrickPlan &P = H.bricks;
+    if ((rc = plan_brick_groups(c, P, ndir, phi, theta, w, chunk, gmax, 0, true))) return rc;
+    P.glanes = 1;
+
+    // the box of every group; is the part outside the boxes worth a brick sweep?
+    struct Box { ForestRegion R; int lo[3], hi[3]; bool any; };
+    std::vector<Box> box(P.groups.size());
+    int64_t inside_bricks = 0, all_bricks = 0;
+    for (size_t g = 0; g < P.groups.size(); ++g) {
+        box[g].any = hybrid_region(c, P, P.groups[g].izone, &box[g].R, box[g].lo, box[g].hi);
+        all_bricks += (int64_t)P.ntu * P.ntv * P.nti;
+        if (box[g].any) inside_bricks += (int64_t)(box[g].hi[0] - box[g].lo[0] + 1) * (box[g].hi[1] - box[g].lo[1] + 1) * (box[g].hi[2] - box[g].lo[2] + 1);
+    }
+    H.key = key;
+    H.valid = true;
+    H.worthwhile = !P.groups.empty() && inside_bricks * 2 <= all_bricks; // else: the forest path for the whole tree
+    if (!H.worthwhile) return FTTE_OK;
+
+    // Halves: the forests stream records at the memory system's rate while the brick stages of a 128^3 grid are short launches
+    // that leave most of it idle, so the sweep runs as two pipelines (bricks - forests - bricks each) on two streams.  What the
+    // groups of one accumulator write is ordered by their launches, so an accumulator's groups stay together; halves are
+    // balanced by direction count.
+    std::vector<int> half_of_group(P.groups.size(), 0);
+    H.nhalves = 1;
+    if (c->halves > 1 && P.nacc[0] + P.nacc[1] + P.nacc[2] >= 2) {
+        H.nhalves = std::min(c->halves, P.nacc[0] + P.nacc[1] + P.nacc[2]);
+        std::vector<int> weight(3 * (size_t)kMaxAcc, 0), order;
+        for (const auto &G : P.groups) weight[(size_t)G.layout * kMaxAcc + G.acc] += (int)G.dirs.size();
+        for (int a = 0; a < 3 * kMaxAcc; ++a) if (weight[(size_t)a]) order.push_back(a);
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return weight[(size_t)x] > weight[(size_t)y]; });
+        std::vector<int> half_of_acc(3 * (size_t)kMaxAcc, 0);
+        int load[ftte_ctx::kMaxPipes] = {0, 0, 0, 0};
+        for (int a : order) {
+            int h = 0;
+            for (int q = 1; q < H.nhalves; ++q) if (load[q] < load[h]) h = q;
+            half_of_acc[(size_t)a] = h; load[h] += weight[(size_t)a];
+        }
+        for (size_t g = 0; g < P.groups.size(); ++g) half_of_group[g] = half_of_acc[(size_t)P.groups[g].layout * kMaxAcc + P.groups[g].acc];
+    }
+    H.half_dirs.assign((size_t)H.nhalves, std::vector<int>());
+    {
+        std::vector<int> half_of_dir((size_t)ndir, 0);
+        for (size_t g = 0; g < P.groups.size(); ++g) for (int d : P.groups[g].dirs) half_of_dir[(size_t)d] = half_of_group[g];
+        for (int d = 0; d < ndir; ++d) H.half_dirs[(size_t)half_of_dir[(size_t)d]].push_back(d);
+    }
+
+    // tasks: the bricks outside the boxes.  Phase 1: those that do not lie behind their group's box (no tile index at or beyond
+    // the box's first one in all three directions); phase 3: the others.  Within a phase stage by stage as in a plain sweep.
+    int max_offset = 0;
+    for (const auto &G : P.groups) max_offset = std::max(max_offset, G.offset);
+    const int per_phase = P.ntu + P.ntv + P.nti - 2 + max_offset;
+    H.nlist = 2 * (size_t)per_phase;
+    const size_t nlist = (size_t)H.nhalves * H.nlist;
+    H.phase1_stages = (size_t)per_phase;
+    auto list_of = [&](size_t g, const Box &B, int tu, int tv, int ti, int offset) {
+        const bool behind = B.any && tu >= B.lo[0] && tv >= B.lo[1] && ti >= B.lo[2];
+        return (size_t)half_of_group[g] * H.nlist + (size_t)(behind ? per_phase : 0) + (size_t)(tu + tv + ti + offset);
+    };
+    auto in_box = [&](const Box &B, int tu, int tv, int ti) {
+        return B.any && tu >= B.lo[0] && tu <= B.hi[0] && tv >= B.lo[1] && tv <= B.hi[1] && ti >= B.lo[2] && ti <= B.hi[2];
+    };
+    const size_t nb = (size_t)P.ntu * P.ntv * P.nti;
+    std::vector<std::vector<size_t>> first(3 * (size_t)kMaxAcc);
+    auto brick_of = [&](const BrickPlan::Group &G, int tu, int tv, int ti) {
+        const DirPlan &D0 = P.dirs[G.dirs[0]];
+        const int bu = D0.su < 0 ? P.ntu - 1 - tu : tu, bv = D0.sv < 0 ? P.ntv - 1 - tv : tv, bi = D0.si < 0 ? P.nti - 1 - ti : ti;
+        return ((size_t)bi * P.ntv + bv) * P.ntu + bu;
+    };
+    H.stage_off.assign(nlist + 1, 0);
+    for (size_t g = 0; g < P.groups.size(); ++g) {
+        const BrickPlan::Group &G = P.groups[g];
+        std::vector<size_t> &F = first[(size_t)G.layout * kMaxAcc + G.acc];
+        if (F.empty()) F.assign(nb, ~(size_t)0);
+        for (int ti = 0; ti < P.nti; ++ti)
+            for (int tv = 0; tv < P.ntv; ++tv)
+                for (int tu = 0; tu < P.ntu; ++tu) {
+                    if (in_box(box[g], tu, tv, ti)) continue;
+                    const size_t l = list_of(g, box[g], tu, tv, ti, G.offset);
+                    ++H.stage_off[l + 1];
+                    size_t &f = F[brick_of(G, tu, tv, ti)];
+                    f = std::min(f, l);
+                }
+    }
+    for (size_t l = 0; l < nlist; ++l) H.stage_off[l + 1] += H.stage_off[l];
+    P.tasks.resize(H.stage_off[nlist]);
+    std::vector<size_t> fill(H.stage_off.begin(), H.stage_off.end() - 1);
+    H.brick_updates = 0;
+    for (size_t g = 0; g < P.groups.size(); ++g) {
+        const BrickPlan::Group &G = P.groups[g];
+        const std::vector<size_t> &F = first[(size_t)G.layout * kMaxAcc + G.acc];
+        for (int ti = 0; ti < P.nti; ++ti)
+            for (int tv = 0; tv < P.ntv; ++tv)
+                for (int tu = 0; tu < P.ntu; ++tu) {
+                    if (in_box(box[g], tu, tv, ti)) continue;
+                    const size_t l = list_of(g, box[g], tu, tv, ti, G.offset);
+                    BrickTask T;
+                    T.group = (int16_t)g; T.tu = (int16_t)tu; T.tv = (int16_t)tv;
+                    T.ti = (int16_t)(ti | (l > F[brick_of(G, tu, tv, ti)] ? kBrickAccumulate : 0));
+                    P.tasks[fill[l]++] = T;
+                    const int64_t cu = std::min(64, n - 64 * tu), cv = std::min(kBrickRows, n - kBrickRows * tv), ci = std::min(chunk, n - chunk * ti);
+                    H.brick_updates += cu * cv * ci * (int64_t)G.dirs.size();
+                }
+    }
+
+    // The forests, restricted to the boxes: linked on the host a few directions at a time.  Once the leaves that lie in any box are
+    // known they are numbered by their place in that list, and segments (3 * place + piece), activity bytes, opacities and scratch
+    // use those numbers: what the forests need of memory follows the boxes, not the tree.
+    std::vector<int> group_of((size_t)ndir, -1);
+    for (size_t g = 0; g < P.groups.size(); ++g) for (int d : P.groups[g].dirs) group_of[(size_t)d] = (int)g;
+    H.dirs.resize((size_t)ndir);
+    const int64_t ncell = c->ncell;
+    const int nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<uint8_t> in_any((size_t)ncell, 0);
+    std::vector<std::vector<SegRec>> rec((size_t)ndir);
+    std::vector<std::vector<uint8_t>> active((size_t)ndir);  // per leaf, until the list is known
+    std::vector<std::vector<AmrExport>> exports((size_t)ndir);
+    ++c->n_forest_builds;
+    for (int d0 = 0; d0 < ndir; d0 += nthreads) {
+        const int nbt = std::min(nthreads, ndir - d0);
+        std::vector<AmrForest> F(nbt);
+        std::vector<int> st(nbt, 0);
+        std::vector<std::string> msg(nbt);
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nbt; ++t)
+            pool.emplace_back([&, t] {
+                const int d = d0 + t;
+                const DirPlan &D = P.dirs[(size_t)d];
+                const Box &B = box[(size_t)group_of[(size_t)d]];
+                st[t] = build_forest(c->tree, D.phi, D.theta, D.izone, c->box, &F[t], &msg[t], &B.R);
+                if (st[t]) return;
+                const AmrForest &f = F[t];
+                const size_t nact = f.order.size();
+                rec[(size_t)d].resize(std::max<size_t>(nact, 1));
+                for (size_t q = 0; q < nact; ++q) {
+                    const int32_t sg = f.order[q];
+                    SegRec &R = rec[(size_t)d][q];
+                    R.seg = sg; R.up = f.up[sg]; R.up2 = f.up2[sg];
+                    R.at = f.up[sg] == AmrForest::kImport ? f.import_at[sg] : 0;
+                    R.dpath = f.dpath[sg];
+                }
+                active[(size_t)d].resize((size_t)ncell);
+                for (int64_t q = 0; q < ncell; ++q)
+                    active[(size_t)d][(size_t)q] = (uint8_t)((f.up[3 * q + 1] != AmrForest::kInactive ? 1 : 0) | (f.up[3 * q + 2] != AmrForest::kInactive ? 2 : 0) |
+                                                             (f.inside[(size_t)q] ? 0 : 4));
+            });
+        for (auto &th : pool) th.join();
+        for (int t = 0; t < nbt; ++t) {
+            if (st[t]) { const std::string m = msg[t]; const int code = st[t]; free_hybrid(c); return fail(c, code, "direction " + std::to_string(d0 + t) + ": " + m); }
+            ftte_ctx::HybridPlan::Dir &D = H.dirs[(size_t)(d0 + t)];
+            D.depth_off = F[t].depth_off;
+            D.nexports = (int64_t)F[t].exports.size();
+            static_assert(sizeof(AmrForest::Export) == sizeof(AmrExport), "export records: host and device forms must agree");
+            exports[(size_t)(d0 + t)].resize(F[t].exports.size());
+            if (!F[t].exports.empty()) std::memcpy(exports[(size_t)(d0 + t)].data(), F[t].exports.data(), sizeof(AmrExport) * F[t].exports.size());
+            for (int64_t q = 0; q < ncell; ++q) in_any[(size_t)q] |= F[t].inside[(size_t)q];
+        }
+    }
+    std::vector<int32_t> cells, place((size_t)ncell, -1);
+    for (int64_t q = 0; q < ncell; ++q)
+        if (in_any[(size_t)q]) { place[(size_t)q] = (int32_t)cells.size(); cells.push_back((int32_t)q); }
+    H.ncells = (int64_t)cells.size();
+    FTTE_HIP(c, hipMalloc((void **)&H.cells, sizeof(int32_t) * std::max<size_t>(cells.size(), 1)));
+    if (!cells.empty()) FTTE_HIP(c, hipMemcpy(H.cells, cells.data(), sizeof(int32_t) * cells.size(), hipMemcpyHostToDevice));
+    {
+        auto renumber = [&](int32_t sg) { return sg < 0 ? sg : 3 * place[(size_t)(sg / 3)] + sg % 3; }; // negative: inflow / import marks
+        std::vector<int> bad((size_t)ndir, 0);
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; ++t)
+            pool.emplace_back([&, t] {
+                std::vector<uint8_t> compact(cells.size());
+                for (int d = t; d < ndir; d += nthreads) {
+                    for (SegRec &R : rec[(size_t)d]) {
+                        if (place[(size_t)(R.seg / 3)] < 0 || (R.up >= 0 && place[(size_t)(R.up / 3)] < 0) || (R.up2 >= 0 && place[(size_t)(R.up2 / 3)] < 0)) { bad[(size_t)d] = 1; break; }
+                        R.seg = renumber(R.seg); R.up = renumber(R.up); R.up2 = renumber(R.up2);
+                    }
+                    for (AmrExport &X : exports[(size_t)d]) {
+                        if (place[(size_t)(X.seg / 3)] < 0) { bad[(size_t)d] = 1; break; }
+                        X.seg = renumber(X.seg);
+                    }
+                    for (size_t q = 0; q < cells.size(); ++q) compact[q] = active[(size_t)d][(size_t)cells[q]];
+                    active[(size_t)d].assign(compact.begin(), compact.end());
+                }
+            });
+        for (auto &th : pool) th.join();
+        for (int d = 0; d < ndir; ++d)
+            if (bad[(size_t)d]) { free_hybrid(c); return fail(c, FTTE_ERR_STATE, "hybrid plan: a forest segment lies outside every box"); }
+    }
+    for (int d = 0; d < ndir; ++d) {
+        ftte_ctx::HybridPlan::Dir &D = H.dirs[(size_t)d];
+        FTTE_HIP(c, hipMalloc((void **)&D.rec, sizeof(SegRec) * rec[(size_t)d].size()));
+        FTTE_HIP(c, hipMalloc((void **)&D.active, std::max<size_t>(active[(size_t)d].size(), 1)));
+        FTTE_HIP(c, hipMalloc((void **)&D.exports, sizeof(AmrExport) * std::max<size_t>(exports[(size_t)d].size(), 1)));
+        FTTE_HIP(c, hipMemcpy(D.rec, rec[(size_t)d].data(), sizeof(SegRec) * rec[(size_t)d].size(), hipMemcpyHostToDevice));
+        if (!active[(size_t)d].empty()) FTTE_HIP(c, hipMemcpy(D.active, active[(size_t)d].data(), active[(size_t)d].size(), hipMemcpyHostToDevice));
+        if (!exports[(size_t)d].empty())
+            FTTE_HIP(c, hipMemcpy(D.exports, exports[(size_t)d].data(), sizeof(AmrExport) * exports[(size_t)d].size(), hipMemcpyHostToDevice));
+        std::vector<SegRec>().swap(rec[(size_t)d]);
+        std::vector<uint8_t>().swap(active[(size_t)d]);
+    }
+    c->kappa_ready[3] = false; // the forests' copy of the opacities follows the list
+    H.uploaded = false;
+    return FTTE_OK;
+}
+
+int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, const double *w, const double *uvb, double *J_dev,
+                 hipStream_t stream, bool *done)
+{
+    *done = false;
+    int rc;
+    if ((rc = wait_sweep(c))) return rc;
+    FTTE_HIP(c, hipStreamSynchronize(stream));
+    if (stream != c->stream) FTTE_HIP(c, hipStreamSynchronize(c->stream));
+    if ((rc = build_hybrid_plan(c, ndir, phi, theta, w))) return rc;
+    ftte_ctx::HybridPlan &H = c->hplan;
+    if (!H.worthwhile) return FTTE_OK; // the caller takes the forest path for the whole tree
+    BrickPlan &P = H.bricks;
+    const int n = c->n, nnu = c->nnu;
+    const int64_t ncell = c->ncell, nbase = (int64_t)n * n * n;
+
+    // ---- device state that depends on the tree only
+    if (!c->d_leaf_of_base) {
+        std::vector<int32_t> map((size_t)nbase);
+        for (int64_t b = 0; b < nbase; ++b) map[(size_t)b] = c->tree.leaf[(size_t)b];
+        FTTE_HIP(c, hipMalloc((void **)&c->d_leaf_of_base, sizeof(int32_t) * (size_t)nbase));
+        FTTE_HIP(c, hipMemcpy(c->d_leaf_of_base, map.data(), sizeof(int32_t) * (size_t)nbase, hipMemcpyHostToDevice));
+    }
+    const size_t per_base = (size_t)nnu * (size_t)nbase;
+    if (c->base_kappa_cap < per_base) {
+        for (int l = 0; l < 3; ++l) if (c->base_kappa[l]) { FTTE_HIP(c, hipFree(c->base_kappa[l])); c->base_kappa[l] = nullptr; }
+        for (int l = 0; l < 3; ++l) FTTE_HIP(c, hipMalloc((void **)&c->base_kappa[l], sizeof(double) * per_base));
+        c->base_kappa_cap = per_base;
+    }
+    if (c->acc_cap < (size_t)nnu * (size_t)ncell) {
+        for (int l = 0; l < 3; ++l)
+            for (int s = 0; s < kMaxAcc; ++s)
+                if (c->acc[l][s]) { FTTE_HIP(c, hipFree(c->acc[l][s])); c->acc[l][s] = nullptr; }
+        c->acc_cap = (size_t)nnu * (size_t)ncell;
+    }
+    for (int l = 0; l < 3; ++l)
+        for (int s = 0; s < P.nacc[l]; ++s)
+            if (!c->acc[l][s]) FTTE_HIP(c, hipMalloc((void **)&c->acc[l][s], sizeof(double) * c->acc_cap));
+    const size_t face_need = (size_t)ndir * nnu * (size_t)P.face_elems;
+    if ((rc = ensure(c, &c->d_faces, &c->d_faces_cap, face_need))) return rc;
+    if (!H.uploaded) {
+        if ((rc = ensure(c, &c->d_blayers, &c->d_blayers_cap, P.layers.size()))) return rc;
+        if ((rc = ensure(c, &c->d_btasks, &c->d_btasks_cap, P.tasks.size()))) return rc;
+        if ((rc = ensure(c, &c->d_bgroups, &c->d_bgroups_cap, P.groups.size()))) return rc;
+        FTTE_HIP(c, hipMemcpy(c->d_blayers, P.layers.data(), sizeof(LayerRec) * P.layers.size(), hipMemcpyHostToDevice));
+        if (!P.tasks.empty()) FTTE_HIP(c, hipMemcpy(c->d_btasks, P.tasks.data(), sizeof(BrickTask) * P.tasks.size(), hipMemcpyHostToDevice));
+        H.uploaded = true;
+        c->bplan_uploaded = false; c->bplan.valid = false; // the uniform-grid plan shared these buffers
+    }
+    {
+        std::vector<BrickGroup> G(P.groups.size());
+        std::memset(G.data(), 0, sizeof(BrickGroup) * G.size());
+        for (size_t g = 0; g < P.groups.size(); ++g) {
+            const BrickPlan::Group &Hg = P.groups[g];
+            const DirPlan &D0 = P.dirs[Hg.dirs[0]];
+            G[g].kappa = c->base_kappa[Hg.layout];
+            G[g].J = c->acc[Hg.layout][Hg.acc];
+            G[g].org = D0.org; G[g].si = D0.si; G[g].sv = D0.sv; G[g].su = D0.su;
+            G[g].ndir = (int)Hg.dirs.size();
+            for (size_t q = 0; q < Hg.dirs.size(); ++q) {
+                const int d = Hg.dirs[q];
+                G[g].dir[q].layers = c->d_blayers + P.dirs[d].layer_off;
+                G[g].dir[q].faces = c->d_faces + (size_t)d * nnu * (size_t)P.face_elems;
+                G[g].dir[q].w = P.dirs[d].w;
+            }
+        }
+        FTTE_HIP(c, hipMemcpy(c->d_bgroups, G.data(), sizeof(BrickGroup) * G.size(), hipMemcpyHostToDevice)); c->bgroups_sent.clear();
+    }
+    if ((rc = ensure(c, &c->d_uvb, &c->d_uvb_cap, (size_t)nnu))) return rc;
+    FTTE_HIP(c, hipMemcpy(c->d_uvb, uvb, sizeof(double) * nnu, hipMemcpyHostToDevice)); c->uvb_sent.clear();
+
+    // forest scratch: as forest_sweep, for the leaves of the plan's list only
+    const size_t per_dir = (size_t)3 * (size_t)std::max<int64_t>(H.ncells, 1) * nnu;
+    int batch = std::max(1, std::min(ndir, kAmrBatch));
+    if (c->amr_scratch_cap < per_dir * (size_t)batch) {
+        if (c->amr_Iout) { FTTE_HIP(c, hipFree(c->amr_Iout)); c->amr_Iout = nullptr; }
+        if (c->amr_mean) { FTTE_HIP(c, hipFree(c->amr_mean)); c->amr_mean = nullptr; }
+        c->amr_scratch_cap = 0;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)batch, (size_t)(0.9 * (double)free_b) / (2 * sizeof(double) * per_dir)));
+        FTTE_HIP(c, hipMalloc((void **)&c->amr_Iout, sizeof(double) * per_dir * (size_t)batch));
+        FTTE_HIP(c, hipMalloc((void **)&c->amr_mean, sizeof(double) * per_dir * (size_t)batch));
+        c->amr_scratch_cap = per_dir * (size_t)batch;
+    } else batch = (int)std::min<size_t>((size_t)kAmrBatch, c->amr_scratch_cap / per_dir);
+    if (nnu > 96) return FTTE_OK; // the cell-major copy of kappa is what the level kernel reads here: leave it to the forest path
+    if ((rc = ensure(c, &c->amr_kappa, &c->amr_kappa_cap, (size_t)nnu * (size_t)std::max<int64_t>(H.ncells, 1)))) return rc;
+    if (!c->kappa_ready[3] || c->amr_kappa_form != 1) {
+        if (launch_cell_major(c->kappa[0], c->amr_kappa, ncell, nnu, stream, H.cells, (long)H.ncells)) return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
+        c->kappa_ready[3] = true; c->amr_kappa_form = 1;
+    }
+
+    while (c->timing.size() < 1) {
+        LaunchTiming t;
+        FTTE_HIP(c, hipEventCreate(&t.start));
+        FTTE_HIP(c, hipEventCreate(&t.stop));
+        c->timing.push_back(t);
+    }
+    LaunchTiming &Tm = c->timing[0];
+    Tm.updates = (int64_t)ndir * ncell * nnu; Tm.lanes = 0;
+    c->timing_used = 0;
+    FTTE_HIP(c, hipEventRecord(Tm.start, stream));
+
+    // ---- opacity of the base cells in the three layouts; accumulators and J start from zero
+    if (launch_base_cells(c->kappa[0], c->d_leaf_of_base, c->base_kappa[0], (long)nbase, (long)ncell, nnu, stream))
+        return fail(c, FTTE_ERR_NO_DEVICE, "base-cell kernel launch failed");
+    for (int l = 1; l < 3; ++l)
+        if (P.nacc[l] && launch_to_layout(l, c->base_kappa[0], c->base_kappa[l], n, nnu, (long)nbase, stream))
+            return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
+    for (int l = 0; l < 3; ++l)
+        for (int s = 0; s < P.nacc[l]; ++s) FTTE_HIP(c, hipMemsetAsync(c->acc[l][s], 0, sizeof(double) * per_base, stream));
+    FTTE_HIP(c, hipMemsetAsync(J_dev, 0, sizeof(double) * (size_t)nnu * ncell, stream));
+
+    static const ftte_consts kMath = FTTE_CONSTS_INIT;
+    auto brick_stages = [&](int half, size_t from, size_t to, hipStream_t q) -> int {
+        const size_t *off = &H.stage_off[(size_t)half * H.nlist];
+        for (size_t l = from; l < to; ++l) {
+            if (off[l + 1] == off[l]) continue;
+            BrickLaunch L;
+            std::memset(&L, 0, sizeof L);
+            L.groups = c->d_bgroups;
+            L.tasks = c->d_btasks + off[l];
+            L.uvb = c->d_uvb;
+            L.group_stride = nbase;
+            L.face_stride = P.face_elems;
+            L.vface_off = P.vface_off; L.iface_off = P.iface_off;
+            L.n = n; L.ntasks = (int)(off[l + 1] - off[l]); L.nnu = nnu; L.nu0 = 0; L.chunk = P.chunk;
+            L.up = P.up; L.vp = P.vp; L.uw = P.uw; L.ut = P.ut; L.nslot = P.nslot;
+            L.math = kMath;
+            const int lrc = launch_brick(L, P.max_dirs, c->brick_waves, q);
+            if (lrc) return fail(c, lrc == -1 ? FTTE_ERR_ARG : FTTE_ERR_NO_DEVICE, "brick kernel launch failed");
+        }
+        return FTTE_OK;
+    };
+
+    // ---- per half: bricks not behind the boxes, the forests of the boxes (all directions of the half per depth launch), the
+    // bricks behind them.  The halves run side by side on two streams and meet only in J: the second half's means are added
+    // after the first half's (an event), the bricks' accumulators after both.
+    const int nh = (H.nhalves > 1 && batch >= ndir) ? H.nhalves : 1; // scratch for every direction at once, or one pipeline
+    hipStream_t qs[ftte_ctx::kMaxPipes] = {stream, stream, stream, stream};
+    if (nh > 1) {
+        while ((int)c->lane_stream.size() < nh - 1) {
+            hipStream_t q; hipEvent_t e;
+            FTTE_HIP(c, hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+            FTTE_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c->lane_stream.push_back(q); c->lane_done.push_back(e);
+        }
+        if (!c->ev_fork) FTTE_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        for (int r = 0; r < nh; ++r) {
+            if (!c->ev_combine[r]) FTTE_HIP(c, hipEventCreateWithFlags(&c->ev_combine[r], hipEventDisableTiming));
+            if (r) qs[r] = c->lane_stream[(size_t)r - 1];
+        }
+    }
+    AmrLevelRec A;
+    std::memset(&A, 0, sizeof A);
+    A.kappa = c->amr_kappa; A.emis = nullptr;
+    A.group_stride = 1; A.cell_stride = nnu;
+    A.emit = 0;
+    A.uvb = c->d_uvb;
+    A.ncell = ncell; A.nnu = nnu;
+    A.cells = H.cells; A.ncells = H.ncells;
+    A.face_stride = P.face_elems;
+    A.math = kMath;
+    std::vector<ForestRun> runs;
+    {
+        std::vector<std::vector<ForestDirHost>> sets((size_t)nh);
+        std::vector<int> slot0((size_t)nh, 0);
+        for (int h = 0; h < H.nhalves; ++h) {
+            const int to = nh > 1 ? h : 0;
+            for (int d : H.half_dirs[(size_t)h]) {
+                const ftte_ctx::HybridPlan::Dir &D = H.dirs[(size_t)d];
+                sets[(size_t)to].push_back(ForestDirHost{D.rec, D.active, P.dirs[(size_t)d].w, c->d_faces + (size_t)d * nnu * (size_t)P.face_elems,
+                                                         D.exports, D.nexports, &D.depth_off});
+            }
+        }
+        for (int r = 1; r < nh; ++r) slot0[(size_t)r] = slot0[(size_t)r - 1] + (int)sets[(size_t)r - 1].size();
+        // one batch per pipeline when they run side by side (their scratch must not overlap), else `batch` directions at a time
+        if ((rc = prepare_forests(c, stream, sets, slot0, nh > 1 ? ndir : batch, per_dir, &runs))) return rc;
+    }
+    if (nh > 1) {
+        FTTE_HIP(c, hipEventRecord(c->ev_fork, stream));
+        for (int r = 1; r < nh; ++r) FTTE_HIP(c, hipStreamWaitEvent(qs[r], c->ev_fork, 0));
+    }
+    // issued phase by phase, alternating between the streams, so that none waits for the host to finish with the others
+    for (int h = 0; h < H.nhalves; ++h)
+        if ((rc = brick_stages(h, 0, H.phase1_stages, qs[nh > 1 ? h : 0]))) return rc;
+    for (int r = 0; r < nh; ++r)
+        if ((rc = launch_forests(c, qs[r], runs[(size_t)r], A, J_dev, false, false, (nh > 1 && r > 0) ? c->ev_combine[r - 1] : nullptr,
+                                 (nh > 1 && r + 1 < nh) ? c->ev_combine[r] : nullptr))) return rc;
+    for (int h = 0; h < H.nhalves; ++h)
+        if ((rc = brick_stages(h, H.phase1_stages, H.nlist, qs[nh > 1 ? h : 0]))) return rc;
+    for (int r = 1; r < nh; ++r) {
+        FTTE_HIP(c, hipEventRecord(c->lane_done[(size_t)r - 1], qs[r]));
+        FTTE_HIP(c, hipStreamWaitEvent(stream, c->lane_done[(size_t)r - 1], 0));
+    }
+
+    // ---- J of the unrefined base cells += what the bricks stored (layout after layout, accumulator after accumulator)
+    {
+        const double *accs[3 * kMaxAcc];
+        int layouts[3 * kMaxAcc], count = 0;
+        for (int l = 0; l < 3; ++l)
+            for (int s = 0; s < P.nacc[l]; ++s) { accs[count] = c->acc[l][s]; layouts[count++] = l; }
+        if (count && launch_merge(accs, layouts, count, J_dev, n, nnu, (long)nbase, true, stream, c->d_leaf_of_base, (long)ncell))
+            return fail(c, FTTE_ERR_NO_DEVICE, "merge kernel launch failed");
+    }
+    FTTE_HIP(c, hipEventRecord(Tm.stop, stream));
+    c->timing_used = 1;
+    *done = true;
+    return mark_sweep(c, stream);
+}
+
+
+} // namespace ftte

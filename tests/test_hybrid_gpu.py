@@ -1,4 +1,4 @@
-"""Hybrid sweep of a refined cell array (csrc/ftte_api.cpp: hybrid_sweep): the brick kernel outside a box around the refined cells,
+"""Hybrid sweep of a refined cell array (csrc/ftte_hybrid.cpp: hybrid_sweep): the brick kernel outside a box around the refined cells,
 the segment forest inside it, rays handed over through the bricks' face buffers.  Against the oracle's tree sweep (the reference's
 setRaysRefined / findNeighbours / transport restated, pinned by the AMR goldens) with the device arithmetic -- bit for bit for a
 single direction, to summation order for several -- and against the forest path for the whole tree (option "hybrid" = 0)."""
