@@ -86,6 +86,24 @@ def test_hybrid_pipelines_agree(pipelines):
     assert np.allclose(J_a, J_default, rtol=SUM_RTOL, atol=0)
 
 
+def test_hybrid_more_directions_than_a_forest_batch():
+    """192 directions: more than one forest batch holds (96), so the pipelines cannot run side by side (their scratch would
+    overlap) and take turns on one stream instead, their forests in batches.  Same J as the forest path of the whole tree."""
+    n = 64
+    blocks = [(30 + a, 29 + b, 33 + c) for a in range(2) for b in range(3) for c in range(2)]
+    level, kappa, uvb = patch_case(n, blocks, 1, 2, seed=3)
+    phi, theta, w = O.healpix_directions(3)
+    assert len(phi) == 192
+    with rt.DiffuseTransfer() as e:
+        e.set_grid(n, level, 1.0)
+        e.set_opacity(kappa)
+        J_hybrid = e.transport(phi, theta, w, uvb)
+        assert np.array_equal(J_hybrid, e.transport(phi, theta, w, uvb))
+        e.set_option("hybrid", 0)
+        J_forest = e.transport(phi, theta, w, uvb)
+    assert np.allclose(J_hybrid, J_forest, rtol=SUM_RTOL, atol=0)
+
+
 def test_small_trees_stay_on_the_forest_path(golden):
     """Where the box around the refined cells takes up most of the grid (the AMR goldens: 8^3 and 6^3) nothing is left for the bricks:
     the whole tree goes through the forest, bit for bit as before."""
