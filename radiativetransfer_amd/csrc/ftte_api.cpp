@@ -295,6 +295,9 @@ int ftte_set_option(ftte_ctx *c, const char *key, int value)
         if (value != 0 && value != 1) return fail(c, FTTE_ERR_ARG, "hybrid must be 0 (a refined cell array goes through the forest path as a whole) or 1 (bricks outside a box around the refined cells)");
         c->hybrid = value;
         c->hplan.valid = false;
+    } else if (!std::strcmp(key, "forest_batch")) {
+        if (value < 0 || value > 65535) return fail(c, FTTE_ERR_ARG, "forest_batch (directions per launch of the segment forests) must be 1..65535, or 0 for the default");
+        c->forest_batch = value;
     } else if (!std::strcmp(key, "pipelines")) {
         if (value < 1 || value > ftte_ctx::kMaxPipes) return fail(c, FTTE_ERR_ARG, "pipelines (independent bricks-forests-bricks sequences of the hybrid sweep, each on a stream of its own) must be 1..4");
         c->halves = value;

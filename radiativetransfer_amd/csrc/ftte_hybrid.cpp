@@ -353,18 +353,20 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
 
     // forest scratch: as forest_sweep, for the leaves of the plan's list only
     const size_t per_dir = (size_t)3 * (size_t)std::max<int64_t>(H.ncells, 1) * nnu;
-    int batch = std::max(1, std::min(ndir, kAmrBatch));
+    // (numbered by the list, a direction's scratch is small: every direction at once, where the memory is there)
+    const int most = c->forest_batch > 0 ? c->forest_batch : 1024;
+    int batch = std::max(1, std::min(ndir, most));
     if (c->amr_scratch_cap < per_dir * (size_t)batch) {
         if (c->amr_Iout) { FTTE_HIP(c, hipFree(c->amr_Iout)); c->amr_Iout = nullptr; }
         if (c->amr_mean) { FTTE_HIP(c, hipFree(c->amr_mean)); c->amr_mean = nullptr; }
         c->amr_scratch_cap = 0;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-            batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)batch, (size_t)(0.9 * (double)free_b) / (2 * sizeof(double) * per_dir)));
+            batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)batch, (size_t)(0.6 * (double)free_b) / (2 * sizeof(double) * per_dir)));
         FTTE_HIP(c, hipMalloc((void **)&c->amr_Iout, sizeof(double) * per_dir * (size_t)batch));
         FTTE_HIP(c, hipMalloc((void **)&c->amr_mean, sizeof(double) * per_dir * (size_t)batch));
         c->amr_scratch_cap = per_dir * (size_t)batch;
-    } else batch = (int)std::min<size_t>((size_t)kAmrBatch, c->amr_scratch_cap / per_dir);
+    } else batch = (int)std::min<size_t>((size_t)most, c->amr_scratch_cap / per_dir);
     if (nnu > 96) return FTTE_OK; // the cell-major copy of kappa is what the level kernel reads here: leave it to the forest path
     if ((rc = ensure(c, &c->amr_kappa, &c->amr_kappa_cap, (size_t)nnu * (size_t)std::max<int64_t>(H.ncells, 1)))) return rc;
     if (!c->kappa_ready[3] || c->amr_kappa_form != 1) {

@@ -235,7 +235,8 @@ int forest_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
     // direction list, kAmrBatch and the free memory allow (two arrays of 3 ncell nnu doubles per direction: 38 GB for 48
     // directions of a 128^3 x 8 tree), and shrinks once more if the allocation still fails.
     const size_t per_dir = (size_t)nseg * nnu;
-    int batch = std::max(1, std::min(ndir, kAmrBatch));
+    const int most = c->forest_batch > 0 ? c->forest_batch : kAmrBatch;
+    int batch = std::max(1, std::min(ndir, most));
     if (c->amr_scratch_cap < per_dir * (size_t)batch) {
         FTTE_HIP(c, hipStreamSynchronize(stream));
         if (c->amr_Iout) { FTTE_HIP(c, hipFree(c->amr_Iout)); c->amr_Iout = nullptr; }
@@ -257,7 +258,7 @@ int forest_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
             batch = (batch + 1) / 2;
         }
         c->amr_scratch_cap = per_dir * (size_t)batch;
-    } else batch = (int)std::min<size_t>((size_t)kAmrBatch, c->amr_scratch_cap / per_dir);
+    } else batch = (int)std::min<size_t>((size_t)most, c->amr_scratch_cap / per_dir);
     FTTE_HIP(c, hipStreamSynchronize(stream)); // d_uvb below may still be read by the previous sweep
     if ((rc = ensure(c, &c->d_uvb, &c->d_uvb_cap, (size_t)nnu))) return rc;
     FTTE_HIP(c, hipMemcpy(c->d_uvb, uvb, sizeof(double) * nnu, hipMemcpyHostToDevice)); c->uvb_sent.clear();

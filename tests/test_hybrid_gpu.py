@@ -87,8 +87,9 @@ def test_hybrid_pipelines_agree(pipelines):
 
 
 def test_hybrid_more_directions_than_a_forest_batch():
-    """192 directions: more than one forest batch holds (96), so the pipelines cannot run side by side (their scratch would
-    overlap) and take turns on one stream instead, their forests in batches.  Same J as the forest path of the whole tree."""
+    """192 directions, first all at once, then with forest batches capped at 40 directions (what a tree too large for the
+    device memory gets): the pipelines can then not run side by side (their scratch would overlap) and take turns on one stream
+    instead, their forests in batches.  Same J either way, and as the forest path of the whole tree."""
     n = 64
     blocks = [(30 + a, 29 + b, 33 + c) for a in range(2) for b in range(3) for c in range(2)]
     level, kappa, uvb = patch_case(n, blocks, 1, 2, seed=3)
@@ -99,9 +100,13 @@ def test_hybrid_more_directions_than_a_forest_batch():
         e.set_opacity(kappa)
         J_hybrid = e.transport(phi, theta, w, uvb)
         assert np.array_equal(J_hybrid, e.transport(phi, theta, w, uvb))
+        e.set_option("forest_batch", 40)
+        J_batched = e.transport(phi, theta, w, uvb)
+        assert np.array_equal(J_batched, e.transport(phi, theta, w, uvb))
         e.set_option("hybrid", 0)
         J_forest = e.transport(phi, theta, w, uvb)
     assert np.allclose(J_hybrid, J_forest, rtol=SUM_RTOL, atol=0)
+    assert np.allclose(J_batched, J_forest, rtol=SUM_RTOL, atol=0)
 
 
 def test_small_trees_stay_on_the_forest_path(golden):
