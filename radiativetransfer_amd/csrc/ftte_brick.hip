@@ -64,8 +64,11 @@ __device__ __forceinline__ void brick_step(const ftte_consts &K, double (&cur)[k
                                            const double (&xs)[EMIT ? kBrickRows : 1],
                                            double (&Jacc)[kBrickRows], bool third_first, double d0, double d1, double d2,
                                            double w, double uvb, gcbyte *uin, gbyte *uout, gcbyte *vin, gbyte *vout, int lane, bool through = false,
-                                           bool same_launch = false)
+                                           bool same_launch = false, int take_lane = 0, int hand_lane = 63, bool active = true)
 {
+    // take_lane / hand_lane / active: a brick that sweeps only the lanes take_lane .. hand_lane (hybrid sweep of a refined cell
+    // array: the others belong to the segment forest).  The rays waiting in `uin` then enter lane take_lane, lane hand_lane hands
+    // its rays to `uout`, and only active lanes write to the v-face.  Defaults: the whole brick, nothing added to the code.
     constexpr bool HAS_U = SHAPE == RC_TWO_U || SHAPE == RC_THREE_U || SHAPE == RC_THREE_V;
     constexpr bool HAS_V = SHAPE == RC_TWO_V || SHAPE == RC_THREE_U || SHAPE == RC_THREE_V;
     double ui[kBrickRows];
@@ -85,7 +88,7 @@ __device__ __forceinline__ void brick_step(const ftte_consts &K, double (&cur)[k
         }
     }
     if (HAS_V && vin) carry = *(gcdouble *)(vin + 8 * lane);
-    const bool hands_u = HAS_U && uout != nullptr && lane == 63;
+    const bool hands_u = HAS_U && uout != nullptr && lane == hand_lane;
 
 #pragma unroll
     for (int r = 0; r < kBrickRows; ++r) {
@@ -98,6 +101,7 @@ __device__ __forceinline__ void brick_step(const ftte_consts &K, double (&cur)[k
         } else if (SHAPE == RC_TWO_U) {
             if (hands_u) { if (through) __hip_atomic_store((double *)(uout + 8 * r), I, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *(gdouble *)(uout + 8 * r) = I; }
             I = shift_up_inject(I, ui[r]);
+            if (take_lane) I = lane == take_lane ? ui[r] : I;
             acc += brick_segment<EMIT>(K, I, kap[r], xs[EMIT ? r : 0], d1);
             cur[r] = I;
             Jacc[r] += ftte_cell_mean(acc, 2, w);
@@ -110,6 +114,7 @@ __device__ __forceinline__ void brick_step(const ftte_consts &K, double (&cur)[k
         } else if (SHAPE == RC_THREE_U) { // 2nd piece one column on, 3rd one row on
             if (hands_u) { if (through) __hip_atomic_store((double *)(uout + 8 * r), I, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *(gdouble *)(uout + 8 * r) = I; }
             I = shift_up_inject(I, ui[r]);
+            if (take_lane) I = lane == take_lane ? ui[r] : I;
             const double m1 = brick_segment<EMIT>(K, I, kap[r], xs[EMIT ? r : 0], d1);
             double c = carry;
             carry = I;
@@ -125,6 +130,7 @@ __device__ __forceinline__ void brick_step(const ftte_consts &K, double (&cur)[k
             const double m1 = brick_segment<EMIT>(K, b, kap[r], xs[EMIT ? r : 0], d1);
             if (hands_u) { if (through) __hip_atomic_store((double *)(uout + 8 * r), b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *(gdouble *)(uout + 8 * r) = b; }
             b = shift_up_inject(b, ui[r]);
+            if (take_lane) b = lane == take_lane ? ui[r] : b;
             const double m2 = brick_segment<EMIT>(K, b, kap[r], xs[EMIT ? r : 0], d2);
             acc += third_first ? m2 : m1;
             acc += third_first ? m1 : m2;
@@ -134,14 +140,17 @@ __device__ __forceinline__ void brick_step(const ftte_consts &K, double (&cur)[k
         asm volatile("" : "+v"(Jacc[r]));
         __builtin_amdgcn_sched_barrier(0); // rows in program order: interleaved they multiply the live registers
     }
-    if (HAS_V && vout) { // the top row's ray goes on in the brick above
+    if (HAS_V && vout && active) { // the top row's ray goes on in the brick above
         if (through) __hip_atomic_store((double *)(vout + 8 * lane), carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else *(gdouble *)(vout + 8 * lane) = carry;
     }
 }
 
 // grid: ntasks * nnu workgroups of one wavefront; dynamic LDS: 4 KB per direction of the largest group
-template <int WAVES, int EMIT, bool FLOW>
+// MASKED: the tasks sweep a range of lanes only (BrickTask::tu carries it, kBrickLaneLoShift / kBrickLaneHiShift): the bricks of the
+// hybrid sweep that a box of the segment forest cuts through; rays cross between the two at 16-lane boundaries through faces of
+// their own.
+template <int WAVES, int EMIT, bool FLOW, bool MASKED = false>
 __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
 {
     extern __shared__ double state[]; // [slot][row][lane]: the rays of the directions that are not in registers
@@ -163,7 +172,11 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
     const int nu = L.nu0 + (int)(work % (unsigned)nnu);
     const unsigned task_index = work / (unsigned)nnu;
     const BrickTask T = L.tasks[task_index];
-    const int tu = uniform((int)T.tu), tv = uniform((int)T.tv), ti = uniform((int)T.ti) & (kBrickAccumulate - 1);
+    const int tu_field = uniform((int)T.tu);
+    const int tu = MASKED ? tu_field & kBrickTuMask : tu_field;
+    const int lane_lo = MASKED ? 16 * ((tu_field >> kBrickLaneLoShift) & 3) : 0;
+    const int lane_hi = MASKED ? 16 * ((tu_field >> kBrickLaneHiShift) & 3) + 15 : 63;
+    const int tv = uniform((int)T.tv), ti = uniform((int)T.ti) & (kBrickAccumulate - 1);
     const bool accumulate = (uniform((int)T.ti) & kBrickAccumulate) != 0;
     cgroup *G = (cgroup *)(L.groups + uniform((int)T.group));
     const int n = L.n, chunk = L.chunk, up = L.up, vp = L.vp;
@@ -182,20 +195,23 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
     const int cv0 = R * tv + 1;
     const int cuc = cu < n ? cu : n;
     const unsigned off0 = 8u * (unsigned)(mirror_u ? n + 1 - cuc : cuc);
-    const bool own_lane = cu <= n;
+    const bool own_lane = cu <= n && (!MASKED || (lane >= lane_lo && lane <= lane_hi));
     const long row_bytes = 8l * sv;
     const int i0 = ti * chunk + 1;
     const int i1 = (i0 + chunk - 1 < n) ? i0 + chunk - 1 : n;
 
-    const bool has_u_in = tu > 0, has_u_out = 64 * (tu + 1) < n;
+    const bool has_u_in = tu > 0 || lane_lo > 0, has_u_out = 64 * (tu + 1) < n || lane_hi < 63;
     const bool has_v_in = tv > 0, has_v_out = R * (tv + 1) < n;
     const bool has_i_in = ti > 0, has_i_out = i1 < n;
     const long fnu = (long)nu * L.face_stride;
     // element offsets inside a direction's face block (ftte_internal.h)
     const int uw = L.uw, ut = L.ut;
     const int ns = L.nslot, sl = ti % ns;
-    const long u_out = ((long)(tu * ns + sl) * chunk) * uw + ut * tv;
-    const long u_in = ((long)((tu - 1) * ns + sl) * chunk) * uw + ut * tv;
+    // the faces inside a brick, at lanes 16, 32, 48 (masked bricks only): three more rings laid out like the u-faces
+    const long u_out = lane_hi < 63 ? L.uqface_off + ((long)((tu * 3 + (lane_hi + 1) / 16 - 1) * ns + sl) * chunk) * uw + ut * tv
+                                    : ((long)(tu * ns + sl) * chunk) * uw + ut * tv;
+    const long u_in = lane_lo > 0 ? L.uqface_off + ((long)((tu * 3 + lane_lo / 16 - 1) * ns + sl) * chunk) * uw + ut * tv
+                                  : ((long)((tu - 1) * ns + sl) * chunk) * uw + ut * tv;
     const long v_out = L.vface_off + ((long)(tv * ns + sl) * chunk) * up + 64 * tu;
     const long v_in = L.vface_off + ((long)((tv - 1) * ns + sl) * chunk) * up + 64 * tu;
     const long i_in = L.iface_off + ((long)sl * vp + R * tv) * up + 64 * tu + lane;
@@ -304,15 +320,15 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
             gbyte *vout = has_v_out ? f + 8 * (v_out + (long)il * up) : nullptr;
             const bool third_first = rc == RC_THREE_U_SWAP || rc == RC_THREE_V_SWAP;
             switch (rc) {
-            case RC_ONE: brick_step<RC_ONE, EMIT>(L.math, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW); break;
-            case RC_TWO_U: brick_step<RC_TWO_U, EMIT>(L.math, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW); break;
-            case RC_TWO_V: brick_step<RC_TWO_V, EMIT>(L.math, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW); break;
+            case RC_ONE: brick_step<RC_ONE, EMIT>(L.math, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW, lane_lo, lane_hi, !MASKED || own_lane); break;
+            case RC_TWO_U: brick_step<RC_TWO_U, EMIT>(L.math, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW, lane_lo, lane_hi, !MASKED || own_lane); break;
+            case RC_TWO_V: brick_step<RC_TWO_V, EMIT>(L.math, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW, lane_lo, lane_hi, !MASKED || own_lane); break;
             case RC_THREE_U:
             case RC_THREE_U_SWAP:
-                brick_step<RC_THREE_U, EMIT>(L.math, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW);
+                brick_step<RC_THREE_U, EMIT>(L.math, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW, lane_lo, lane_hi, !MASKED || own_lane);
                 break;
             default:
-                brick_step<RC_THREE_V, EMIT>(L.math, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW);
+                brick_step<RC_THREE_V, EMIT>(L.math, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW, lane_lo, lane_hi, !MASKED || own_lane);
                 break;
             }
         }
@@ -336,6 +352,7 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const double leaving = j ? state[((j - 1) * R + r) * 64 + lane] : cur[r];
+                if (MASKED && !own_lane) continue; // the forest's lanes: its own rays wait there
                 if (through) __hip_atomic_store((double *)&f[i_out + (long)r * up], leaving, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 else f[i_out + (long)r * up] = leaving;
             }
@@ -511,13 +528,18 @@ int launch_brick_team(const BrickLaunch &L, int max_dirs, int waves, hipStream_t
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-int launch_brick(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stream)
+int launch_brick(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stream, bool masked)
 {
     if (L.ntasks <= 0) return 0;
     if (max_dirs < 1 || max_dirs > kBrickMaxDirs) return -1;
     const dim3 grid((unsigned)L.ntasks * (unsigned)L.nnu);
     const size_t lds = (size_t)(max_dirs - 1) * kBrickRows * 64 * sizeof(double) + (size_t)lds_pad(); // pad: diagnostic knob "ldspad"
     const bool flow = L.ticket != nullptr;
+    if (masked) {
+        if (L.emit || flow) return -1; // the hybrid sweep runs without emission, a launch per stage
+        hipLaunchKernelGGL((brick_kernel<3, 0, false, true>), grid, dim3(64), lds, stream, L); // (128 registers would spill 16)
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     // emission: the log-mean's own division and polynomials need more registers than three waves per SIMD leave
     if (L.emit == 1 && !flow) hipLaunchKernelGGL((brick_kernel<3, 1, false>), grid, dim3(64), lds, stream, L);
     else if (L.emit == 2 && !flow) hipLaunchKernelGGL((brick_kernel<3, 2, false>), grid, dim3(64), lds, stream, L);

@@ -82,6 +82,7 @@ struct BrickPlan {
     bool dataflow = false;             // one launch, bricks wait for each other through flags (needs whole bricks: n % 64 == 0)
     std::vector<int32_t> deps;         // [tasks][kBrickDeps]
     int ut = kBrickRows, uw = 0;       // u-face ring: doubles per brick and layer, per layer
+    int64_t uqface_off = 0;            // BrickLaunch::uqface_off
     int nslot = 2;                     // face slots along the march (BrickLaunch::nslot)
     int glanes = 1, nstages = 0;       // the groups are dealt to `glanes` streams (the groups of one accumulator stay together)
     std::vector<size_t> stage_off;     // [glanes][nstages + 1] into tasks
@@ -196,6 +197,7 @@ struct ftte_ctx {
     // Hybrid sweep of a refined cell array: bricks outside a box around the refined cells, the segment forest inside it
     int hybrid = 1;                       // option: 0 = the whole tree through the forest path
     int forest_batch = 0;                 // option: most directions per forest batch (0: what the path and the memory allow)
+    int hybrid_lanes = 16;                // option "box_lanes": the boxes of the hybrid sweep end on multiples of 16 lanes along u, or of 64
     int halves = 3;                       // option "pipelines": the hybrid sweep as this many independent pipelines on streams of their own (1..kMaxPipes)
     static constexpr int kMaxPipes = 4;
     hipEvent_t ev_combine[kMaxPipes] = {nullptr, nullptr, nullptr, nullptr}; // hybrid sweep: pipeline k's forest means are in J

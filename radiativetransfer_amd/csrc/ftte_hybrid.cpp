@@ -23,7 +23,11 @@ void free_hybrid(ftte_ctx *c)
     c->hplan = ftte_ctx::HybridPlan();
 }
 
-// the box of izone `izone`, sweep frame, tile-aligned and widened by a brick; false if the tree has no refined cell
+// The box of izone `izone` in the sweep frame: the refined base cells and a rim of unrefined ones, on brick boundaries along v and
+// the march axis (one brick of rim) and on multiples of 16 lanes along u (one cell of rim, then outwards to the next multiple):
+// a brick is 64 lanes wide, and whole bricks of rim would put every column of a 128^3 grid into the box of a 32^3 patch.  Bricks
+// that the box cuts through sweep the lanes outside it (brick_kernel<..., MASKED>).  tile_lo / tile_hi: the bricks the box
+// touches.  False if the tree has no refined cell.
 bool hybrid_region(const ftte_ctx *c, const BrickPlan &P, int izone, ForestRegion *R, int tile_lo[3], int tile_hi[3])
 {
     const AmrTree &T = c->tree;
@@ -51,15 +55,18 @@ bool hybrid_region(const ftte_ctx *c, const BrickPlan &P, int izone, ForestRegio
     const int size[3] = {P.chunk, 0, 0};
     (void)size;
     const int tsize_i = P.chunk, tsize_u = 64, tsize_v = kBrickRows;
-    tile_lo[0] = std::max(0, (slo[ju] - 1) / tsize_u - 1); tile_hi[0] = std::min(P.ntu - 1, (shi[ju] - 1) / tsize_u + 1);
+    const int lanes = c->hybrid_lanes; // 16, or 64: whole bricks along u as along the other axes
+    const int ulo = lanes == 64 ? std::max(0, (slo[ju] - 1) / 64 - 1) * 64 + 1 : std::max(0, (slo[ju] - 2) / lanes) * lanes + 1;
+    const int uhi = lanes == 64 ? std::min(n, (std::min(P.ntu - 1, (shi[ju] - 1) / 64 + 1) + 1) * 64) : std::min(n, (shi[ju] + lanes) / lanes * lanes);
+    tile_lo[0] = (ulo - 1) / tsize_u; tile_hi[0] = (uhi - 1) / tsize_u;
     tile_lo[1] = std::max(0, (slo[jv] - 1) / tsize_v - 1); tile_hi[1] = std::min(P.ntv - 1, (shi[jv] - 1) / tsize_v + 1);
     tile_lo[2] = std::max(0, (slo[0] - 1) / tsize_i - 1);  tile_hi[2] = std::min(P.nti - 1, (shi[0] - 1) / tsize_i + 1);
     R->u_is_k = u_is_k;
     R->lo[0] = tile_lo[2] * tsize_i + 1; R->hi[0] = std::min(n, (tile_hi[2] + 1) * tsize_i);
-    R->lo[ju] = tile_lo[0] * tsize_u + 1; R->hi[ju] = std::min(n, (tile_hi[0] + 1) * tsize_u);
+    R->lo[ju] = ulo; R->hi[ju] = uhi;
     R->lo[jv] = tile_lo[1] * tsize_v + 1; R->hi[jv] = std::min(n, (tile_hi[1] + 1) * tsize_v);
     R->chunk = P.chunk; R->ut = P.ut; R->nslot = P.nslot; R->ntv = P.ntv; R->up = P.up; R->vp = P.vp;
-    R->vface_off = P.vface_off; R->iface_off = P.iface_off;
+    R->vface_off = P.vface_off; R->iface_off = P.iface_off; R->uqface_off = P.uqface_off;
     return true;
 }
 
@@ -70,7 +77,7 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
     // short bricks: the box is widened by one brick on every side, and what lies inside it costs several times a brick's bytes
     const int chunk = std::min(c->chunk > 0 ? c->chunk : 4, n);
     const int gmax = c->group > 0 ? c->group : (nnu >= 2 ? 3 : 2);
-    std::vector<double> key = {c->box, (double)chunk, (double)gmax, (double)c->share, (double)c->halves};
+    std::vector<double> key = {c->box, (double)chunk, (double)gmax, (double)c->share, (double)c->halves, (double)c->hybrid_lanes};
     key.insert(key.end(), phi, phi + ndir);
     key.insert(key.end(), theta, theta + ndir);
     key.insert(key.end(), w, w + ndir);
@@ -82,13 +89,17 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
     P.glanes = 1;
 
     // the box of every group; is the part outside the boxes worth a brick sweep?
-    struct Box { ForestRegion R; int lo[3], hi[3]; bool any; };
+    struct Box { ForestRegion R; int lo[3], hi[3]; int ulo, uhi; bool any; }; // lo / hi: bricks (u, v, march axis); ulo / uhi: cells
     std::vector<Box> box(P.groups.size());
     int64_t inside_bricks = 0, all_bricks = 0;
     for (size_t g = 0; g < P.groups.size(); ++g) {
         box[g].any = hybrid_region(c, P, P.groups[g].izone, &box[g].R, box[g].lo, box[g].hi);
         all_bricks += (int64_t)P.ntu * P.ntv * P.nti;
-        if (box[g].any) inside_bricks += (int64_t)(box[g].hi[0] - box[g].lo[0] + 1) * (box[g].hi[1] - box[g].lo[1] + 1) * (box[g].hi[2] - box[g].lo[2] + 1);
+        if (box[g].any) {
+            const ForestRegion &R = box[g].R;
+            box[g].ulo = R.lo[R.u_is_k ? 2 : 1]; box[g].uhi = R.hi[R.u_is_k ? 2 : 1];
+            inside_bricks += (int64_t)(box[g].hi[0] - box[g].lo[0] + 1) * (box[g].hi[1] - box[g].lo[1] + 1) * (box[g].hi[2] - box[g].lo[2] + 1);
+        }
     }
     H.key = key;
     H.valid = true;
@@ -131,12 +142,22 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
     H.nlist = 2 * (size_t)per_phase;
     const size_t nlist = (size_t)H.nhalves * H.nlist;
     H.phase1_stages = (size_t)per_phase;
-    auto list_of = [&](size_t g, const Box &B, int tu, int tv, int ti, int offset) {
-        const bool behind = B.any && tu >= B.lo[0] && tv >= B.lo[1] && ti >= B.lo[2];
+    auto list_of = [&](size_t g, bool behind, int tu, int tv, int ti, int offset) {
         return (size_t)half_of_group[g] * H.nlist + (size_t)(behind ? per_phase : 0) + (size_t)(tu + tv + ti + offset);
     };
-    auto in_box = [&](const Box &B, int tu, int tv, int ti) {
-        return B.any && tu >= B.lo[0] && tu <= B.hi[0] && tv >= B.lo[1] && tv <= B.hi[1] && ti >= B.lo[2] && ti <= B.hi[2];
+    // What a group sweeps of brick (tu, tv, ti): nothing (the box holds it), all of it, or -- the box cuts through it along u --
+    // the lanes on the near side of the box (before the forests) and / or those on the far side (after them).
+    struct Piece { int lane_lo, lane_hi; bool behind, masked; };
+    auto pieces_of = [&](const Box &B, int tu, int tv, int ti, Piece out[2]) -> int {
+        const int last = std::min(63, n - 64 * tu - 1); // last lane with a cell
+        const bool behind = B.any && tu >= B.lo[0] && tv >= B.lo[1] && ti >= B.lo[2];
+        const bool in_vi = B.any && tv >= B.lo[1] && tv <= B.hi[1] && ti >= B.lo[2] && ti <= B.hi[2];
+        const int first_in = in_vi ? std::max(B.ulo, 64 * tu + 1) - (64 * tu + 1) : 64, last_in = in_vi ? std::min(B.uhi, 64 * tu + 64) - (64 * tu + 1) : -1;
+        if (first_in > last_in) { out[0] = Piece{0, 63, behind, false}; return 1; } // the box does not reach into this brick
+        int count = 0;
+        if (first_in > 0) out[count++] = Piece{0, first_in - 1, false, true};
+        if (last_in < last) out[count++] = Piece{last_in + 1, 63, true, true};
+        return count;
     };
     const size_t nb = (size_t)P.ntu * P.ntv * P.nti;
     std::vector<std::vector<size_t>> first(3 * (size_t)kMaxAcc);
@@ -145,7 +166,20 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
         const int bu = D0.su < 0 ? P.ntu - 1 - tu : tu, bv = D0.sv < 0 ? P.ntv - 1 - tv : tv, bi = D0.si < 0 ? P.nti - 1 - ti : ti;
         return ((size_t)bi * P.ntv + bv) * P.ntu + bu;
     };
-    H.stage_off.assign(nlist + 1, 0);
+    // Two sets of lists in one task array, [whole lists][masked lists]: the masked kernel (more registers, three waves per SIMD)
+    // takes every brick of a stage in which some brick is cut by a box -- two launches per stage would run one after the other,
+    // and a launch of a few bricks lasts as long as one of many --, the plain kernel the stages without.
+    std::vector<uint8_t> cut(nlist, 0);
+    for (size_t g = 0; g < P.groups.size(); ++g)
+        for (int ti = 0; ti < P.nti; ++ti)
+            for (int tv = 0; tv < P.ntv; ++tv)
+                for (int tu = 0; tu < P.ntu; ++tu) {
+                    Piece pc[2];
+                    const int np = pieces_of(box[g], tu, tv, ti, pc);
+                    for (int q = 0; q < np; ++q)
+                        if (pc[q].masked) cut[list_of(g, pc[q].behind, tu, tv, ti, P.groups[g].offset)] = 1;
+                }
+    H.stage_off.assign(2 * nlist + 1, 0);
     for (size_t g = 0; g < P.groups.size(); ++g) {
         const BrickPlan::Group &G = P.groups[g];
         std::vector<size_t> &F = first[(size_t)G.layout * kMaxAcc + G.acc];
@@ -153,15 +187,18 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
         for (int ti = 0; ti < P.nti; ++ti)
             for (int tv = 0; tv < P.ntv; ++tv)
                 for (int tu = 0; tu < P.ntu; ++tu) {
-                    if (in_box(box[g], tu, tv, ti)) continue;
-                    const size_t l = list_of(g, box[g], tu, tv, ti, G.offset);
-                    ++H.stage_off[l + 1];
-                    size_t &f = F[brick_of(G, tu, tv, ti)];
-                    f = std::min(f, l);
+                    Piece pc[2];
+                    const int np = pieces_of(box[g], tu, tv, ti, pc);
+                    for (int q = 0; q < np; ++q) {
+                        const size_t l = list_of(g, pc[q].behind, tu, tv, ti, G.offset);
+                        ++H.stage_off[(cut[l] ? nlist : 0) + l + 1];
+                        size_t &f = F[brick_of(G, tu, tv, ti)];
+                        f = std::min(f, l);
+                    }
                 }
     }
-    for (size_t l = 0; l < nlist; ++l) H.stage_off[l + 1] += H.stage_off[l];
-    P.tasks.resize(H.stage_off[nlist]);
+    for (size_t l = 0; l < 2 * nlist; ++l) H.stage_off[l + 1] += H.stage_off[l];
+    P.tasks.resize(H.stage_off[2 * nlist]);
     std::vector<size_t> fill(H.stage_off.begin(), H.stage_off.end() - 1);
     H.brick_updates = 0;
     for (size_t g = 0; g < P.groups.size(); ++g) {
@@ -170,16 +207,23 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
         for (int ti = 0; ti < P.nti; ++ti)
             for (int tv = 0; tv < P.ntv; ++tv)
                 for (int tu = 0; tu < P.ntu; ++tu) {
-                    if (in_box(box[g], tu, tv, ti)) continue;
-                    const size_t l = list_of(g, box[g], tu, tv, ti, G.offset);
-                    BrickTask T;
-                    T.group = (int16_t)g; T.tu = (int16_t)tu; T.tv = (int16_t)tv;
-                    T.ti = (int16_t)(ti | (l > F[brick_of(G, tu, tv, ti)] ? kBrickAccumulate : 0));
-                    P.tasks[fill[l]++] = T;
-                    const int64_t cu = std::min(64, n - 64 * tu), cv = std::min(kBrickRows, n - kBrickRows * tv), ci = std::min(chunk, n - chunk * ti);
-                    H.brick_updates += cu * cv * ci * (int64_t)G.dirs.size();
+                    Piece pc[2];
+                    const int np = pieces_of(box[g], tu, tv, ti, pc);
+                    for (int q = 0; q < np; ++q) {
+                        const size_t l = list_of(g, pc[q].behind, tu, tv, ti, G.offset);
+                        BrickTask T;
+                        T.group = (int16_t)g; T.tv = (int16_t)tv;
+                        T.tu = (int16_t)(cut[l] ? tu | ((pc[q].lane_lo / 16) << kBrickLaneLoShift) | ((pc[q].lane_hi / 16) << kBrickLaneHiShift) : tu);
+                        // (two pieces of one brick write different lanes of rows that start from zero: either may come first)
+                        T.ti = (int16_t)(ti | (l > F[brick_of(G, tu, tv, ti)] ? kBrickAccumulate : 0));
+                        P.tasks[fill[(cut[l] ? nlist : 0) + l]++] = T;
+                        const int64_t cu = std::max(0, std::min(pc[q].lane_hi, n - 64 * tu - 1) - pc[q].lane_lo + 1), cv = std::min(kBrickRows, n - kBrickRows * tv),
+                                      ci = std::min(chunk, n - chunk * ti);
+                        H.brick_updates += cu * cv * ci * (int64_t)G.dirs.size();
+                    }
                 }
     }
+    if (P.ntu > kBrickTuMask) { free_hybrid(c); return fail(c, FTTE_ERR_UNSUPPORTED, "hybrid sweep: more than 1023 bricks along a row"); }
 
     // The forests, restricted to the boxes: linked on the host a few directions at a time.  Once the leaves that lie in any box are
     // known they are numbered by their place in that list, and segments (3 * place + piece), activity bytes, opacities and scratch
@@ -396,9 +440,11 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
     FTTE_HIP(c, hipMemsetAsync(J_dev, 0, sizeof(double) * (size_t)nnu * ncell, stream));
 
     static const ftte_consts kMath = FTTE_CONSTS_INIT;
+    const size_t masked_lists = (size_t)H.nhalves * H.nlist;
     auto brick_stages = [&](int half, size_t from, size_t to, hipStream_t q) -> int {
-        const size_t *off = &H.stage_off[(size_t)half * H.nlist];
-        for (size_t l = from; l < to; ++l) {
+      for (size_t l = from; l < to; ++l)
+        for (int masked = 0; masked < 2; ++masked) { // the stage's whole bricks, then those a box cuts through
+            const size_t *off = &H.stage_off[(masked ? masked_lists : 0) + (size_t)half * H.nlist];
             if (off[l + 1] == off[l]) continue;
             BrickLaunch L;
             std::memset(&L, 0, sizeof L);
@@ -407,14 +453,14 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
             L.uvb = c->d_uvb;
             L.group_stride = nbase;
             L.face_stride = P.face_elems;
-            L.vface_off = P.vface_off; L.iface_off = P.iface_off;
+            L.vface_off = P.vface_off; L.iface_off = P.iface_off; L.uqface_off = P.uqface_off;
             L.n = n; L.ntasks = (int)(off[l + 1] - off[l]); L.nnu = nnu; L.nu0 = 0; L.chunk = P.chunk;
             L.up = P.up; L.vp = P.vp; L.uw = P.uw; L.ut = P.ut; L.nslot = P.nslot;
             L.math = kMath;
-            const int lrc = launch_brick(L, P.max_dirs, c->brick_waves, q);
+            const int lrc = launch_brick(L, P.max_dirs, c->brick_waves, q, masked != 0);
             if (lrc) return fail(c, lrc == -1 ? FTTE_ERR_ARG : FTTE_ERR_NO_DEVICE, "brick kernel launch failed");
         }
-        return FTTE_OK;
+      return FTTE_OK;
     };
 
     // ---- per half: bricks not behind the boxes, the forests of the boxes (all directions of the half per depth launch), the

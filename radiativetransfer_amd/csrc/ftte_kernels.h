@@ -12,7 +12,7 @@ void set_lds_pad(int bytes); // diagnostic: dynamic LDS per workgroup, to cap re
 int lds_pad();
 int launch_sweep(const LaunchRec &L, int rows, int waves, int stack, int nnu, hipStream_t stream);
 // one stage of the cell-fixed brick sweep; max_dirs: directions of the launch's largest group (sizes the LDS); waves 2..4
-int launch_brick(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stream);
+int launch_brick(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stream, bool masked = false);
 // the same stage by teams: one wavefront per direction of a group in one workgroup
 int launch_brick_team(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stream);
 // cell-array order -> layout 1 ([jc][ic][kc]) or 2 ([kc][ic][jc]); nnu groups, group_stride apart
