@@ -90,9 +90,12 @@ struct Builder {
         if (face == 0) return (int32_t)(R.iface_off + ((int64_t)(ti % R.nslot) * R.vp + (v - 1)) * R.up + (u - 1));
         const bool along_u = (face == 2) == R.u_is_k; // face 2 steps along sweep-k
         if (along_u) {
-            const int first_lane = (u - 1) % 64; // of the brick the ray enters; 0: it comes from the brick on the left
-            const int64_t ring = first_lane == 0 ? (int64_t)(tu - 1) : (int64_t)tu * 3 + first_lane / 16 - 1;
-            return (int32_t)((first_lane == 0 ? 0 : R.uqface_off) + ((ring * R.nslot + ti % R.nslot) * R.chunk + il) * ((int64_t)R.ntv * R.ut) +
+            // between two bricks: the u-face ring of the brick on the left.  Inside a brick (the box's u-faces need not lie on
+            // brick boundaries): the box's near face is ring 0, its far face ring 1 of the two rings at uqface_off
+            const bool between = (u - 1) % 64 == 0;
+            const int ju = R.u_is_k ? 2 : 1;
+            const int64_t ring = between ? (int64_t)(tu - 1) : (u == R.lo[ju] ? 0 : 1);
+            return (int32_t)((between ? 0 : R.uqface_off) + ((ring * R.nslot + ti % R.nslot) * R.chunk + il) * ((int64_t)R.ntv * R.ut) +
                              (int64_t)R.ut * tv + (v - 1) % kBrickRowsHost);
         }
         return (int32_t)(R.vface_off + (((int64_t)(tv - 1) * R.nslot + ti % R.nslot) * R.chunk + il) * R.up + (u - 1));

@@ -44,8 +44,8 @@ struct ForestRegion {
     int chunk = 1, ut = 8, nslot = 1;          // layers per brick, u-face doubles per brick and layer, face slots along the march
     int ntv = 1, up = 64, vp = 8;              // v bricks, padded extents
     int64_t vface_off = 0, iface_off = 0;      // as BrickLaunch
-    int64_t uqface_off = 0;                    // as BrickLaunch: where the u extent of the box is not a multiple of 64, rays
-                                               // cross its u faces inside a brick, at a multiple of 16 lanes
+    int64_t uqface_off = 0;                    // as BrickLaunch: the box's own two u-face rings, used where its u-faces lie
+                                               // inside a brick
     bool contains(int i, int j, int k) const { return i >= lo[0] && i <= hi[0] && j >= lo[1] && j <= hi[1] && k >= lo[2] && k <= hi[2]; }
 };
 

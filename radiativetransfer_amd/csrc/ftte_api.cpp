@@ -296,7 +296,7 @@ int ftte_set_option(ftte_ctx *c, const char *key, int value)
         c->hybrid = value;
         c->hplan.valid = false;
     } else if (!std::strcmp(key, "box_lanes")) {
-        if (value != 16 && value != 64) return fail(c, FTTE_ERR_ARG, "box_lanes (where the boxes of the hybrid sweep end along a brick's lanes) must be 16 or 64");
+        if (value < 1 || value > 64 || 64 % value) return fail(c, FTTE_ERR_ARG, "box_lanes (the boxes of the hybrid sweep end on multiples of it along a brick's 64 lanes) must divide 64");
         c->hybrid_lanes = value;
     } else if (!std::strcmp(key, "forest_batch")) {
         if (value < 0 || value > 65535) return fail(c, FTTE_ERR_ARG, "forest_batch (directions per launch of the segment forests) must be 1..65535, or 0 for the default");

@@ -147,9 +147,8 @@ __device__ __forceinline__ void brick_step(const ftte_consts &K, double (&cur)[k
 }
 
 // grid: ntasks * nnu workgroups of one wavefront; dynamic LDS: 4 KB per direction of the largest group
-// MASKED: the tasks sweep a range of lanes only (BrickTask::tu carries it, kBrickLaneLoShift / kBrickLaneHiShift): the bricks of the
-// hybrid sweep that a box of the segment forest cuts through; rays cross between the two at 16-lane boundaries through faces of
-// their own.
+// MASKED: the tasks sweep a range of lanes only (BrickTask::tu and ::group carry it): the bricks of the hybrid sweep that a box of
+// the segment forest cuts through; where the box's u-faces lie inside a brick, rays cross them through two face rings of their own.
 template <int WAVES, int EMIT, bool FLOW, bool MASKED = false>
 __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
 {
@@ -174,11 +173,12 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
     const BrickTask T = L.tasks[task_index];
     const int tu_field = uniform((int)T.tu);
     const int tu = MASKED ? tu_field & kBrickTuMask : tu_field;
-    const int lane_lo = MASKED ? 16 * ((tu_field >> kBrickLaneLoShift) & 3) : 0;
-    const int lane_hi = MASKED ? 16 * ((tu_field >> kBrickLaneHiShift) & 3) + 15 : 63;
+    const int group_field = uniform((int)T.group);
+    const int lane_lo = MASKED ? (tu_field >> kBrickLaneLoShift) & 63 : 0;
+    const int lane_hi = MASKED ? (group_field >> kBrickLaneHiShift) & 63 : 63;
     const int tv = uniform((int)T.tv), ti = uniform((int)T.ti) & (kBrickAccumulate - 1);
     const bool accumulate = (uniform((int)T.ti) & kBrickAccumulate) != 0;
-    cgroup *G = (cgroup *)(L.groups + uniform((int)T.group));
+    cgroup *G = (cgroup *)(L.groups + (MASKED ? group_field & kBrickGroupMask : group_field));
     const int n = L.n, chunk = L.chunk, up = L.up, vp = L.vp;
     const int ndir = G->ndir;
     const double uvb = L.uvb[nu];
@@ -207,11 +207,10 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
     // element offsets inside a direction's face block (ftte_internal.h)
     const int uw = L.uw, ut = L.ut;
     const int ns = L.nslot, sl = ti % ns;
-    // the faces inside a brick, at lanes 16, 32, 48 (masked bricks only): three more rings laid out like the u-faces
-    const long u_out = lane_hi < 63 ? L.uqface_off + ((long)((tu * 3 + (lane_hi + 1) / 16 - 1) * ns + sl) * chunk) * uw + ut * tv
-                                    : ((long)(tu * ns + sl) * chunk) * uw + ut * tv;
-    const long u_in = lane_lo > 0 ? L.uqface_off + ((long)((tu * 3 + lane_lo / 16 - 1) * ns + sl) * chunk) * uw + ut * tv
-                                  : ((long)((tu - 1) * ns + sl) * chunk) * uw + ut * tv;
+    // masked bricks: lanes that end inside the brick hand their rays to the box's near u-face (ring 0 at uqface_off), lanes that
+    // start inside it take theirs from the box's far u-face (ring 1)
+    const long u_out = lane_hi < 63 ? L.uqface_off + ((long)sl * chunk) * uw + ut * tv : ((long)(tu * ns + sl) * chunk) * uw + ut * tv;
+    const long u_in = lane_lo > 0 ? L.uqface_off + ((long)(ns + sl) * chunk) * uw + ut * tv : ((long)((tu - 1) * ns + sl) * chunk) * uw + ut * tv;
     const long v_out = L.vface_off + ((long)(tv * ns + sl) * chunk) * up + 64 * tu;
     const long v_in = L.vface_off + ((long)((tv - 1) * ns + sl) * chunk) * up + 64 * tu;
     const long i_in = L.iface_off + ((long)sl * vp + R * tv) * up + 64 * tu + lane;

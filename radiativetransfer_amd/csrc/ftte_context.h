@@ -197,7 +197,7 @@ struct ftte_ctx {
     // Hybrid sweep of a refined cell array: bricks outside a box around the refined cells, the segment forest inside it
     int hybrid = 1;                       // option: 0 = the whole tree through the forest path
     int forest_batch = 0;                 // option: most directions per forest batch (0: what the path and the memory allow)
-    int hybrid_lanes = 16;                // option "box_lanes": the boxes of the hybrid sweep end on multiples of 16 lanes along u, or of 64
+    int hybrid_lanes = 1;                 // option "box_lanes": along u the boxes of the hybrid sweep end on multiples of this many lanes
     int halves = 3;                       // option "pipelines": the hybrid sweep as this many independent pipelines on streams of their own (1..kMaxPipes)
     static constexpr int kMaxPipes = 4;
     hipEvent_t ev_combine[kMaxPipes] = {nullptr, nullptr, nullptr, nullptr}; // hybrid sweep: pipeline k's forest means are in J

@@ -24,7 +24,7 @@ void free_hybrid(ftte_ctx *c)
 }
 
 // The box of izone `izone` in the sweep frame: the refined base cells and a rim of unrefined ones, on brick boundaries along v and
-// the march axis (one brick of rim) and on multiples of 16 lanes along u (one cell of rim, then outwards to the next multiple):
+// the march axis (one brick of rim) and, along u, one cell of rim (option "box_lanes": then outwards to the next multiple of it):
 // a brick is 64 lanes wide, and whole bricks of rim would put every column of a 128^3 grid into the box of a 32^3 patch.  Bricks
 // that the box cuts through sweep the lanes outside it (brick_kernel<..., MASKED>).  tile_lo / tile_hi: the bricks the box
 // touches.  False if the tree has no refined cell.
@@ -55,7 +55,7 @@ bool hybrid_region(const ftte_ctx *c, const BrickPlan &P, int izone, ForestRegio
     const int size[3] = {P.chunk, 0, 0};
     (void)size;
     const int tsize_i = P.chunk, tsize_u = 64, tsize_v = kBrickRows;
-    const int lanes = c->hybrid_lanes; // 16, or 64: whole bricks along u as along the other axes
+    const int lanes = c->hybrid_lanes; // 1 (the rim and no more), a multiple such as 16, or 64: whole bricks along u as along the other axes
     const int ulo = lanes == 64 ? std::max(0, (slo[ju] - 1) / 64 - 1) * 64 + 1 : std::max(0, (slo[ju] - 2) / lanes) * lanes + 1;
     const int uhi = lanes == 64 ? std::min(n, (std::min(P.ntu - 1, (shi[ju] - 1) / 64 + 1) + 1) * 64) : std::min(n, (shi[ju] + lanes) / lanes * lanes);
     tile_lo[0] = (ulo - 1) / tsize_u; tile_hi[0] = (uhi - 1) / tsize_u;
@@ -212,8 +212,9 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
                     for (int q = 0; q < np; ++q) {
                         const size_t l = list_of(g, pc[q].behind, tu, tv, ti, G.offset);
                         BrickTask T;
-                        T.group = (int16_t)g; T.tv = (int16_t)tv;
-                        T.tu = (int16_t)(cut[l] ? tu | ((pc[q].lane_lo / 16) << kBrickLaneLoShift) | ((pc[q].lane_hi / 16) << kBrickLaneHiShift) : tu);
+                        T.tv = (int16_t)tv;
+                        T.group = (int16_t)(cut[l] ? (int)g | (pc[q].lane_hi << kBrickLaneHiShift) : (int)g);
+                        T.tu = (int16_t)(uint16_t)(cut[l] ? tu | (pc[q].lane_lo << kBrickLaneLoShift) : tu);
                         // (two pieces of one brick write different lanes of rows that start from zero: either may come first)
                         T.ti = (int16_t)(ti | (l > F[brick_of(G, tu, tv, ti)] ? kBrickAccumulate : 0));
                         P.tasks[fill[(cut[l] ? nlist : 0) + l]++] = T;
@@ -223,7 +224,7 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
                     }
                 }
     }
-    if (P.ntu > kBrickTuMask) { free_hybrid(c); return fail(c, FTTE_ERR_UNSUPPORTED, "hybrid sweep: more than 1023 bricks along a row"); }
+    if (P.ntu > kBrickTuMask || (int)P.groups.size() > kBrickGroupMask) { free_hybrid(c); return fail(c, FTTE_ERR_UNSUPPORTED, "hybrid sweep: more than 1023 bricks along a row, or more than 255 groups of directions"); }
 
     // The forests, restricted to the boxes: linked on the host a few directions at a time.  Once the leaves that lie in any box are
     // known they are numbered by their place in that list, and segments (3 * place + piece), activity bytes, opacities and scratch

@@ -226,7 +226,7 @@ int plan_brick_groups(ftte_ctx *c, BrickPlan &P, int ndir, const double *phi, co
     P.iface_off = P.vface_off + (int64_t)P.ntv * P.nslot * chunk * P.up;
     P.uqface_off = P.iface_off + (int64_t)P.nslot * P.vp * P.up;
     // (the faces inside a brick are used by the hybrid sweep only, which keeps every chunk's faces)
-    P.face_elems = P.uqface_off + (whole_faces ? 3 * (int64_t)P.ntu * P.nslot * chunk * P.uw : 0);
+    P.face_elems = P.uqface_off + (whole_faces ? 2 * (int64_t)P.nslot * chunk * P.uw : 0);
 
     if (P.nti >= kBrickAccumulate) return fail(c, FTTE_ERR_UNSUPPORTED, "brick engine: more than 16383 chunks along the march axis: raise option \"chunk\"");
 

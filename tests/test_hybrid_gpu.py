@@ -87,11 +87,11 @@ def test_hybrid_pipelines_agree(pipelines):
 
 
 def test_boxes_cut_through_bricks_or_end_on_brick_boundaries():
-    """Along a brick's 64 lanes the boxes end on multiples of 16 (option "box_lanes", default) and the bricks they cut through
-    sweep the lanes outside (brick_kernel<..., MASKED>: rays cross at lanes 16 / 32 / 48 through faces of their own), or they end on
-    brick boundaries (64).  A patch in the middle of a 128^3 row of two bricks leaves lanes on the near side of the first brick and
-    on the far side of the second; one near the edge leaves both sides in one brick.  Same J to the rounding of the sum, bit for
-    bit for a single direction."""
+    """Along a brick's 64 lanes the boxes end one cell beyond the refined cells (option "box_lanes" = 1, default; 16: on the next
+    multiple of 16) and the bricks they cut through sweep the lanes outside (brick_kernel<..., MASKED>: rays cross the box's
+    u-faces inside a brick through two face rings of their own), or they end on brick boundaries (64).  A patch in the middle of
+    a 128^3 row of two bricks leaves lanes on the near side of the first brick and on the far side of the second; one near the
+    edge leaves both sides in one brick.  Same J to the rounding of the sum, bit for bit for a single direction."""
     n = 128
     for blocks in ([(60 + a, 70 + b, 66 + c) for a in range(3) for b in range(2) for c in range(8)],      # straddles lanes 63 | 64 of u = k
                    [(30 + a, 90 + b, 20 + c) for a in range(2) for b in range(2) for c in range(3)]):    # inside the first brick
@@ -102,6 +102,8 @@ def test_boxes_cut_through_bricks_or_end_on_brick_boundaries():
             e.set_opacity(kappa)
             J16 = e.transport(phi, theta, w, uvb)
             one16 = [e.transport(phi[d:d + 1], theta[d:d + 1], w[d:d + 1], uvb) for d in (0, 17, 40)]
+            e.set_option("box_lanes", 16)
+            assert np.allclose(e.transport(phi, theta, w, uvb), J16, rtol=SUM_RTOL, atol=0)
             e.set_option("box_lanes", 64)
             J64 = e.transport(phi, theta, w, uvb)
             one64 = [e.transport(phi[d:d + 1], theta[d:d + 1], w[d:d + 1], uvb) for d in (0, 17, 40)]

@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/mask
 timeout -k 10 900 python -m pytest tests/test_hybrid_gpu.py tests/test_configs_gpu.py -x -q -m gpu 2>&1 | tail -15 || exit 1
-for lanes in 16 64; do
+for lanes in 1 16 64; do
 timeout -k 10 300 python3 - <<PY 2>&1 | grep -v amdgpu.ids
 import sys, time, numpy as np, torch
 sys.path.insert(0, ".")
@@ -25,4 +25,4 @@ np.save("gpurun_out/mask/J$lanes.npy", J.cpu().numpy()[:, ::97])
 PY
 done
 python3 -c "
-import numpy as np; a=np.load('gpurun_out/mask/J16.npy'); b=np.load('gpurun_out/mask/J64.npy'); print('max rel diff 16 vs 64 lanes', np.abs(a-b).max()/np.abs(b).max(), np.abs(a/b-1).max())"
+import numpy as np; a=np.load('gpurun_out/mask/J1.npy'); b=np.load('gpurun_out/mask/J64.npy'); print('max rel diff 1 vs 64 lanes', np.abs(a-b).max()/np.abs(b).max(), np.abs(a/b-1).max())"
