@@ -115,13 +115,15 @@ int main()
             R.ntv = ntv; R.up = 64 * ntu; R.vp = 8 * ntv;
             R.vface_off = (int64_t)ntu * R.nslot * R.chunk * ((int64_t)ntv * R.ut);
             R.iface_off = R.vface_off + (int64_t)ntv * R.nslot * R.chunk * R.up;
-            const int64_t face_elems = R.iface_off + (int64_t)R.nslot * R.vp * R.up;
+            R.uqface_off = R.iface_off + (int64_t)R.nslot * R.vp * R.up;
+            const int64_t face_elems = R.uqface_off + 2 * (int64_t)R.nslot * R.chunk * ((int64_t)ntv * R.ut);
             R.u_is_k = (pix & 1) != 0;
-            // i and the v axis on brick boundaries, the u axis whole (a brick is wider than these grids)
+            // i and the v axis on brick boundaries; the u axis whole, or (every other direction) ending inside the brick, where the
+            // rays cross through the box's own two face rings
             const int iv = R.u_is_k ? 1 : 2, iu = R.u_is_k ? 2 : 1;
             R.lo[0] = 1 + R.chunk * (int)(rnd() * (n / R.chunk / 2)); R.hi[0] = std::min(n, R.lo[0] + R.chunk * (1 + (int)(rnd() * 2)) - 1);
             R.lo[iv] = 1; R.hi[iv] = n <= 8 ? n : 8;
-            R.lo[iu] = 1; R.hi[iu] = n;
+            R.lo[iu] = (pix % 10 == 0 && n > 8) ? 3 : 1; R.hi[iu] = (pix % 10 == 0 && n > 8) ? n - 2 : n;
             // (refined cells outside the box are not this routine's concern: the planner only builds boxes that hold them all;
             // here the box is arbitrary, so only trees whose refined cells it holds are restricted)
             bool holds_all = true;
