@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=256)
+    ap.add_argument("--n", "--grid", dest="n", type=int, default=256)  # (--grid: torch.distributed.run takes "--n" for an abbreviation of its own options)
     ap.add_argument("--nnu", type=int, default=8)
     ap.add_argument("--ndir", type=int, default=96, help="directions in all (per GPU with --weak)")
     ap.add_argument("--weak", action="store_true", help="96 directions per GPU instead of 96 in all")
@@ -74,6 +74,9 @@ def parse():
     ap.add_argument("--dataflow", type=int, default=-1, help="bricks: 1 one launch with flags (default where the grid allows), 0 a launch per stage")
     ap.add_argument("--lanes", type=int, default=0, help="bricks: streams the frequency groups are spread over")
     ap.add_argument("--ldspad", type=int, default=0, help="diagnostic: extra dynamic LDS per workgroup (bytes), to cap residency")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 ranks sharing GPU 0 with the collectives on host copies over gloo: exercises this script's multi-rank "
+                         "path on a one-GPU box (RCCL refuses two ranks on one device); the timings mean nothing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=0, help="grid size of the CPU sample (default: --n)")
     return ap.parse_args()
@@ -211,11 +214,16 @@ def main():
         a.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the sweep has no CPU path")
+    if a.rehearse_on_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from radiativetransfer_amd.distributed import Shard2D
     n, nnu = a.n, a.nnu
@@ -276,12 +284,13 @@ def main():
         if timed:
             ev[1].record()
         if world > 1:
+            Jx = J.cpu() if a.rehearse_on_one_gpu else J   # rehearsal: gloo moves host tensors
             if shard is None:
-                dist.all_reduce(J)
+                dist.all_reduce(Jx)
             elif a.exchange == "gather":
-                shard.combine(J, out=J_full)
+                shard.combine(Jx, out=None if a.rehearse_on_one_gpu else J_full)
             else:
-                shard.exchange(J)
+                shard.exchange(Jx)
         if timed:
             ev[2].record()
 
@@ -308,7 +317,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed, compute_ms, collective_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, compute_ms, collective_ms], dtype=torch.float64, device="cpu" if a.rehearse_on_one_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, compute_ms, collective_ms = (float(x) for x in t.tolist())
 

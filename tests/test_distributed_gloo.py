@@ -188,3 +188,24 @@ def test_frequency_by_direction_sharding_through_the_library(tmp_path, world, nn
     """The same layout with every rank sweeping its share on the GPU through libftte.so (the ranks share the one card of the
     test box; the exchange stays on gloo: RCCL needs one device per rank)."""
     _check_2d(tmp_path, world, nnu, 24, use_gpu=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks,exchange", [(2, "slabs"), (3, "slabs"), (2, "gather")])
+def test_bench_multi_rank_path_rehearsed_on_one_gpu(tmp_path, ranks, exchange):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), rehearsed on the one-GPU box:
+    the ranks share GPU 0 and the collectives run on host copies over gloo (RCCL refuses two ranks on one device).  Checks that
+    the script's multi-rank branch runs through and reports BASELINE's fixed workload, sharded."""
+    import json
+    import subprocess
+    port = 36500 + os.getpid() % 2000 + ranks
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1",
+           "--grid", "64", "--rehearse-on-one-gpu", "--exchange", exchange]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert run.returncode == 0, run.stderr[-3000:]
+    line = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == ranks and line["scaling"] == "strong" and line["steps"] == 2
+    assert line["config"]["ndir_total"] == 96 and line["config"]["nnu"] == 8
+    assert line["config"]["nnu_this_rank"] * line["config"]["ndir_this_rank"] * ranks >= 8 * 96   # (3 ranks: 32 directions each)
+    assert line["value"] > 0 and "cpu_baseline" not in line
