@@ -112,6 +112,31 @@ def test_boxes_cut_through_bricks_or_end_on_brick_boundaries():
             assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("corner", [0, 1])
+def test_refined_cells_on_the_domain_boundary(corner):
+    """A refined patch in a corner of the grid: the box ends on the domain boundary on three sides (inflow enters the forest
+    directly there, or its rays leave the grid) and cuts through the corner brick.  Every izone, single directions bit for bit
+    against the forest path of the whole tree; all 24 together to the rounding of the sum."""
+    n = 128
+    base = 0 if corner == 0 else n - 3
+    blocks = [(base + a, base + b, base + c) for a in range(3) for b in range(2) for c in range(3)]
+    level, kappa, uvb = patch_case(n, blocks, 1, 2, seed=7 + corner)
+    dirs = one_per_izone()
+    phi, theta = np.array([d[0] for d in dirs]), np.array([d[1] for d in dirs])
+    w = np.full(len(dirs), 1.0 / len(dirs))
+    with rt.DiffuseTransfer() as e:
+        e.set_grid(n, level, 1.0)
+        e.set_opacity(kappa)
+        J_all = e.transport(phi, theta, w, uvb)
+        singles = [e.transport(phi[d:d + 1], theta[d:d + 1], w[d:d + 1], uvb) for d in range(0, 24, 5)]
+        assert e.counter("forest_builds") >= 2
+        e.set_option("hybrid", 0)
+        J_forest = e.transport(phi, theta, w, uvb)
+        for k, d in enumerate(range(0, 24, 5)):
+            assert np.array_equal(singles[k], e.transport(phi[d:d + 1], theta[d:d + 1], w[d:d + 1], uvb)), f"direction {d}"
+    assert np.allclose(J_all, J_forest, rtol=SUM_RTOL, atol=0)
+
+
 def test_hybrid_more_directions_than_a_forest_batch():
     """192 directions, first all at once, then with forest batches capped at 40 directions (what a tree too large for the
     device memory gets): the pipelines can then not run side by side (their scratch would overlap) and take turns on one stream
