@@ -302,13 +302,28 @@ int ftte_host_unregister(ftte_ctx *ctx, void *ptr);
  * planner), "forest_builds" (per-direction segment forests of a refined cell array).  -1 for an unknown name. */
 long long ftte_counter(const ftte_ctx *ctx, const char *name);
 
-/* Tuning knobs: "rows" (rays per lane: 4, 8 or 16), "stack" (wavefronts per workgroup, stacked
- * along the row axis and exchanging their boundary row through LDS: 1, 2, 4 or 8), "slots"
- * (directions in flight per launch, 1..16), "waves" (waves per SIMD the sweep kernel's register
- * allocation is held to: 2..6), "forest" (1: use the refined-grid path on a uniform grid
- * too, for cross-checks).  Built variants: rows x stack = 4x{1,4,8}, 8x{1,2,4}, 16x1.
- * Results do not depend on any of them except through the order in which "slots" sums
- * directions.  Unknown keys return FTTE_ERR_ARG. */
+/* Tuning knobs.  0 means "automatic" where noted.  Results do not depend on any of them except through the order in which the
+ * directions' contributions are added into J (last bits); unknown keys return FTTE_ERR_ARG.
+ *   uniform grids
+ *     "engine"      0 automatic = 2 cell-fixed bricks, 1 ray-following tiles (3a)
+ *     "chunk"       bricks: layers per brick (0: 16, fewer with few frequency groups)
+ *     "group"       bricks: most directions of one izone that share a brick pass, 1..8 (0: 3)
+ *     "share"       bricks: groups sharing a J accumulator: 0 none, 1 the passes of one izone, 2 and izone pairs (default)
+ *     "lanes"       bricks: streams the frequency groups (or, with fewer groups than lanes, the direction groups) are spread over
+ *     "brick_waves" bricks: waves per SIMD the kernel is compiled for, 2..4
+ *     "dataflow"    bricks: 0 a launch per stage (default), 1 one launch whose bricks wait for each other, 2 the same with
+ *                   write-through stores
+ *     "team"        bricks: 1 = one wavefront per direction of a group instead of one per group
+ *     "rows", "stack", "slots", "waves"  tiles: rays per lane (4, 8, 16), wavefronts per workgroup (1, 2, 4, 8), directions in flight
+ *                   per launch (1..16), waves per SIMD (2..6); built variants rows x stack = 4x{1,4,8}, 8x{1,2,4}, 16x1
+ *   refined cell arrays
+ *     "hybrid"      1 bricks outside boxes around the refined cells, segment forests inside (default; 3b), 0 forests for the whole tree
+ *     "pipelines"   hybrid: independent bricks-forests-bricks sequences on streams of their own, 1..4 (default 3)
+ *     "box_lanes"   hybrid: along a brick's 64 lanes the boxes end on multiples of this (a divisor of 64; default 1: one cell beyond
+ *                   the refined cells)
+ *     "forest_batch" most directions per launch of the segment forests (0: what the path and the device memory allow)
+ *     "forest"      1: use the segment forests on a uniform grid too, for cross-checks
+ *   "ldspad"        diagnostic: extra dynamic LDS per workgroup (bytes), to cap residency */
 int ftte_set_option(ftte_ctx *ctx, const char *key, int value);
 /* Launch records of the last sweep (valid after the sweep's stream has been synchronised).
  * Each sweep-kernel launch is bracketed by HIP events on the stream it runs on. */
