@@ -52,8 +52,6 @@ bool hybrid_region(const ftte_ctx *c, const BrickPlan &P, int izone, ForestRegio
     const int fast_c = (march_c == 2) ? 1 : 2;
     const bool u_is_k = zm.src[fast_c] == 2;
     const int ju = u_is_k ? 2 : 1, jv = u_is_k ? 1 : 2; // sweep axes of u and v
-    const int size[3] = {P.chunk, 0, 0};
-    (void)size;
     const int tsize_i = P.chunk, tsize_u = 64, tsize_v = kBrickRows;
     const int lanes = c->hybrid_lanes; // 1 (the rim and no more), a multiple such as 16, or 64: whole bricks along u as along the other axes
     const int ulo = lanes == 64 ? std::max(0, (slo[ju] - 1) / 64 - 1) * 64 + 1 : std::max(0, (slo[ju] - 2) / lanes) * lanes + 1;

@@ -351,7 +351,6 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
     const bool lane_ends = pipe != nullptr;
     bool lane_layout[3] = {false, false, false};
     // accumulators and the opacity in the layouts the groups march through
-    bool transposed = false;
     for (int l = 0; l < 3; ++l) {
         for (int s = 0; s < P.nacc[l]; ++s)
             if (!c->acc[l][s]) FTTE_HIP(c, hipMalloc((void **)&c->acc[l][s], sizeof(double) * c->acc_cap));
@@ -362,7 +361,6 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
                     return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
                 c->kappa_ready[l] = true;
             } else lane_layout[l] = true;
-            transposed = true;
         }
         if (P.nacc[l] && c->emit_mode && !c->emis_ready[l]) {
             if (!c->emis[l]) FTTE_HIP(c, hipMalloc((void **)&c->emis[l], sizeof(double) * c->kappa_cap));
@@ -371,7 +369,6 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
             c->emis_ready[l] = true;
         }
     }
-    (void)transposed;
 
     if (!c->bplan_uploaded) {
         c->bgroups_sent.clear();
