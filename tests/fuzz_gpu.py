@@ -21,7 +21,7 @@ def main():
     eng = rt.DiffuseTransfer()
     worst = 0.0
     for case in range(cases):
-        n = int(rng.integers(3, 41))
+        n = int(rng.integers(3, 41)) if rng.random() < 0.8 else int(rng.choice([64, 70, 128]))
         nnu = int(rng.integers(1, 10))
         level_dirs = int(rng.integers(1, 4))
         phi, theta, _ = O.healpix_directions(level_dirs)
@@ -39,6 +39,12 @@ def main():
         kappa = rng.lognormal(0, 1.2, (nnu, nc)) * n * 10 ** rng.uniform(-2, 0.5) * (2.0 ** level)[None, :]
         uvb = 10 ** rng.uniform(-23, -20, nnu)
         eng.set_option("slots", slots)
+        # the organisation of the uniform-grid sweep: bricks with random shapes and sharing, now and then one launch with flags,
+        # now and then the ray-following tiles
+        opts = dict(engine=int(rng.choice([0, 0, 0, 1])), chunk=int(rng.choice([0, 1, 3, 4, 16, 32])), group=int(rng.integers(0, 6)),
+                    share=int(rng.integers(0, 3)), lanes=int(rng.integers(1, 5)), dataflow=int(rng.choice([0, 0, 0, 2])))
+        for k, v in opts.items():
+            eng.set_option(k, v)
         eng.set_grid(n, level, 1.0)
         eng.set_opacity(kappa)
         J = eng.transport(phi, theta, w, uvb)
@@ -50,7 +56,7 @@ def main():
         err = float(np.max(np.abs(J - ref) / np.abs(ref)))
         worst = max(worst, err)
         flag = "" if err < 1e-13 else "   <-- FAIL"
-        print(f"case {case:3d}: n={n:2d} nnu={nnu} ndir={pick.size:3d} slots={slots:2d} {'refined' if refined else 'uniform'} "
+        print(f"case {case:3d}: n={n:3d} nnu={nnu} ndir={pick.size:3d} slots={slots:2d} {opts} {'refined' if refined else 'uniform'} "
               f"cells={nc:6d}: max rel diff {err:.2e}{flag}", flush=True)
         if err >= 1e-13:
             sys.exit(1)
