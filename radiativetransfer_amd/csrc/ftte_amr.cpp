@@ -94,7 +94,7 @@ struct Builder {
             // brick boundaries): the box's near face is ring 0, its far face ring 1 of the two rings at uqface_off
             const bool between = (u - 1) % 64 == 0;
             const int ju = R.u_is_k ? 2 : 1;
-            const int64_t ring = between ? (int64_t)(tu - 1) : (u == R.lo[ju] ? 0 : 1);
+            const int64_t ring = between ? (int64_t)(tu - 1) : 2 * (int64_t)R.id + (u == R.lo[ju] ? 0 : 1);
             return (int32_t)((between ? 0 : R.uqface_off) + ((ring * R.nslot + ti % R.nslot) * R.chunk + il) * ((int64_t)R.ntv * R.ut) +
                              (int64_t)R.ut * tv + (v - 1) % kBrickRowsHost);
         }
@@ -238,6 +238,13 @@ struct Builder {
         }
     }
 
+    // every leaf under `node` belongs to a box swept in pass `pass`
+    void mark_inside(int32_t node, uint8_t pass, std::vector<uint8_t> &pass_of)
+    {
+        if (T.child0[node] < 0) { F.inside[(size_t)T.leaf[node]] = 1; pass_of[(size_t)T.leaf[node]] = pass; return; }
+        for (int c = 0; c < 8; ++c) mark_inside(T.child0[node] + c, pass, pass_of);
+    }
+
     // transport's recursion order, transportRoutinesModule.f90:577-586: children in sweep order
     void visit(int32_t node, int32_t pat, int lvl, double cell)
     {
@@ -259,18 +266,27 @@ struct Builder {
 int build_forest(const AmrTree &tree, double phi, double theta, int izone, double box, AmrForest *out, std::string *err,
                  const ForestRegion *region)
 {
+    std::vector<ForestRegion> regions;
+    if (region) regions.push_back(*region);
+    return build_forest_regions(tree, phi, theta, izone, box, out, err, regions);
+}
+
+int build_forest_regions(const AmrTree &tree, double phi, double theta, int izone, double box, AmrForest *out, std::string *err,
+                         const std::vector<ForestRegion> &regions)
+{
     AmrForest &F = *out;
     const int n = tree.n;
     const int64_t nseg = 3 * tree.ncell;
+    const bool restricted = !regions.empty();
     F.izone = izone; F.phi = phi; F.theta = theta;
     F.up.assign(nseg, AmrForest::kInactive);
     F.up2.assign(nseg, -1);
     F.dpath.assign(nseg, 0.0);
 
     F.import_at.clear(); F.exports.clear(); F.inside.clear();
-    if (region) { F.import_at.assign(nseg, -1); F.inside.assign((size_t)tree.ncell, 0); }
+    if (restricted) { F.import_at.assign(nseg, -1); F.inside.assign((size_t)tree.ncell, 0); }
     Builder B(tree, F);
-    B.izone = izone; B.phi = phi; B.theta = theta; B.reg = region;
+    B.izone = izone; B.phi = phi; B.theta = theta; B.reg = nullptr;
     for (int i = 0; i < 2; ++i)
         for (int j = 0; j < 2; ++j)
             for (int k = 0; k < 2; ++k) {
@@ -289,26 +305,49 @@ int build_forest(const AmrTree &tree, double phi, double theta, int izone, doubl
     B.depth.assign(nseg, 0);
 
     const double cell = box / (double)n; // equiSources.f90:1570
-    for (int i = 1; i <= n && !B.status; ++i)
-        for (int j = 1; j <= n && !B.status; ++j)
-            for (int k = 1; k <= n && !B.status; ++k) {
-                int ic, jc, kc;
-                rotate_indices(i, j, k, n, n, n, izone, &ic, &jc, &kc);
-                B.seq[0][0] = i; B.seq[0][1] = j; B.seq[0][2] = k;
-                if (region && !region->contains(i, j, k)) continue;
-                B.visit((int32_t)(((int64_t)(ic - 1) * n + (jc - 1)) * n + (kc - 1)), i - 1, 0, cell);
-            }
-    if (B.status) { *err = B.err; return B.status; }
-    if (region) {
-        for (size_t v = 0; v < tree.parent.size(); ++v)
-            if (B.node_pat[v] >= 0 && tree.leaf[v] >= 0) F.inside[(size_t)tree.leaf[v]] = 1;
-        // the rays that leave the region: for every base cell just outside its far faces, the piece of the cell inside that
-        // ends on the shared face (same rule as a link inside the forest; the rim cells are unrefined base cells)
-        const ForestRegion &R = *region;
+    // pass of every leaf that belongs to a box (0 without boxes); exports carry their box's pass until they are sorted
+    std::vector<uint8_t> pass_of;
+    std::vector<int> export_pass;
+    int npass = 1;
+    if (restricted) {
+        pass_of.assign((size_t)tree.ncell, 0);
+        for (const ForestRegion &R : regions) {
+            if (R.pass < 0 || R.pass > 254) { *err = "hybrid sweep: too many passes"; return FTTE_ERR_STATE; }
+            npass = std::max(npass, R.pass + 1);
+        }
+    }
+    const size_t nreg = restricted ? regions.size() : 1;
+    for (size_t r = 0; r < nreg && !B.status; ++r) {
+        const ForestRegion *R = restricted ? &regions[r] : nullptr;
+        B.reg = R;
+        const int lo0 = R ? std::max(1, R->lo[0]) : 1, hi0 = R ? std::min(n, R->hi[0]) : n;
+        const int lo1 = R ? std::max(1, R->lo[1]) : 1, hi1 = R ? std::min(n, R->hi[1]) : n;
+        const int lo2 = R ? std::max(1, R->lo[2]) : 1, hi2 = R ? std::min(n, R->hi[2]) : n;
+        for (int i = lo0; i <= hi0 && !B.status; ++i)
+            for (int j = lo1; j <= hi1 && !B.status; ++j)
+                for (int k = lo2; k <= hi2 && !B.status; ++k) {
+                    int ic, jc, kc;
+                    rotate_indices(i, j, k, n, n, n, izone, &ic, &jc, &kc);
+                    B.seq[0][0] = i; B.seq[0][1] = j; B.seq[0][2] = k;
+                    const int32_t node = (int32_t)(((int64_t)(ic - 1) * n + (jc - 1)) * n + (kc - 1));
+                    if (R && B.node_pat[node] >= 0) { *err = "hybrid sweep: two boxes overlap"; return FTTE_ERR_STATE; }
+                    B.visit(node, i - 1, 0, cell);
+                }
+        if (B.status) break;
+        if (!R) continue;
+        // the leaves of this box, and the rays that leave it: for every base cell just outside its far faces, the piece of the
+        // cell inside that ends on the shared face (same rule as a link inside the forest; the rim cells are unrefined base cells)
+        for (int i = lo0; i <= hi0; ++i)
+            for (int j = lo1; j <= hi1; ++j)
+                for (int k = lo2; k <= hi2; ++k) {
+                    int ic, jc, kc;
+                    rotate_indices(i, j, k, n, n, n, izone, &ic, &jc, &kc);
+                    B.mark_inside((int32_t)(((int64_t)(ic - 1) * n + (jc - 1)) * n + (kc - 1)), (uint8_t)R->pass, pass_of);
+                }
         for (int face = 0; face < 3; ++face) {
-            if (R.hi[face] >= n) continue; // the region reaches the domain boundary: the rays leave the grid
-            int lo[3] = {R.lo[0], R.lo[1], R.lo[2]}, hi[3] = {R.hi[0], R.hi[1], R.hi[2]};
-            lo[face] = hi[face] = R.hi[face]; // the region's last layer of cells along this axis
+            if (R->hi[face] >= n) continue; // the box reaches the domain boundary: the rays leave the grid
+            int lo[3] = {lo0, lo1, lo2}, hi[3] = {hi0, hi1, hi2};
+            lo[face] = hi[face] = R->hi[face]; // the box's last layer of cells along this axis
             for (int i = lo[0]; i <= hi[0]; ++i)
                 for (int j = lo[1]; j <= hi[1]; ++j)
                     for (int k = lo[2]; k <= hi[2]; ++k) {
@@ -321,20 +360,37 @@ int build_forest(const AmrTree &tree, double phi, double theta, int izone, doubl
                         if (top == 0) continue; // no piece of this layer's pattern ends on that face: nothing crosses it
                         const int di = i + (face == 0), dj = j + (face == 1), dk = k + (face == 2);
                         F.exports.push_back({B.face_element(di, dj, dk, face), (int32_t)(3 * tree.leaf[U] + Builder::slot_of(top))});
+                        export_pass.push_back(R->pass);
                     }
         }
     }
+    if (B.status) { *err = B.err; return B.status; }
 
-    // counting sort of the active segments by depth
-    int32_t maxd = 0;
-    for (int64_t s = 0; s < nseg; ++s) if (F.up[s] != AmrForest::kInactive) maxd = std::max(maxd, B.depth[s]);
-    F.depth_off.assign((size_t)maxd + 2, 0);
-    for (int64_t s = 0; s < nseg; ++s) if (F.up[s] != AmrForest::kInactive) ++F.depth_off[B.depth[s] + 1];
+    // counting sort of the active segments by (pass, depth)
+    std::vector<int32_t> maxd((size_t)npass, -1);
+    auto pass_of_seg = [&](int64_t s) { return restricted ? (int)pass_of[(size_t)(s / 3)] : 0; };
+    auto listed = [&](int64_t s) { return F.up[s] != AmrForest::kInactive && (!restricted || F.inside[(size_t)(s / 3)]); };
+    for (int64_t s = 0; s < nseg; ++s) if (listed(s)) maxd[(size_t)pass_of_seg(s)] = std::max(maxd[(size_t)pass_of_seg(s)], B.depth[s]);
+    F.pass_first.assign((size_t)npass + 1, 0);
+    for (int p = 0; p < npass; ++p) F.pass_first[(size_t)p + 1] = F.pass_first[(size_t)p] + (maxd[(size_t)p] + 1);
+    const size_t ndepth = (size_t)F.pass_first[(size_t)npass];
+    F.depth_off.assign(ndepth + 1, 0);
+    for (int64_t s = 0; s < nseg; ++s) if (listed(s)) ++F.depth_off[(size_t)F.pass_first[(size_t)pass_of_seg(s)] + (size_t)B.depth[s] + 1];
     for (size_t d = 1; d < F.depth_off.size(); ++d) F.depth_off[d] += F.depth_off[d - 1];
     F.order.resize((size_t)F.depth_off.back());
     std::vector<int64_t> cursor(F.depth_off.begin(), F.depth_off.end() - 1);
     for (int64_t s = 0; s < nseg; ++s)
-        if (F.up[s] != AmrForest::kInactive) F.order[(size_t)cursor[B.depth[s]]++] = (int32_t)s;
+        if (listed(s)) F.order[(size_t)cursor[(size_t)F.pass_first[(size_t)pass_of_seg(s)] + (size_t)B.depth[s]]++] = (int32_t)s;
+    // the rays that leave the boxes, pass after pass
+    F.export_first.assign((size_t)npass + 1, 0);
+    if (!F.exports.empty()) {
+        std::vector<AmrForest::Export> sorted(F.exports.size());
+        for (int p : export_pass) ++F.export_first[(size_t)p + 1];
+        for (int p = 0; p < npass; ++p) F.export_first[(size_t)p + 1] += F.export_first[(size_t)p];
+        std::vector<int64_t> at(F.export_first.begin(), F.export_first.end() - 1);
+        for (size_t q = 0; q < F.exports.size(); ++q) sorted[(size_t)at[(size_t)export_pass[q]]++] = F.exports[q];
+        F.exports.swap(sorted);
+    }
     return 0;
 }
 

@@ -44,8 +44,11 @@ struct ForestRegion {
     int chunk = 1, ut = 8, nslot = 1;          // layers per brick, u-face doubles per brick and layer, face slots along the march
     int ntv = 1, up = 64, vp = 8;              // v bricks, padded extents
     int64_t vface_off = 0, iface_off = 0;      // as BrickLaunch
-    int64_t uqface_off = 0;                    // as BrickLaunch: the box's own two u-face rings, used where its u-faces lie
-                                               // inside a brick
+    int64_t uqface_off = 0;                    // as BrickLaunch: the boxes' own u-face rings (two per box: 2 * id, 2 * id + 1),
+                                               // used where a box's u-faces lie inside a brick
+    int id = 0;                                // which box of the direction this is (its pair of rings)
+    int pass = 0;                              // the boxes of a direction are swept in passes (a box behind another one waits
+                                               // for the bricks in between): this box's pass
     bool contains(int i, int j, int k) const { return i >= lo[0] && i <= hi[0] && j >= lo[1] && j <= hi[1] && k >= lo[2] && k <= hi[2]; }
 };
 
@@ -62,8 +65,10 @@ struct AmrForest {
     struct Export { int32_t at, seg; };  // face element <- outgoing intensity of segment `seg`
     std::vector<Export> exports;    // the rays that leave the region into a brick (region only)
     std::vector<uint8_t> inside;    // [ncell] the leaf belongs to the region (region only; empty = all)
-    std::vector<int32_t> order;  // active segments sorted by depth
-    std::vector<int64_t> depth_off; // [ndepth + 1] ranges of `order`
+    std::vector<int32_t> order;  // active segments sorted by pass, then depth
+    std::vector<int64_t> depth_off; // [ndepth + 1] ranges of `order`; the depths of all passes one after the other
+    std::vector<int32_t> pass_first;   // [npass + 1] where each pass starts in depth_off ({0, ndepth} without regions)
+    std::vector<int64_t> export_first; // [npass + 1] where each pass's rays start in `exports` (sorted by pass)
     int izone = 0;
     double phi = 0, theta = 0;
 };
@@ -73,5 +78,9 @@ struct AmrForest {
 // region (may be null): restrict the forest to the leaves of that box; links across its surface become imports / exports.
 int build_forest(const AmrTree &tree, double phi_folded, double theta_folded, int izone, double box, AmrForest *out,
                  std::string *err, const ForestRegion *region = nullptr);
+// The same restricted to several boxes that do not touch each other (a rim of unrefined base cells and at least one brick
+// between any two): one forest per box, ordered by the boxes' passes.
+int build_forest_regions(const AmrTree &tree, double phi_folded, double theta_folded, int izone, double box, AmrForest *out,
+                         std::string *err, const std::vector<ForestRegion> &regions);
 
 } // namespace ftte

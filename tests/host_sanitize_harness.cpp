@@ -146,6 +146,54 @@ int main()
             ++cases;
         }
     }
+    // two boxes that do not touch, swept in two passes: slabs along the march axis with a gap of two layers, on a tree whose
+    // refined cells lie in the slabs whatever the izone does to the axes
+    {
+        const int n = 12;
+        std::vector<int32_t> levels;
+        for (int b = 0; b < n * n * n; ++b) {
+            const int c3[3] = {b / (n * n) + 1, (b / n) % n + 1, b % n + 1};
+            bool fine = true;
+            for (int a = 0; a < 3; ++a) fine = fine && (c3[a] == 2 || c3[a] == 3 || c3[a] == 9 || c3[a] == 10);
+            if (fine && (c3[0] + c3[1] + c3[2]) % 2 == 0) for (int c = 0; c < 8; ++c) levels.push_back(1); else levels.push_back(0);
+        }
+        AmrTree T;
+        const std::string why2 = T.build(n, (int64_t)levels.size(), levels.data());
+        CHECK(why2.empty() && T.max_level == 1, "two-slab tree: %s (max level %d)", why2.c_str(), T.max_level);
+        for (int pix = 0; pix < 48; pix += 3) {
+            double phi_l, theta_l, phi, theta;
+            int izone;
+            CHECK(pix2ang_nest(2, pix, &phi_l, &theta_l) == 0 && fold_direction(phi_l, theta_l, &phi, &theta, &izone) == 0, "direction");
+            std::vector<ForestRegion> regions(2);
+            int64_t face_elems = 0;
+            for (int r = 0; r < 2; ++r) {
+                ForestRegion &R = regions[(size_t)r];
+                R.chunk = 1; R.ut = 8; R.nslot = n;
+                const int ntu = 1, ntv = 2;
+                R.ntv = ntv; R.up = 64; R.vp = 16;
+                R.vface_off = (int64_t)ntu * R.nslot * R.chunk * ((int64_t)ntv * R.ut);
+                R.iface_off = R.vface_off + (int64_t)ntv * R.nslot * R.chunk * R.up;
+                R.uqface_off = R.iface_off + (int64_t)R.nslot * R.vp * R.up;
+                face_elems = R.uqface_off + 4 * (int64_t)R.nslot * R.chunk * ((int64_t)ntv * R.ut);
+                R.u_is_k = true;
+                R.lo[0] = r == 0 ? 1 : 8; R.hi[0] = r == 0 ? 5 : 12;
+                R.lo[1] = 1; R.hi[1] = n; R.lo[2] = 1; R.hi[2] = n;
+                R.id = r; R.pass = r;
+            }
+            AmrForest F;
+            std::string err;
+            CHECK(build_forest_regions(T, phi, theta, izone, 1.0, &F, &err, regions) == 0, "two boxes: %s", err.c_str());
+            check_forest(T, F, &regions[0], face_elems);
+            CHECK(F.pass_first.size() == 3 && F.export_first.size() == 3 && F.pass_first[2] + 1 == (int32_t)F.depth_off.size(), "passes");
+            // the first pass holds the leaves of the first slab only
+            for (int64_t q = 0; q < F.depth_off[(size_t)F.pass_first[1]]; ++q) {
+                const int32_t leaf = F.order[(size_t)q] / 3;
+                CHECK(F.inside[(size_t)leaf], "pass 0 lists a leaf outside the boxes");
+            }
+            CHECK(F.export_first[1] > 0 && F.export_first[2] == (int64_t)F.exports.size(), "the first box hands rays on, the second reaches the boundary");
+            ++cases;
+        }
+    }
     // per-layer patterns of every direction of level 3
     for (int pix = 0; pix < 192; ++pix) {
         double phi_l, theta_l, phi, theta;
