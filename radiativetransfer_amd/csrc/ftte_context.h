@@ -212,7 +212,7 @@ struct ftte_ctx {
         std::vector<size_t> stage_off;    // into bricks.tasks: [half][list]
         int64_t brick_updates = 0;        // cell.direction updates the bricks perform (per frequency group)
         struct Dir { SegRec *rec = nullptr; uint8_t *active = nullptr; AmrExport *exports = nullptr; int64_t nexports = 0;
-                     std::vector<int64_t> depth_off; };
+                     std::vector<int64_t> depth_off; std::vector<int32_t> pass_first; std::vector<int64_t> export_first; };
         std::vector<Dir> dirs;
         int32_t *cells = nullptr; int64_t ncells = 0; // the leaves inside the box of at least one direction
         bool uploaded = false;
@@ -301,12 +301,15 @@ struct ForestDirHost {
     const SegRec *rec; const uint8_t *active; double w;
     double *faces; const AmrExport *exports; int64_t nexports; // hybrid sweep only, else null / 0
     const std::vector<int64_t> *depth_off;
+    const std::vector<int32_t> *pass_first;    // the passes of depth_off (AmrForest::pass_first), or null: one pass
+    const std::vector<int64_t> *export_first;  // the passes of exports, or null: all in the first
 };
 
 // A forest pass made ready: the per-direction records and the per-depth tables are in device memory (a batch of 96 would not
 // fit the kernel arguments), what is left is a list of launches.
 struct ForestRun {
-    struct Batch { int d0, nb; size_t table_at, most_at, maxdepth; int64_t most_exports; };
+    struct Pass { size_t table_at = 0, most_at = 0, maxdepth = 0, export_at = 0; int64_t most_exports = 0; };
+    struct Batch { int d0 = 0, nb = 0; std::vector<Pass> passes; };
     std::vector<Batch> batches;
     std::vector<int64_t> most_of;
     size_t dir_at = 0;
@@ -314,6 +317,8 @@ struct ForestRun {
 
 int prepare_forests(ftte_ctx *c, hipStream_t stream, const std::vector<std::vector<ForestDirHost>> &sets, const std::vector<int> &slot0,
                     int batch, size_t per_dir, std::vector<ForestRun> *runs);
+int launch_forest_pass(ftte_ctx *c, hipStream_t stream, const ForestRun &R, size_t b, size_t p, AmrLevelRec A);
+int launch_forest_combine(ftte_ctx *c, hipStream_t stream, const ForestRun &R, size_t b, AmrLevelRec A, double *J_dev, bool zero_first);
 int launch_forests(ftte_ctx *c, hipStream_t stream, const ForestRun &R, AmrLevelRec A, double *J_dev, bool zero_first, bool time_batches,
                    hipEvent_t before_combine, hipEvent_t after_combine);
 int run_forests(ftte_ctx *c, hipStream_t stream, const std::vector<ForestDirHost> &dirs, int batch, size_t per_dir, AmrLevelRec A,

@@ -270,6 +270,8 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
             if (st[t]) { const std::string m = msg[t]; const int code = st[t]; free_hybrid(c); return fail(c, code, "direction " + std::to_string(d0 + t) + ": " + m); }
             ftte_ctx::HybridPlan::Dir &D = H.dirs[(size_t)(d0 + t)];
             D.depth_off = F[t].depth_off;
+            D.pass_first = F[t].pass_first;
+            D.export_first = F[t].export_first;
             D.nexports = (int64_t)F[t].exports.size();
             static_assert(sizeof(AmrForest::Export) == sizeof(AmrExport), "export records: host and device forms must agree");
             exports[(size_t)(d0 + t)].resize(F[t].exports.size());
@@ -499,7 +501,7 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
             for (int d : H.half_dirs[(size_t)h]) {
                 const ftte_ctx::HybridPlan::Dir &D = H.dirs[(size_t)d];
                 sets[(size_t)to].push_back(ForestDirHost{D.rec, D.active, P.dirs[(size_t)d].w, c->d_faces + (size_t)d * nnu * (size_t)P.face_elems,
-                                                         D.exports, D.nexports, &D.depth_off});
+                                                         D.exports, D.nexports, &D.depth_off, &D.pass_first, &D.export_first});
             }
         }
         for (int r = 1; r < nh; ++r) slot0[(size_t)r] = slot0[(size_t)r - 1] + (int)sets[(size_t)r - 1].size();

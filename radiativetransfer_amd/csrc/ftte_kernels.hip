@@ -584,8 +584,10 @@ __global__ void __launch_bounds__(256) amr_export_kernel(const AmrLevelRec A)
     const int nnu = A.nnu;
     const long e = t / nnu;
     const int nu = (int)(t - e * nnu);
-    if (e >= D.nexports) return;
-    const AmrExport X = D.exports[e];
+    // this launch's share of the direction's rays (a pass of the hybrid sweep), or all of them
+    const long count = A.count ? (long)A.count[blockIdx.y] : (long)D.nexports, first = A.begin ? (long)A.begin[blockIdx.y] : 0l;
+    if (e >= count) return;
+    const AmrExport X = D.exports[first + e];
     D.faces[(size_t)nu * A.face_stride + (size_t)X.at] = D.Iout[(size_t)(unsigned)X.seg * nnu + nu];
 }
 

@@ -58,8 +58,10 @@ void free_forests(ftte_ctx *c)
     c->forest_key.clear();
 }
 
-// Tables of several independent passes (`sets`: direction lists that may run side by side on different streams, set q using the
-// scratch slots from slot0[q] on), `batch` directions at a time each; built and uploaded in one go on `stream`.
+// Tables of several independent runs (`sets`: direction lists that may run side by side on different streams, set q using the
+// scratch slots from slot0[q] on), `batch` directions at a time each; built and uploaded in one go on `stream`.  A direction's
+// forest may come in passes (hybrid sweep with several boxes): every batch gets per-depth tables pass by pass, and per pass the
+// range of the rays that leave its boxes.
 int prepare_forests(ftte_ctx *c, hipStream_t stream, const std::vector<std::vector<ForestDirHost>> &sets, const std::vector<int> &slot0,
                     int batch, size_t per_dir, std::vector<ForestRun> *runs)
 {
@@ -74,7 +76,9 @@ int prepare_forests(ftte_ctx *c, hipStream_t stream, const std::vector<std::vect
         R.dir_at = recs.size();
         for (int d0 = 0; d0 < ndir; d0 += batch) {
             const int nb = std::min(batch, ndir - d0);
-            ForestRun::Batch B{d0, nb, 0, 0, 0, 0};
+            ForestRun::Batch B;
+            B.d0 = d0; B.nb = nb;
+            size_t npass = 1;
             for (int t = 0; t < nb; ++t) {
                 const ForestDirHost &D = dirs[(size_t)(d0 + t)];
                 AmrDirRec rec;
@@ -84,24 +88,56 @@ int prepare_forests(ftte_ctx *c, hipStream_t stream, const std::vector<std::vect
                 rec.mean = c->amr_mean + per_dir * (size_t)(slot0[q] + t);
                 rec.faces = D.faces; rec.exports = D.exports; rec.nexports = D.nexports;
                 recs.push_back(rec);
-                B.maxdepth = std::max(B.maxdepth, D.depth_off->size() - 1);
-                B.most_exports = std::max(B.most_exports, D.nexports);
+                if (D.pass_first) npass = std::max(npass, D.pass_first->size() - 1);
             }
-            B.table_at = tables.size();
-            B.most_at = R.most_of.size();
-            for (size_t depth = 0; depth < B.maxdepth; ++depth) {
-                int64_t most = 0;
-                const size_t at = tables.size();
-                tables.resize(at + 2 * (size_t)nb, 0);
+            for (size_t p = 0; p < npass; ++p) {
+                ForestRun::Pass P;
+                // depth d of pass p is entry first(p) + d of the direction's depth_off, while that lies inside the pass
+                auto range = [&](const ForestDirHost &D, size_t *first, size_t *count) {
+                    const size_t all = D.depth_off->size() - 1;
+                    if (!D.pass_first) { *first = 0; *count = p == 0 ? all : 0; return; }
+                    if (p + 1 >= D.pass_first->size()) { *first = all; *count = 0; return; }
+                    *first = (size_t)(*D.pass_first)[p]; *count = (size_t)((*D.pass_first)[p + 1] - (*D.pass_first)[p]);
+                };
                 for (int t = 0; t < nb; ++t) {
-                    const std::vector<int64_t> &off = *dirs[(size_t)(d0 + t)].depth_off;
-                    if (depth + 1 < off.size()) {
-                        tables[at + (size_t)t] = off[depth + 1] - off[depth];
-                        tables[at + (size_t)nb + (size_t)t] = off[depth];
-                        most = std::max(most, off[depth + 1] - off[depth]);
-                    }
+                    size_t first, count;
+                    range(dirs[(size_t)(d0 + t)], &first, &count);
+                    P.maxdepth = std::max(P.maxdepth, count);
                 }
-                R.most_of.push_back(most);
+                P.table_at = tables.size();
+                P.most_at = R.most_of.size();
+                for (size_t depth = 0; depth < P.maxdepth; ++depth) {
+                    int64_t most = 0;
+                    const size_t at = tables.size();
+                    tables.resize(at + 2 * (size_t)nb, 0);
+                    for (int t = 0; t < nb; ++t) {
+                        const ForestDirHost &D = dirs[(size_t)(d0 + t)];
+                        size_t first, count;
+                        range(D, &first, &count);
+                        if (depth < count) {
+                            const std::vector<int64_t> &off = *D.depth_off;
+                            tables[at + (size_t)t] = off[first + depth + 1] - off[first + depth];
+                            tables[at + (size_t)nb + (size_t)t] = off[first + depth];
+                            most = std::max(most, off[first + depth + 1] - off[first + depth]);
+                        }
+                    }
+                    R.most_of.push_back(most);
+                }
+                // the rays that leave this pass's boxes: count[], first[] per direction
+                P.export_at = tables.size();
+                tables.resize(P.export_at + 2 * (size_t)nb, 0);
+                for (int t = 0; t < nb; ++t) {
+                    const ForestDirHost &D = dirs[(size_t)(d0 + t)];
+                    int64_t first = 0, count = p == 0 ? D.nexports : 0;
+                    if (D.export_first) {
+                        first = p + 1 < D.export_first->size() ? (*D.export_first)[p] : D.nexports;
+                        count = p + 1 < D.export_first->size() ? (*D.export_first)[p + 1] - first : 0;
+                    }
+                    tables[P.export_at + (size_t)t] = count;
+                    tables[P.export_at + (size_t)nb + (size_t)t] = first;
+                    P.most_exports = std::max(P.most_exports, count);
+                }
+                B.passes.push_back(P);
             }
             R.batches.push_back(B);
         }
@@ -114,31 +150,55 @@ int prepare_forests(ftte_ctx *c, hipStream_t stream, const std::vector<std::vect
     return FTTE_OK;
 }
 
-// One prepared pass on `stream`: depth after depth (one launch per depth for the whole batch), then the rays that leave the region
-// (hybrid), then the per-leaf means into J in list order.  The combine launches read-modify-write J: `before_combine` (if any) is
-// waited for in front of the first one, `after_combine` (if any) recorded behind the last, which is how two passes on two streams
-// keep a fixed order of additions.
+// One pass of one batch of a prepared run on `stream`: depth after depth (one launch per depth for the whole batch), then the rays
+// that leave the pass's boxes (hybrid sweep) into the bricks' face buffers.
+int launch_forest_pass(ftte_ctx *c, hipStream_t stream, const ForestRun &R, size_t b, size_t p, AmrLevelRec A)
+{
+    const ForestRun::Batch &B = R.batches[b];
+    if (p >= B.passes.size()) return FTTE_OK;
+    const ForestRun::Pass &P = B.passes[p];
+    A.dir = c->d_amr_dirs + R.dir_at + (size_t)B.d0;
+    A.ndir = B.nb;
+    for (size_t depth = 0; depth < P.maxdepth; ++depth) {
+        A.count = c->d_amr_tables + P.table_at + depth * 2 * (size_t)B.nb;
+        A.begin = A.count + B.nb;
+        A.most = R.most_of[P.most_at + depth];
+        if (launch_amr_level(A, stream)) return fail(c, FTTE_ERR_NO_DEVICE, "forest level kernel launch failed");
+    }
+    A.count = c->d_amr_tables + P.export_at;
+    A.begin = A.count + B.nb;
+    if (launch_amr_export(A, P.most_exports, stream)) return fail(c, FTTE_ERR_NO_DEVICE, "forest export kernel launch failed");
+    return FTTE_OK;
+}
+
+// The per-leaf means of one batch into J, directions in list order.
+int launch_forest_combine(ftte_ctx *c, hipStream_t stream, const ForestRun &R, size_t b, AmrLevelRec A, double *J_dev, bool zero_first)
+{
+    const ForestRun::Batch &B = R.batches[b];
+    A.dir = c->d_amr_dirs + R.dir_at + (size_t)B.d0;
+    A.ndir = B.nb;
+    if (launch_amr_combine(A, J_dev, zero_first, stream)) return fail(c, FTTE_ERR_NO_DEVICE, "forest combine kernel launch failed");
+    return FTTE_OK;
+}
+
+// A prepared run on `stream`, batch after batch: its passes, then the means into J.  The combine launches read-modify-write J:
+// `before_combine` (if any) is waited for in front of the first one, `after_combine` (if any) recorded behind the last, which is
+// how two runs on two streams keep a fixed order of additions.
 int launch_forests(ftte_ctx *c, hipStream_t stream, const ForestRun &R, AmrLevelRec A, double *J_dev, bool zero_first, bool time_batches,
                    hipEvent_t before_combine, hipEvent_t after_combine)
 {
     const int nnu = c->nnu;
+    int rc;
     for (size_t b = 0; b < R.batches.size(); ++b) {
         const ForestRun::Batch &B = R.batches[b];
-        A.dir = c->d_amr_dirs + R.dir_at + (size_t)B.d0;
-        A.ndir = B.nb;
         if (time_batches) {
             c->timing[b].updates = (int64_t)B.nb * c->ncell * nnu; c->timing[b].lanes = 0;
             FTTE_HIP(c, hipEventRecord(c->timing[b].start, stream));
         }
-        for (size_t depth = 0; depth < B.maxdepth; ++depth) {
-            A.count = c->d_amr_tables + B.table_at + depth * 2 * (size_t)B.nb;
-            A.begin = A.count + B.nb;
-            A.most = R.most_of[B.most_at + depth];
-            if (launch_amr_level(A, stream)) return fail(c, FTTE_ERR_NO_DEVICE, "forest level kernel launch failed");
-        }
-        if (launch_amr_export(A, B.most_exports, stream)) return fail(c, FTTE_ERR_NO_DEVICE, "forest export kernel launch failed");
+        for (size_t p = 0; p < B.passes.size(); ++p)
+            if ((rc = launch_forest_pass(c, stream, R, b, p, A))) return rc;
         if (b == 0 && before_combine) FTTE_HIP(c, hipStreamWaitEvent(stream, before_combine, 0));
-        if (launch_amr_combine(A, J_dev, zero_first && b == 0, stream)) return fail(c, FTTE_ERR_NO_DEVICE, "forest combine kernel launch failed");
+        if ((rc = launch_forest_combine(c, stream, R, b, A, J_dev, zero_first && b == 0))) return rc;
         if (time_batches) {
             FTTE_HIP(c, hipEventRecord(c->timing[b].stop, stream));
             c->timing_used = (int)b + 1;
@@ -307,7 +367,7 @@ int forest_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
         std::vector<ForestDirHost> dirs((size_t)ndir);
         for (int d = 0; d < ndir; ++d) {
             const ftte_ctx::ForestDev &D = c->forests[(size_t)d];
-            dirs[(size_t)d] = ForestDirHost{D.rec, D.active, D.w, nullptr, nullptr, 0, &D.depth_off};
+            dirs[(size_t)d] = ForestDirHost{D.rec, D.active, D.w, nullptr, nullptr, 0, &D.depth_off, nullptr, nullptr};
         }
         if ((rc = run_forests(c, stream, dirs, batch, per_dir, A, J_dev, true, true))) return rc;
     }
