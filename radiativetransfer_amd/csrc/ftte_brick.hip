@@ -176,7 +176,9 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
     const int group_field = uniform((int)T.group);
     const int lane_lo = MASKED ? (tu_field >> kBrickLaneLoShift) & 63 : 0;
     const int lane_hi = MASKED ? (group_field >> kBrickLaneHiShift) & 63 : 63;
-    const int tv = uniform((int)T.tv), ti = uniform((int)T.ti) & (kBrickAccumulate - 1);
+    const int tv_field = uniform((int)T.tv);
+    const int tv = MASKED ? tv_field & kBrickTvMask : tv_field, box = MASKED ? (tv_field >> kBrickBoxShift) & kBrickBoxMask : 0;
+    const int ti = uniform((int)T.ti) & (kBrickAccumulate - 1);
     const bool accumulate = (uniform((int)T.ti) & kBrickAccumulate) != 0;
     cgroup *G = (cgroup *)(L.groups + (MASKED ? group_field & kBrickGroupMask : group_field));
     const int n = L.n, chunk = L.chunk, up = L.up, vp = L.vp;
@@ -207,10 +209,11 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
     // element offsets inside a direction's face block (ftte_internal.h)
     const int uw = L.uw, ut = L.ut;
     const int ns = L.nslot, sl = ti % ns;
-    // masked bricks: lanes that end inside the brick hand their rays to the box's near u-face (ring 0 at uqface_off), lanes that
-    // start inside it take theirs from the box's far u-face (ring 1)
-    const long u_out = lane_hi < 63 ? L.uqface_off + ((long)sl * chunk) * uw + ut * tv : ((long)(tu * ns + sl) * chunk) * uw + ut * tv;
-    const long u_in = lane_lo > 0 ? L.uqface_off + ((long)(ns + sl) * chunk) * uw + ut * tv : ((long)((tu - 1) * ns + sl) * chunk) * uw + ut * tv;
+    // masked bricks: lanes that end inside the brick hand their rays to the near u-face of the box there (ring 2 * box at
+    // uqface_off), lanes that start inside it take theirs from that box's far u-face (ring 2 * box + 1)
+    const long u_out = lane_hi < 63 ? L.uqface_off + ((long)((2 * box) * ns + sl) * chunk) * uw + ut * tv : ((long)(tu * ns + sl) * chunk) * uw + ut * tv;
+    const long u_in = lane_lo > 0 ? L.uqface_off + ((long)((2 * box + 1) * ns + sl) * chunk) * uw + ut * tv
+                                  : ((long)((tu - 1) * ns + sl) * chunk) * uw + ut * tv;
     const long v_out = L.vface_off + ((long)(tv * ns + sl) * chunk) * up + 64 * tu;
     const long v_in = L.vface_off + ((long)((tv - 1) * ns + sl) * chunk) * up + 64 * tu;
     const long i_in = L.iface_off + ((long)sl * vp + R * tv) * up + 64 * tu + lane;

@@ -205,8 +205,11 @@ struct ftte_ctx {
         bool valid = false, worthwhile = false;
         std::vector<double> key;          // box, chunk, group, share, then phi, theta, w
         BrickPlan bricks;                 // groups, tasks of the bricks outside the regions (phase 1, then phase 3)
-        size_t phase1_stages = 0;         // per half: stage lists [0, phase1_stages) come before the forest pass, the rest after it
-        size_t nlist = 0;                 // stage lists per half (2 x phase1_stages)
+        size_t phase1_stages = 0;         // stage lists per phase
+        int most_boxes = 0;               // boxes of the izone that has most
+        int npass = 1;                    // passes of the forests (boxes behind other boxes wait for the bricks in between); the
+                                          // bricks run in npass + 1 phases: before pass 0, after pass 0, ..., after the last
+        size_t nlist = 0;                 // stage lists per half ((npass + 1) x phase1_stages)
         int nhalves = 1;                  // the groups of an accumulator stay in one half; halves share nothing but kappa and J
         std::vector<std::vector<int>> half_dirs; // directions of each half, list order
         std::vector<size_t> stage_off;    // into bricks.tasks: [half][list]

@@ -23,49 +23,148 @@ void free_hybrid(ftte_ctx *c)
     c->hplan = ftte_ctx::HybridPlan();
 }
 
-// The box of izone `izone` in the sweep frame: the refined base cells and a rim of unrefined ones, on brick boundaries along v and
-// the march axis (one brick of rim) and, along u, one cell of rim (option "box_lanes": then outwards to the next multiple of it):
-// a brick is 64 lanes wide, and whole bricks of rim would put every column of a 128^3 grid into the box of a 32^3 patch.  Bricks
-// that the box cuts through sweep the lanes outside it (brick_kernel<..., MASKED>).  tile_lo / tile_hi: the bricks the box
-// touches.  False if the tree has no refined cell.
-bool hybrid_region(const ftte_ctx *c, const BrickPlan &P, int izone, ForestRegion *R, int tile_lo[3], int tile_hi[3])
+// Where the refined base cells are, in storage coordinates (1-based, inclusive): one bounding box per cluster.  Two refined cells
+// belong to one cluster when they lie within two 8-cell blocks of each other; what the per-izone alignment below still brings
+// into contact is merged there.
+struct Extent { int lo[3], hi[3]; };
+
+std::vector<Extent> refined_clusters(const AmrTree &T)
 {
-    const AmrTree &T = c->tree;
-    const int n = T.n;
-    int clo[3] = {n + 1, n + 1, n + 1}, chi[3] = {0, 0, 0}; // storage coordinates of the refined base cells
+    const int n = T.n, M = 8, nm = (n + M - 1) / M;
+    std::vector<int32_t> label((size_t)nm * nm * nm, -2); // -2: no refined cell, -1: not yet labelled
+    for (int64_t b = 0; b < (int64_t)n * n * n; ++b)
+        if (T.child0[(size_t)b] >= 0)
+            label[(((size_t)(b / ((int64_t)n * n)) / M) * nm + (size_t)((b / n) % n) / M) * nm + (size_t)(b % n) / M] = -1;
+    int32_t count = 0;
+    std::vector<int32_t> stack;
+    for (int32_t m0 = 0; m0 < (int32_t)label.size(); ++m0) {
+        if (label[(size_t)m0] != -1) continue;
+        label[(size_t)m0] = count;
+        stack.assign(1, m0);
+        while (!stack.empty()) {
+            const int32_t m = stack.back();
+            stack.pop_back();
+            const int a = m / (nm * nm), b = (m / nm) % nm, c2 = m % nm;
+            for (int da = -2; da <= 2; ++da)
+                for (int db = -2; db <= 2; ++db)
+                    for (int dc = -2; dc <= 2; ++dc) {
+                        const int x = a + da, y = b + db, z = c2 + dc;
+                        if (x < 0 || y < 0 || z < 0 || x >= nm || y >= nm || z >= nm) continue;
+                        int32_t &l = label[((size_t)x * nm + y) * nm + z];
+                        if (l == -1) { l = count; stack.push_back((int32_t)(((size_t)x * nm + y) * nm + z)); }
+                    }
+        }
+        ++count;
+    }
+    std::vector<Extent> out((size_t)count);
+    for (auto &e : out) for (int a = 0; a < 3; ++a) { e.lo[a] = n + 1; e.hi[a] = 0; }
     for (int64_t b = 0; b < (int64_t)n * n * n; ++b)
         if (T.child0[(size_t)b] >= 0) {
             const int cc[3] = {(int)(b / ((int64_t)n * n)) + 1, (int)((b / n) % n) + 1, (int)(b % n) + 1};
-            for (int a = 0; a < 3; ++a) { clo[a] = std::min(clo[a], cc[a]); chi[a] = std::max(chi[a], cc[a]); }
+            Extent &e = out[(size_t)label[(((size_t)(cc[0] - 1) / M) * nm + (size_t)(cc[1] - 1) / M) * nm + (size_t)(cc[2] - 1) / M]];
+            for (int a = 0; a < 3; ++a) { e.lo[a] = std::min(e.lo[a], cc[a]); e.hi[a] = std::max(e.hi[a], cc[a]); }
         }
-    if (chi[0] == 0) return false;
-    ZoneMap zm;
-    zone_map(izone, &zm);
-    int slo[3], shi[3]; // sweep frame: i, j, k
-    int march_c = 0;
-    for (int a = 0; a < 3; ++a) {
-        const int sa = zm.src[a];
-        slo[sa] = zm.mirror[a] ? n + 1 - chi[a] : clo[a];
-        shi[sa] = zm.mirror[a] ? n + 1 - clo[a] : chi[a];
-        if (sa == 0) march_c = a;
-    }
-    const int fast_c = (march_c == 2) ? 1 : 2;
-    const bool u_is_k = zm.src[fast_c] == 2;
+    return out;
+}
+
+// A box of one izone: the refined cells of a cluster (`fine`: their extent in the sweep frame i, j, k) and a rim of unrefined ones,
+// on brick boundaries along v and the march axis (one brick of rim) and, along u, one cell of rim (option "box_lanes": then outwards
+// to the next multiple of it): a brick is 64 lanes wide, and whole bricks of rim would put every column of a 128^3 grid into the box
+// of a 32^3 patch.  Bricks that a box cuts through sweep the lanes outside it (brick_kernel<..., MASKED>).
+struct HybridBox {
+    Extent fine;        // sweep frame
+    ForestRegion R;
+    int lo[3], hi[3];   // the bricks the box touches: u, v, march axis
+    int ulo, uhi;       // its cells along u
+    int level = 0;      // pass of its forest: 1 + the highest level among the boxes it lies behind
+};
+
+void align_box(const ftte_ctx *c, const BrickPlan &P, bool u_is_k, HybridBox *B)
+{
+    const int n = c->n;
     const int ju = u_is_k ? 2 : 1, jv = u_is_k ? 1 : 2; // sweep axes of u and v
+    const int *slo = B->fine.lo, *shi = B->fine.hi;
     const int tsize_i = P.chunk, tsize_u = 64, tsize_v = kBrickRows;
     const int lanes = c->hybrid_lanes; // 1 (the rim and no more), a multiple such as 16, or 64: whole bricks along u as along the other axes
-    const int ulo = lanes == 64 ? std::max(0, (slo[ju] - 1) / 64 - 1) * 64 + 1 : std::max(0, (slo[ju] - 2) / lanes) * lanes + 1;
-    const int uhi = lanes == 64 ? std::min(n, (std::min(P.ntu - 1, (shi[ju] - 1) / 64 + 1) + 1) * 64) : std::min(n, (shi[ju] + lanes) / lanes * lanes);
-    tile_lo[0] = (ulo - 1) / tsize_u; tile_hi[0] = (uhi - 1) / tsize_u;
-    tile_lo[1] = std::max(0, (slo[jv] - 1) / tsize_v - 1); tile_hi[1] = std::min(P.ntv - 1, (shi[jv] - 1) / tsize_v + 1);
-    tile_lo[2] = std::max(0, (slo[0] - 1) / tsize_i - 1);  tile_hi[2] = std::min(P.nti - 1, (shi[0] - 1) / tsize_i + 1);
+    B->ulo = lanes == 64 ? std::max(0, (slo[ju] - 1) / 64 - 1) * 64 + 1 : std::max(0, (slo[ju] - 2) / lanes) * lanes + 1;
+    B->uhi = lanes == 64 ? std::min(n, (std::min(P.ntu - 1, (shi[ju] - 1) / 64 + 1) + 1) * 64) : std::min(n, (shi[ju] + lanes) / lanes * lanes);
+    B->lo[0] = (B->ulo - 1) / tsize_u; B->hi[0] = (B->uhi - 1) / tsize_u;
+    B->lo[1] = std::max(0, (slo[jv] - 1) / tsize_v - 1); B->hi[1] = std::min(P.ntv - 1, (shi[jv] - 1) / tsize_v + 1);
+    B->lo[2] = std::max(0, (slo[0] - 1) / tsize_i - 1);  B->hi[2] = std::min(P.nti - 1, (shi[0] - 1) / tsize_i + 1);
+    ForestRegion *R = &B->R;
     R->u_is_k = u_is_k;
-    R->lo[0] = tile_lo[2] * tsize_i + 1; R->hi[0] = std::min(n, (tile_hi[2] + 1) * tsize_i);
-    R->lo[ju] = ulo; R->hi[ju] = uhi;
-    R->lo[jv] = tile_lo[1] * tsize_v + 1; R->hi[jv] = std::min(n, (tile_hi[1] + 1) * tsize_v);
+    R->lo[0] = B->lo[2] * tsize_i + 1; R->hi[0] = std::min(n, (B->hi[2] + 1) * tsize_i);
+    R->lo[ju] = B->ulo; R->hi[ju] = B->uhi;
+    R->lo[jv] = B->lo[1] * tsize_v + 1; R->hi[jv] = std::min(n, (B->hi[1] + 1) * tsize_v);
     R->chunk = P.chunk; R->ut = P.ut; R->nslot = P.nslot; R->ntv = P.ntv; R->up = P.up; R->vp = P.vp;
     R->vface_off = P.vface_off; R->iface_off = P.iface_off; R->uqface_off = P.uqface_off;
-    return true;
+}
+
+// The boxes of one izone: every cluster's, merged where two would touch or cut through the same brick, with their levels: box B lies
+// behind box A when some ray can pass A first and B later (B's last brick >= A's first one on every axis).  Then B's forest needs the
+// bricks in between, which need A's: A is swept in an earlier pass.
+std::vector<HybridBox> izone_boxes(const ftte_ctx *c, const BrickPlan &P, int izone, const std::vector<Extent> &clusters)
+{
+    const int n = c->n;
+    ZoneMap zm;
+    zone_map(izone, &zm);
+    int march_c = 0;
+    for (int a = 0; a < 3; ++a) if (zm.src[a] == 0) march_c = a;
+    const int fast_c = (march_c == 2) ? 1 : 2;
+    const bool u_is_k = zm.src[fast_c] == 2;
+    std::vector<HybridBox> boxes;
+    for (const Extent &e : clusters) {
+        HybridBox B;
+        for (int a = 0; a < 3; ++a) {
+            const int sa = zm.src[a];
+            B.fine.lo[sa] = zm.mirror[a] ? n + 1 - e.hi[a] : e.lo[a];
+            B.fine.hi[sa] = zm.mirror[a] ? n + 1 - e.lo[a] : e.hi[a];
+        }
+        align_box(c, P, u_is_k, &B);
+        boxes.push_back(B);
+    }
+    auto join = [&](size_t x, size_t y) {
+        for (int a = 0; a < 3; ++a) {
+            boxes[x].fine.lo[a] = std::min(boxes[x].fine.lo[a], boxes[y].fine.lo[a]);
+            boxes[x].fine.hi[a] = std::max(boxes[x].fine.hi[a], boxes[y].fine.hi[a]);
+        }
+        align_box(c, P, u_is_k, &boxes[x]);
+        boxes.erase(boxes.begin() + (long)y);
+    };
+    for (bool changed = true; changed;) {
+        changed = false;
+        for (size_t x = 0; x < boxes.size() && !changed; ++x)
+            for (size_t y = x + 1; y < boxes.size() && !changed; ++y) {
+                const HybridBox &A = boxes[x], &B = boxes[y];
+                // too close: next to each other brick-wise along v and the march axis and, along u, in one brick or within two cells
+                const bool near_v = A.lo[1] - 1 <= B.hi[1] && B.lo[1] - 1 <= A.hi[1], near_i = A.lo[2] - 1 <= B.hi[2] && B.lo[2] - 1 <= A.hi[2];
+                const bool near_u = (A.lo[0] <= B.hi[0] && B.lo[0] <= A.hi[0]) || (A.ulo - 2 <= B.uhi && B.ulo - 2 <= A.uhi);
+                // each behind the other: cannot be ordered
+                bool a_then_b = true, b_then_a = true;
+                for (int k = 0; k < 3; ++k) { a_then_b = a_then_b && B.hi[k] >= A.lo[k]; b_then_a = b_then_a && A.hi[k] >= B.lo[k]; }
+                if ((near_u && near_v && near_i) || (a_then_b && b_then_a)) { join(x, y); changed = true; }
+            }
+    }
+    // levels: longest chain of boxes in front.  The relation has no cycles among boxes that do not intersect; should the relaxation
+    // not settle all the same, one box takes everything.
+    const size_t K = boxes.size();
+    bool settled = false;
+    for (size_t round = 0; round <= K && !settled; ++round) {
+        settled = true;
+        for (size_t y = 0; y < K; ++y)
+            for (size_t x = 0; x < K; ++x) {
+                if (x == y) continue;
+                bool x_then_y = true;
+                for (int k = 0; k < 3; ++k) x_then_y = x_then_y && boxes[y].hi[k] >= boxes[x].lo[k];
+                if (x_then_y && boxes[y].level < boxes[x].level + 1) { boxes[y].level = boxes[x].level + 1; settled = false; }
+            }
+    }
+    if (!settled) {
+        while (boxes.size() > 1) join(0, 1);
+        boxes[0].level = 0;
+    }
+    for (size_t x = 0; x < boxes.size(); ++x) { boxes[x].R.id = (int)x; boxes[x].R.pass = boxes[x].level; }
+    return boxes;
 }
 
 int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *theta, const double *w)
@@ -86,22 +185,28 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
     if ((rc = plan_brick_groups(c, P, ndir, phi, theta, w, chunk, gmax, 0, true))) return rc;
     P.glanes = 1;
 
-    // the box of every group; is the part outside the boxes worth a brick sweep?
-    struct Box { ForestRegion R; int lo[3], hi[3]; int ulo, uhi; bool any; }; // lo / hi: bricks (u, v, march axis); ulo / uhi: cells
-    std::vector<Box> box(P.groups.size());
+    // the boxes of every group; is the part outside them worth a brick sweep?
+    const std::vector<Extent> clusters = refined_clusters(c->tree);
+    std::vector<std::vector<HybridBox>> boxes(P.groups.size());
     int64_t inside_bricks = 0, all_bricks = 0;
+    int most_boxes = 0, top_level = 0;
     for (size_t g = 0; g < P.groups.size(); ++g) {
-        box[g].any = hybrid_region(c, P, P.groups[g].izone, &box[g].R, box[g].lo, box[g].hi);
+        if (g > 0 && P.groups[g].izone == P.groups[g - 1].izone) boxes[g] = boxes[g - 1];
+        else boxes[g] = izone_boxes(c, P, P.groups[g].izone, clusters);
         all_bricks += (int64_t)P.ntu * P.ntv * P.nti;
-        if (box[g].any) {
-            const ForestRegion &R = box[g].R;
-            box[g].ulo = R.lo[R.u_is_k ? 2 : 1]; box[g].uhi = R.hi[R.u_is_k ? 2 : 1];
-            inside_bricks += (int64_t)(box[g].hi[0] - box[g].lo[0] + 1) * (box[g].hi[1] - box[g].lo[1] + 1) * (box[g].hi[2] - box[g].lo[2] + 1);
+        most_boxes = std::max(most_boxes, (int)boxes[g].size());
+        for (const HybridBox &B : boxes[g]) {
+            inside_bricks += (int64_t)(B.hi[0] - B.lo[0] + 1) * (B.hi[1] - B.lo[1] + 1) * (B.hi[2] - B.lo[2] + 1);
+            top_level = std::max(top_level, B.level);
         }
     }
+    // every box has its own pair of face rings for rays that cross its u-faces inside a brick
+    P.face_elems = P.uqface_off + 2 * (int64_t)std::max(most_boxes, 1) * P.nslot * P.chunk * P.uw;
     H.key = key;
     H.valid = true;
-    H.worthwhile = !P.groups.empty() && inside_bricks * 2 <= all_bricks; // else: the forest path for the whole tree
+    H.worthwhile = !P.groups.empty() && most_boxes > 0 && most_boxes <= kBrickBoxMask && inside_bricks * 2 <= all_bricks; // else: the forest path for the whole tree
+    H.npass = top_level + 1;
+    H.most_boxes = most_boxes;
     if (!H.worthwhile) return FTTE_OK;
 
     // Halves: the forests stream records at the memory system's rate while the brick stages of a 128^3 grid are short launches
@@ -137,24 +242,35 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
     int max_offset = 0;
     for (const auto &G : P.groups) max_offset = std::max(max_offset, G.offset);
     const int per_phase = P.ntu + P.ntv + P.nti - 2 + max_offset;
-    H.nlist = 2 * (size_t)per_phase;
+    H.nlist = (size_t)(H.npass + 1) * (size_t)per_phase; // phase 0 before the first pass of the forests, phase k after pass k - 1
     const size_t nlist = (size_t)H.nhalves * H.nlist;
     H.phase1_stages = (size_t)per_phase;
-    auto list_of = [&](size_t g, bool behind, int tu, int tv, int ti, int offset) {
-        return (size_t)half_of_group[g] * H.nlist + (size_t)(behind ? per_phase : 0) + (size_t)(tu + tv + ti + offset);
+    auto list_of = [&](size_t g, int phase, int tu, int tv, int ti, int offset) {
+        return (size_t)half_of_group[g] * H.nlist + (size_t)phase * (size_t)per_phase + (size_t)(tu + tv + ti + offset);
     };
-    // What a group sweeps of brick (tu, tv, ti): nothing (the box holds it), all of it, or -- the box cuts through it along u --
-    // the lanes on the near side of the box (before the forests) and / or those on the far side (after them).
-    struct Piece { int lane_lo, lane_hi; bool behind, masked; };
-    auto pieces_of = [&](const Box &B, int tu, int tv, int ti, Piece out[2]) -> int {
+    // What a group sweeps of brick (tu, tv, ti): nothing (a box holds it), all of it, or -- a box cuts through it along u -- the
+    // lanes on the near side of that box and / or those on the far side.  Every piece runs in the phase after the last pass it
+    // depends on: 1 + the highest level among the boxes it lies behind (phase 0: behind none).
+    struct Piece { int lane_lo, lane_hi, phase, box; bool masked; };
+    auto pieces_of = [&](const std::vector<HybridBox> &BX, int tu, int tv, int ti, Piece out[2]) -> int {
         const int last = std::min(63, n - 64 * tu - 1); // last lane with a cell
-        const bool behind = B.any && tu >= B.lo[0] && tv >= B.lo[1] && ti >= B.lo[2];
-        const bool in_vi = B.any && tv >= B.lo[1] && tv <= B.hi[1] && ti >= B.lo[2] && ti <= B.hi[2];
-        const int first_in = in_vi ? std::max(B.ulo, 64 * tu + 1) - (64 * tu + 1) : 64, last_in = in_vi ? std::min(B.uhi, 64 * tu + 64) - (64 * tu + 1) : -1;
-        if (first_in > last_in) { out[0] = Piece{0, 63, behind, false}; return 1; } // the box does not reach into this brick
+        int behind_all = 0, cut = -1;
+        for (size_t x = 0; x < BX.size(); ++x) {
+            const HybridBox &B = BX[x];
+            if (tu >= B.lo[0] && tv >= B.lo[1] && ti >= B.lo[2]) behind_all = std::max(behind_all, B.level + 1);
+            if (tv >= B.lo[1] && tv <= B.hi[1] && ti >= B.lo[2] && ti <= B.hi[2] && B.ulo <= 64 * tu + 64 && B.uhi >= 64 * tu + 1) cut = (int)x;
+        }
+        if (cut < 0) { out[0] = Piece{0, 63, behind_all, 0, false}; return 1; } // no box reaches into this brick
+        const HybridBox &X = BX[(size_t)cut];
+        const int first_in = std::max(X.ulo, 64 * tu + 1) - (64 * tu + 1), last_in = std::min(X.uhi, 64 * tu + 64) - (64 * tu + 1);
         int count = 0;
-        if (first_in > 0) out[count++] = Piece{0, first_in - 1, false, true};
-        if (last_in < last) out[count++] = Piece{last_in + 1, 63, true, true};
+        if (first_in > 0) { // the near side: not behind the box it belongs to
+            int behind_others = 0;
+            for (size_t x = 0; x < BX.size(); ++x)
+                if ((int)x != cut && tu >= BX[x].lo[0] && tv >= BX[x].lo[1] && ti >= BX[x].lo[2]) behind_others = std::max(behind_others, BX[x].level + 1);
+            out[count++] = Piece{0, first_in - 1, behind_others, cut, true};
+        }
+        if (last_in < last) out[count++] = Piece{last_in + 1, 63, behind_all, cut, true};
         return count;
     };
     const size_t nb = (size_t)P.ntu * P.ntv * P.nti;
@@ -173,9 +289,9 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
             for (int tv = 0; tv < P.ntv; ++tv)
                 for (int tu = 0; tu < P.ntu; ++tu) {
                     Piece pc[2];
-                    const int np = pieces_of(box[g], tu, tv, ti, pc);
+                    const int np = pieces_of(boxes[g], tu, tv, ti, pc);
                     for (int q = 0; q < np; ++q)
-                        if (pc[q].masked) cut[list_of(g, pc[q].behind, tu, tv, ti, P.groups[g].offset)] = 1;
+                        if (pc[q].masked) cut[list_of(g, pc[q].phase, tu, tv, ti, P.groups[g].offset)] = 1;
                 }
     H.stage_off.assign(2 * nlist + 1, 0);
     for (size_t g = 0; g < P.groups.size(); ++g) {
@@ -186,9 +302,9 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
             for (int tv = 0; tv < P.ntv; ++tv)
                 for (int tu = 0; tu < P.ntu; ++tu) {
                     Piece pc[2];
-                    const int np = pieces_of(box[g], tu, tv, ti, pc);
+                    const int np = pieces_of(boxes[g], tu, tv, ti, pc);
                     for (int q = 0; q < np; ++q) {
-                        const size_t l = list_of(g, pc[q].behind, tu, tv, ti, G.offset);
+                        const size_t l = list_of(g, pc[q].phase, tu, tv, ti, G.offset);
                         ++H.stage_off[(cut[l] ? nlist : 0) + l + 1];
                         size_t &f = F[brick_of(G, tu, tv, ti)];
                         f = std::min(f, l);
@@ -206,11 +322,11 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
             for (int tv = 0; tv < P.ntv; ++tv)
                 for (int tu = 0; tu < P.ntu; ++tu) {
                     Piece pc[2];
-                    const int np = pieces_of(box[g], tu, tv, ti, pc);
+                    const int np = pieces_of(boxes[g], tu, tv, ti, pc);
                     for (int q = 0; q < np; ++q) {
-                        const size_t l = list_of(g, pc[q].behind, tu, tv, ti, G.offset);
+                        const size_t l = list_of(g, pc[q].phase, tu, tv, ti, G.offset);
                         BrickTask T;
-                        T.tv = (int16_t)tv;
+                        T.tv = (int16_t)(cut[l] ? tv | (pc[q].box << kBrickBoxShift) : tv);
                         T.group = (int16_t)(cut[l] ? (int)g | (pc[q].lane_hi << kBrickLaneHiShift) : (int)g);
                         T.tu = (int16_t)(uint16_t)(cut[l] ? tu | (pc[q].lane_lo << kBrickLaneLoShift) : tu);
                         // (two pieces of one brick write different lanes of rows that start from zero: either may come first)
@@ -222,7 +338,7 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
                     }
                 }
     }
-    if (P.ntu > kBrickTuMask || (int)P.groups.size() > kBrickGroupMask) { free_hybrid(c); return fail(c, FTTE_ERR_UNSUPPORTED, "hybrid sweep: more than 1023 bricks along a row, or more than 255 groups of directions"); }
+    if (P.ntu > kBrickTuMask || P.ntv > kBrickTvMask || (int)P.groups.size() > kBrickGroupMask) { free_hybrid(c); return fail(c, FTTE_ERR_UNSUPPORTED, "hybrid sweep: more than 1023 bricks along a row, or more than 255 groups of directions"); }
 
     // The forests, restricted to the boxes: linked on the host a few directions at a time.  Once the leaves that lie in any box are
     // known they are numbered by their place in that list, and segments (3 * place + piece), activity bytes, opacities and scratch
@@ -247,8 +363,9 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
             pool.emplace_back([&, t] {
                 const int d = d0 + t;
                 const DirPlan &D = P.dirs[(size_t)d];
-                const Box &B = box[(size_t)group_of[(size_t)d]];
-                st[t] = build_forest(c->tree, D.phi, D.theta, D.izone, c->box, &F[t], &msg[t], &B.R);
+                std::vector<ForestRegion> regions;
+                for (const HybridBox &B : boxes[(size_t)group_of[(size_t)d]]) regions.push_back(B.R);
+                st[t] = build_forest_regions(c->tree, D.phi, D.theta, D.izone, c->box, &F[t], &msg[t], regions);
                 if (st[t]) return;
                 const AmrForest &f = F[t];
                 const size_t nact = f.order.size();
@@ -467,6 +584,7 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
     // ---- per half: bricks not behind the boxes, the forests of the boxes (all directions of the half per depth launch), the
     // bricks behind them.  The halves run side by side on two streams and meet only in J: the second half's means are added
     // after the first half's (an event), the bricks' accumulators after both.
+    if (H.npass > 1 && batch < ndir) return FTTE_OK; // several passes keep every direction's scratch: leave it to the forest path
     const int nh = (H.nhalves > 1 && batch >= ndir) ? H.nhalves : 1; // scratch for every direction at once, or one pipeline
     hipStream_t qs[ftte_ctx::kMaxPipes] = {stream, stream, stream, stream};
     if (nh > 1) {
@@ -512,14 +630,28 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
         FTTE_HIP(c, hipEventRecord(c->ev_fork, stream));
         for (int r = 1; r < nh; ++r) FTTE_HIP(c, hipStreamWaitEvent(qs[r], c->ev_fork, 0));
     }
-    // issued phase by phase, alternating between the streams, so that none waits for the host to finish with the others
+    // issued phase by phase, alternating between the streams, so that none waits for the host to finish with the others:
+    // bricks of phase 0, forests pass 0, bricks of phase 1, ..., the means into J, the bricks behind the last boxes
+    const size_t per_phase = H.phase1_stages;
+    for (int pass = 0; pass < H.npass; ++pass) {
+        for (int h = 0; h < H.nhalves; ++h)
+            if ((rc = brick_stages(h, (size_t)pass * per_phase, (size_t)(pass + 1) * per_phase, qs[nh > 1 ? h : 0]))) return rc;
+        if (H.npass == 1) break; // one pass: launch_forests below does it batch by batch
+        for (int r = 0; r < nh; ++r)
+            if ((rc = launch_forest_pass(c, qs[r], runs[(size_t)r], 0, (size_t)pass, A))) return rc;
+    }
+    for (int r = 0; r < nh; ++r) {
+        hipEvent_t before = (nh > 1 && r > 0) ? c->ev_combine[r - 1] : nullptr, after = (nh > 1 && r + 1 < nh) ? c->ev_combine[r] : nullptr;
+        if (H.npass == 1) {
+            if ((rc = launch_forests(c, qs[r], runs[(size_t)r], A, J_dev, false, false, before, after))) return rc;
+        } else { // (several passes: every direction of the run is resident, one batch)
+            if (before) FTTE_HIP(c, hipStreamWaitEvent(qs[r], before, 0));
+            if ((rc = launch_forest_combine(c, qs[r], runs[(size_t)r], 0, A, J_dev, false))) return rc;
+            if (after) FTTE_HIP(c, hipEventRecord(after, qs[r]));
+        }
+    }
     for (int h = 0; h < H.nhalves; ++h)
-        if ((rc = brick_stages(h, 0, H.phase1_stages, qs[nh > 1 ? h : 0]))) return rc;
-    for (int r = 0; r < nh; ++r)
-        if ((rc = launch_forests(c, qs[r], runs[(size_t)r], A, J_dev, false, false, (nh > 1 && r > 0) ? c->ev_combine[r - 1] : nullptr,
-                                 (nh > 1 && r + 1 < nh) ? c->ev_combine[r] : nullptr))) return rc;
-    for (int h = 0; h < H.nhalves; ++h)
-        if ((rc = brick_stages(h, H.phase1_stages, H.nlist, qs[nh > 1 ? h : 0]))) return rc;
+        if ((rc = brick_stages(h, (size_t)H.npass * per_phase, H.nlist, qs[nh > 1 ? h : 0]))) return rc;
     for (int r = 1; r < nh; ++r) {
         FTTE_HIP(c, hipEventRecord(c->lane_done[(size_t)r - 1], qs[r]));
         FTTE_HIP(c, hipStreamWaitEvent(stream, c->lane_done[(size_t)r - 1], 0));

@@ -107,7 +107,9 @@ struct BrickTask { int16_t group, tu, tv, ti; };
 constexpr int kBrickAccumulate = 0x4000;
 // A task that sweeps a range of lanes only (hybrid sweep, brick_kernel<..., MASKED>): tu bits 0-9 the brick, bits 10-15 the first
 // lane; group bits 0-7 the group, bits 8-13 the last lane
+// lane; tv bits 0-9 the brick, bits 10-14 the box whose face rings the lanes' ends use
 constexpr int kBrickTuMask = 0x3ff, kBrickLaneLoShift = 10, kBrickGroupMask = 0xff, kBrickLaneHiShift = 8;
+constexpr int kBrickTvMask = 0x3ff, kBrickBoxShift = 10, kBrickBoxMask = 31;
 static_assert(sizeof(BrickTask) == 8, "BrickTask must be 8 bytes");
 
 struct BrickLaunch {
@@ -117,8 +119,8 @@ struct BrickLaunch {
     int64_t group_stride;     // elements between frequency groups in kappa / J
     int64_t face_stride;      // elements between frequency groups in a direction's face rings
     int64_t vface_off, iface_off; // where the v-face and i-face rings start inside a direction's block (u-face ring at 0)
-    int64_t uqface_off;       // two more rings laid out like the u-faces of ONE column of bricks: the near and the far u-face of the
-                              // direction's box where they lie inside a brick (masked bricks of the hybrid sweep)
+    int64_t uqface_off;       // more rings laid out like the u-faces of ONE column of bricks, two per box of the direction: the near and
+                              // the far u-face of the box where they lie inside a brick (masked bricks of the hybrid sweep)
     int32_t n, ntasks, nnu, chunk; // nnu: frequency groups THIS launch sweeps, nu0, nu0 + 1, ...
     int32_t nu0;
     int32_t emit;             // 0 none, 1 BrickGroup::emis is the reference's eta, 2 a source function (LaunchRec::emit)

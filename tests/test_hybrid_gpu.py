@@ -137,6 +137,34 @@ def test_refined_cells_on_the_domain_boundary(corner):
     assert np.allclose(J_all, J_forest, rtol=SUM_RTOL, atol=0)
 
 
+def test_several_clusters_of_refined_cells_get_boxes_of_their_own():
+    """Refined cells in clusters far apart: a box per cluster, the forests of boxes that lie behind other boxes swept in later
+    passes with the bricks in between (three patches along a diagonal, so that for most izones each lies behind the one before, and
+    two more side by side).  Against the forest path of the whole tree: single directions bit for bit, all together to the
+    rounding of the sum; reproducible."""
+    n = 128
+    blocks = []
+    for corner in [(20, 24, 18), (60, 58, 64), (100, 104, 98), (22, 100, 60), (100, 20, 64)]:
+        blocks += [(corner[0] + a, corner[1] + b, corner[2] + c) for a in range(2) for b in range(3) for c in range(2)]
+    level, kappa, uvb = patch_case(n, blocks, 1, 2, seed=13)
+    dirs = one_per_izone()
+    phi, theta = np.array([d[0] for d in dirs]), np.array([d[1] for d in dirs])
+    w = np.full(len(dirs), 1.0 / len(dirs))
+    with rt.DiffuseTransfer() as e:
+        e.set_grid(n, level, 1.0)
+        e.set_opacity(kappa)
+        J_all = e.transport(phi, theta, w, uvb)
+        assert e.counter("hybrid_boxes") == 5 and e.counter("hybrid_passes") >= 3
+        assert np.array_equal(J_all, e.transport(phi, theta, w, uvb))
+        singles = [e.transport(phi[d:d + 1], theta[d:d + 1], w[d:d + 1], uvb) for d in range(0, 24, 3)]
+        e.set_option("hybrid", 0)
+        J_forest = e.transport(phi, theta, w, uvb)
+        assert e.counter("hybrid_boxes") == 0
+        for k, d in enumerate(range(0, 24, 3)):
+            assert np.array_equal(singles[k], e.transport(phi[d:d + 1], theta[d:d + 1], w[d:d + 1], uvb)), f"direction {d}"
+    assert np.allclose(J_all, J_forest, rtol=SUM_RTOL, atol=0)
+
+
 def test_hybrid_more_directions_than_a_forest_batch():
     """192 directions, first all at once, then with forest batches capped at 40 directions (what a tree too large for the
     device memory gets): the pipelines can then not run side by side (their scratch would overlap) and take turns on one stream
