@@ -26,7 +26,7 @@ def main():
         n = int(rng.choice([64, 72, 96, 100, 128, 136]))
         nnu = int(rng.integers(1, 4))
         blocks = []
-        for _ in range(int(rng.integers(1, 3))):      # one or two clusters
+        for _ in range(int(rng.integers(1, 6))):      # one to five clusters: boxes of their own where they lie apart
             size = rng.integers(1, 5, 3)
             corner = [int(rng.choice([0, n - s, rng.integers(0, n - s + 1)], p=[0.1, 0.1, 0.8])) for s in size]
             blocks += [(corner[0] + a, corner[1] + b, corner[2] + c) for a in range(size[0]) for b in range(size[1]) for c in range(size[2])]
@@ -50,7 +50,7 @@ def main():
                 eng.set_option(k, v)
             J = eng.transport(phi, theta, w, uvb)
             again = eng.transport(phi, theta, w, uvb)
-            plans = eng.counter("forest_builds")
+            shape = (eng.counter("hybrid_boxes"), eng.counter("hybrid_passes"))
             eng.set_option("hybrid", 0)
             ref = eng.transport(phi, theta, w, uvb)
         err = float(np.max(np.abs(J - ref) / np.abs(ref)))
@@ -58,7 +58,7 @@ def main():
         worst = max(worst, err)
         ok = err < 1e-13 and same and np.all(np.isfinite(J))
         print(f"case {case:3d}: n={n:3d} nnu={nnu} ndir={pick.size:2d} depth={depth} refined base cells={len(set(blocks)):3d} {opts}: "
-              f"max rel diff {err:.2e}{'' if same else ' NOT REPRODUCIBLE'} ({time.perf_counter() - t0:.1f} s){'' if ok else '   <-- FAIL'}", flush=True)
+              f"boxes {shape[0]} passes {shape[1]}: max rel diff {err:.2e}{'' if same else ' NOT REPRODUCIBLE'} ({time.perf_counter() - t0:.1f} s){'' if ok else '   <-- FAIL'}", flush=True)
         hybrid_taken += 1
         if not ok:
             sys.exit(1)
