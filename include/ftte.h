@@ -323,6 +323,8 @@ long long ftte_counter(const ftte_ctx *ctx, const char *name);
  *     "pipelines"   hybrid: independent bricks-forests-bricks sequences on streams of their own, 1..4 (default 3)
  *     "box_lanes"   hybrid: along a brick's 64 lanes the boxes end on multiples of this (a divisor of 64; default 1: one cell beyond
  *                   the refined cells)
+ *     "graph"       hybrid: 1 = the launches of a sweep are captured once into a hipGraph and replayed (default 0: measured slower
+ *                   than issuing them on this runtime)
  *     "forest_batch" most directions per launch of the segment forests (0: what the path and the device memory allow)
  *     "forest"      1: use the segment forests on a uniform grid too, for cross-checks
  *   "ldspad"        diagnostic: extra dynamic LDS per workgroup (bytes), to cap residency */

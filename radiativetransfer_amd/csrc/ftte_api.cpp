@@ -295,6 +295,9 @@ int ftte_set_option(ftte_ctx *c, const char *key, int value)
         if (value != 0 && value != 1) return fail(c, FTTE_ERR_ARG, "hybrid must be 0 (a refined cell array goes through the forest path as a whole) or 1 (bricks outside a box around the refined cells)");
         c->hybrid = value;
         c->hplan.valid = false;
+    } else if (!std::strcmp(key, "graph")) {
+        if (value != 0 && value != 1) return fail(c, FTTE_ERR_ARG, "graph must be 0 (every launch of the hybrid sweep issued every time) or 1 (captured once, replayed)");
+        c->use_graph = value;
     } else if (!std::strcmp(key, "box_lanes")) {
         if (value < 1 || value > 64 || 64 % value) return fail(c, FTTE_ERR_ARG, "box_lanes (the boxes of the hybrid sweep end on multiples of it along a brick's 64 lanes) must divide 64");
         c->hybrid_lanes = value;

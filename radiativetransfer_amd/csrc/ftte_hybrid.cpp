@@ -12,8 +12,16 @@ namespace ftte {
 // buffers, rays leaving it written there), then the bricks behind it.  J of a cell = what the bricks stored for the
 // directions in whose box it does not lie + what the forest adds for the others.
 
+static void drop_graph(ftte_ctx::HybridPlan &H)
+{
+    if (H.graph_exec) (void)hipGraphExecDestroy(H.graph_exec);
+    H.graph_exec = nullptr;
+    H.graph_sig.clear();
+}
+
 void free_hybrid(ftte_ctx *c)
 {
+    drop_graph(c->hplan);
     for (auto &d : c->hplan.dirs) {
         if (d.rec) (void)hipFree(d.rec);
         if (d.active) (void)hipFree(d.active);
@@ -545,18 +553,6 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
     LaunchTiming &Tm = c->timing[0];
     Tm.updates = (int64_t)ndir * ncell * nnu; Tm.lanes = 0;
     c->timing_used = 0;
-    FTTE_HIP(c, hipEventRecord(Tm.start, stream));
-
-    // ---- opacity of the base cells in the three layouts; accumulators and J start from zero
-    if (launch_base_cells(c->kappa[0], c->d_leaf_of_base, c->base_kappa[0], (long)nbase, (long)ncell, nnu, stream))
-        return fail(c, FTTE_ERR_NO_DEVICE, "base-cell kernel launch failed");
-    for (int l = 1; l < 3; ++l)
-        if (P.nacc[l] && launch_to_layout(l, c->base_kappa[0], c->base_kappa[l], n, nnu, (long)nbase, stream))
-            return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
-    for (int l = 0; l < 3; ++l)
-        for (int s = 0; s < P.nacc[l]; ++s) FTTE_HIP(c, hipMemsetAsync(c->acc[l][s], 0, sizeof(double) * per_base, stream));
-    FTTE_HIP(c, hipMemsetAsync(J_dev, 0, sizeof(double) * (size_t)nnu * ncell, stream));
-
     static const ftte_consts kMath = FTTE_CONSTS_INIT;
     const size_t masked_lists = (size_t)H.nhalves * H.nlist;
     auto brick_stages = [&](int half, size_t from, size_t to, hipStream_t q) -> int {
@@ -626,46 +622,95 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
         // one batch per pipeline when they run side by side (their scratch must not overlap), else `batch` directions at a time
         if ((rc = prepare_forests(c, stream, sets, slot0, nh > 1 ? ndir : batch, per_dir, &runs))) return rc;
     }
-    if (nh > 1) {
-        FTTE_HIP(c, hipEventRecord(c->ev_fork, stream));
-        for (int r = 1; r < nh; ++r) FTTE_HIP(c, hipStreamWaitEvent(qs[r], c->ev_fork, 0));
-    }
-    // issued phase by phase, alternating between the streams, so that none waits for the host to finish with the others:
-    // bricks of phase 0, forests pass 0, bricks of phase 1, ..., the means into J, the bricks behind the last boxes
-    const size_t per_phase = H.phase1_stages;
-    for (int pass = 0; pass < H.npass; ++pass) {
-        for (int h = 0; h < H.nhalves; ++h)
-            if ((rc = brick_stages(h, (size_t)pass * per_phase, (size_t)(pass + 1) * per_phase, qs[nh > 1 ? h : 0]))) return rc;
-        if (H.npass == 1) break; // one pass: launch_forests below does it batch by batch
-        for (int r = 0; r < nh; ++r)
-            if ((rc = launch_forest_pass(c, qs[r], runs[(size_t)r], 0, (size_t)pass, A))) return rc;
-    }
-    for (int r = 0; r < nh; ++r) {
-        hipEvent_t before = (nh > 1 && r > 0) ? c->ev_combine[r - 1] : nullptr, after = (nh > 1 && r + 1 < nh) ? c->ev_combine[r] : nullptr;
-        if (H.npass == 1) {
-            if ((rc = launch_forests(c, qs[r], runs[(size_t)r], A, J_dev, false, false, before, after))) return rc;
-        } else { // (several passes: every direction of the run is resident, one batch)
-            if (before) FTTE_HIP(c, hipStreamWaitEvent(qs[r], before, 0));
-            if ((rc = launch_forest_combine(c, qs[r], runs[(size_t)r], 0, A, J_dev, false))) return rc;
-            if (after) FTTE_HIP(c, hipEventRecord(after, qs[r]));
-        }
-    }
-    for (int h = 0; h < H.nhalves; ++h)
-        if ((rc = brick_stages(h, (size_t)H.npass * per_phase, H.nlist, qs[nh > 1 ? h : 0]))) return rc;
-    for (int r = 1; r < nh; ++r) {
-        FTTE_HIP(c, hipEventRecord(c->lane_done[(size_t)r - 1], qs[r]));
-        FTTE_HIP(c, hipStreamWaitEvent(stream, c->lane_done[(size_t)r - 1], 0));
-    }
-
-    // ---- J of the unrefined base cells += what the bricks stored (layout after layout, accumulator after accumulator)
-    {
-        const double *accs[3 * kMaxAcc];
-        int layouts[3 * kMaxAcc], count = 0;
+    // ---- the launches of one sweep: the same sequence every iteration while plan and buffers stay what they are
+    auto issue = [&]() -> int {
+        // ---- opacity of the base cells in the three layouts; accumulators and J start from zero
+        if (launch_base_cells(c->kappa[0], c->d_leaf_of_base, c->base_kappa[0], (long)nbase, (long)ncell, nnu, stream))
+            return fail(c, FTTE_ERR_NO_DEVICE, "base-cell kernel launch failed");
+        for (int l = 1; l < 3; ++l)
+            if (P.nacc[l] && launch_to_layout(l, c->base_kappa[0], c->base_kappa[l], n, nnu, (long)nbase, stream))
+                return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
         for (int l = 0; l < 3; ++l)
-            for (int s = 0; s < P.nacc[l]; ++s) { accs[count] = c->acc[l][s]; layouts[count++] = l; }
-        if (count && launch_merge(accs, layouts, count, J_dev, n, nnu, (long)nbase, true, stream, c->d_leaf_of_base, (long)ncell))
-            return fail(c, FTTE_ERR_NO_DEVICE, "merge kernel launch failed");
+            for (int s = 0; s < P.nacc[l]; ++s) FTTE_HIP(c, hipMemsetAsync(c->acc[l][s], 0, sizeof(double) * per_base, stream));
+        FTTE_HIP(c, hipMemsetAsync(J_dev, 0, sizeof(double) * (size_t)nnu * ncell, stream));
+
+        if (nh > 1) {
+            FTTE_HIP(c, hipEventRecord(c->ev_fork, stream));
+            for (int r = 1; r < nh; ++r) FTTE_HIP(c, hipStreamWaitEvent(qs[r], c->ev_fork, 0));
+        }
+        // issued phase by phase, alternating between the streams, so that none waits for the host to finish with the others:
+        // bricks of phase 0, forests pass 0, bricks of phase 1, ..., the means into J, the bricks behind the last boxes
+        const size_t per_phase = H.phase1_stages;
+        for (int pass = 0; pass < H.npass; ++pass) {
+            for (int h = 0; h < H.nhalves; ++h)
+                if ((rc = brick_stages(h, (size_t)pass * per_phase, (size_t)(pass + 1) * per_phase, qs[nh > 1 ? h : 0]))) return rc;
+            if (H.npass == 1) break; // one pass: launch_forests below does it batch by batch
+            for (int r = 0; r < nh; ++r)
+                if ((rc = launch_forest_pass(c, qs[r], runs[(size_t)r], 0, (size_t)pass, A))) return rc;
+        }
+        for (int r = 0; r < nh; ++r) {
+            hipEvent_t before = (nh > 1 && r > 0) ? c->ev_combine[r - 1] : nullptr, after = (nh > 1 && r + 1 < nh) ? c->ev_combine[r] : nullptr;
+            if (H.npass == 1) {
+                if ((rc = launch_forests(c, qs[r], runs[(size_t)r], A, J_dev, false, false, before, after))) return rc;
+            } else { // (several passes: every direction of the run is resident, one batch)
+                if (before) FTTE_HIP(c, hipStreamWaitEvent(qs[r], before, 0));
+                if ((rc = launch_forest_combine(c, qs[r], runs[(size_t)r], 0, A, J_dev, false))) return rc;
+                if (after) FTTE_HIP(c, hipEventRecord(after, qs[r]));
+            }
+        }
+        for (int h = 0; h < H.nhalves; ++h)
+            if ((rc = brick_stages(h, (size_t)H.npass * per_phase, H.nlist, qs[nh > 1 ? h : 0]))) return rc;
+        for (int r = 1; r < nh; ++r) {
+            FTTE_HIP(c, hipEventRecord(c->lane_done[(size_t)r - 1], qs[r]));
+            FTTE_HIP(c, hipStreamWaitEvent(stream, c->lane_done[(size_t)r - 1], 0));
+        }
+
+        // ---- J of the unrefined base cells += what the bricks stored (layout after layout, accumulator after accumulator)
+        {
+            const double *accs[3 * kMaxAcc];
+            int layouts[3 * kMaxAcc], count = 0;
+            for (int l = 0; l < 3; ++l)
+                for (int s = 0; s < P.nacc[l]; ++s) { accs[count] = c->acc[l][s]; layouts[count++] = l; }
+            if (count && launch_merge(accs, layouts, count, J_dev, n, nnu, (long)nbase, true, stream, c->d_leaf_of_base, (long)ncell))
+                return fail(c, FTTE_ERR_NO_DEVICE, "merge kernel launch failed");
+        }
+        return FTTE_OK;
+    };
+
+    // The sequence is hundreds of short launches on up to three streams (more with several passes).  Option "graph" = 1 captures it
+    // once into a hipGraph -- the streams' forks and joins become dependencies of the graph -- and replays it while the plan, J and
+    // every buffer and table the launches name stay the same.  Measured on ROCm 7.2 / MI355X the replay is SLOWER than issuing the
+    // launches (configs[3]: 15.8 against 12.2 ms; 8 clusters in 5 passes: 23.9 against 15.1 ms), so it is off by default.
+    std::vector<uintptr_t> sig = {(uintptr_t)J_dev, (uintptr_t)stream, (uintptr_t)nnu, (uintptr_t)nh, (uintptr_t)c->kappa[0], (uintptr_t)c->amr_kappa,
+                                  (uintptr_t)c->d_faces, (uintptr_t)c->amr_Iout, (uintptr_t)c->amr_mean, (uintptr_t)c->d_bgroups, (uintptr_t)c->d_btasks,
+                                  (uintptr_t)c->d_amr_dirs, (uintptr_t)c->d_amr_tables, (uintptr_t)c->d_uvb, (uintptr_t)c->d_leaf_of_base, (uintptr_t)H.cells,
+                                  (uintptr_t)c->brick_waves};
+    for (int l = 0; l < 3; ++l) { sig.push_back((uintptr_t)c->base_kappa[l]); for (int s2 = 0; s2 < P.nacc[l]; ++s2) sig.push_back((uintptr_t)c->acc[l][s2]); }
+    FTTE_HIP(c, hipEventRecord(Tm.start, stream));
+    bool replayed = false;
+    if (c->use_graph && H.graph_exec && H.graph_sig == sig) {
+        if (hipGraphLaunch(H.graph_exec, stream) == hipSuccess) replayed = true;
+        else { (void)hipGetLastError(); drop_graph(H); }
     }
+    if (!replayed && c->use_graph) {
+        drop_graph(H);
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
+            const int irc = issue();
+            const hipError_t e = hipStreamEndCapture(stream, &graph);
+            if (irc == FTTE_OK && e == hipSuccess && graph && hipGraphInstantiate(&H.graph_exec, graph, nullptr, nullptr, 0) == hipSuccess &&
+                hipGraphLaunch(H.graph_exec, stream) == hipSuccess) {
+                H.graph_sig = sig;
+                replayed = true;
+            } else {
+                (void)hipGetLastError();
+                drop_graph(H);
+                c->use_graph = 0; // this runtime or this sequence does not capture: launches one by one from now on
+            }
+            if (graph) (void)hipGraphDestroy(graph);
+        } else { (void)hipGetLastError(); c->use_graph = 0; }
+    }
+    if (!replayed && (rc = issue())) return rc;
     FTTE_HIP(c, hipEventRecord(Tm.stop, stream));
     c->timing_used = 1;
     *done = true;

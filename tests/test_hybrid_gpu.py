@@ -165,6 +165,29 @@ def test_several_clusters_of_refined_cells_get_boxes_of_their_own():
     assert np.allclose(J_all, J_forest, rtol=SUM_RTOL, atol=0)
 
 
+def test_launches_replayed_from_a_captured_graph():
+    """Option "graph": the hybrid sweep's launches (three streams, forks and joins) captured once into a hipGraph and replayed while
+    nothing they name changes; new opacities and a new J array go through.  Same bits as the launches issued one by one."""
+    n = 128
+    blocks = [(40 + a, 50 + b, 60 + c) for a in range(3) for b in range(3) for c in range(3)] + [(100 + a, 20, 90) for a in range(2)]
+    level, kappa, uvb = patch_case(n, blocks, 1, 2, seed=21)
+    phi, theta, w = O.healpix_directions(2)
+    with rt.DiffuseTransfer() as e:
+        e.set_grid(n, level, 1.0)
+        e.set_opacity(kappa)
+        J_plain = e.transport(phi, theta, w, uvb)
+        e.set_opacity(0.5 * kappa)
+        J_half = e.transport(phi, theta, w, uvb)
+        e.set_option("graph", 1)
+        e.set_opacity(kappa)
+        J_captured = e.transport(phi, theta, w, uvb)       # captures
+        J_replayed = e.transport(phi, theta, w, uvb)       # replays
+        e.set_opacity(0.5 * kappa)
+        J_half_replayed = e.transport(phi, theta, w, uvb)  # replays on new opacities
+    assert np.array_equal(J_captured, J_plain) and np.array_equal(J_replayed, J_plain)
+    assert np.array_equal(J_half_replayed, J_half)
+
+
 def test_hybrid_more_directions_than_a_forest_batch():
     """192 directions, first all at once, then with forest batches capped at 40 directions (what a tree too large for the
     device memory gets): the pipelines can then not run side by side (their scratch would overlap) and take turns on one stream

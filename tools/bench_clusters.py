@@ -15,8 +15,9 @@ sys.path.insert(0, ROOT)
 import radiativetransfer_amd as rt
 from radiativetransfer_amd import synthetic
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-k = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+n = int(args[0]) if len(args) > 0 else 128
+k = int(args[1]) if len(args) > 1 else 8
 rng = np.random.default_rng(5)
 blocks = []
 for _ in range(k):
@@ -37,6 +38,8 @@ for hybrid in (1, 0):
     eng = rt.DiffuseTransfer(device=0)
     eng.set_grid(n, level, 3.0e22)
     eng.set_option("hybrid", hybrid)
+    if "--no-graph" in sys.argv:
+        eng.set_option("graph", 0)
     for it in range(4):
         t0 = time.perf_counter()
         eng.set_opacity_device(nnu, kappa.data_ptr())
