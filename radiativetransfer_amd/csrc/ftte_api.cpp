@@ -86,6 +86,7 @@ int ftte_destroy(ftte_ctx *c)
     free_hybrid(c);
     if (c->d_leaf_of_base) (void)hipFree(c->d_leaf_of_base);
     for (int l = 0; l < 3; ++l) if (c->base_kappa[l]) (void)hipFree(c->base_kappa[l]);
+    for (int l = 0; l < 3; ++l) if (c->base_emis[l]) (void)hipFree(c->base_emis[l]);
     if (c->amr_Iout) (void)hipFree(c->amr_Iout);
     if (c->amr_mean) (void)hipFree(c->amr_mean);
     if (c->d_amr_dirs) (void)hipFree(c->d_amr_dirs);
@@ -344,7 +345,7 @@ int ftte_diffuse_sweep_device(ftte_ctx *c, int ndir, const double *phi, const do
     hipStream_t stream = stream_v ? (hipStream_t)stream_v : c->stream;
 
     if (c->use_forest) {
-        if (c->hybrid && c->tree.refined() && !c->force_forest && !c->emit_mode && ndir > 0) {
+        if (c->hybrid && c->tree.refined() && !c->force_forest && ndir > 0) {
             bool done = false;
             if ((rc = hybrid_sweep(c, ndir, phi, theta, w, uvb, J_dev, stream, &done)) || done) return rc;
         }

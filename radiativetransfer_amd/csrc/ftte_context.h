@@ -226,6 +226,8 @@ struct ftte_ctx {
     int32_t *d_leaf_of_base = nullptr;
     double *base_kappa[3] = {nullptr, nullptr, nullptr};
     size_t base_kappa_cap = 0;
+    double *base_emis[3] = {nullptr, nullptr, nullptr}; // emissivity / source function of the base cells (hybrid sweep with emission)
+    size_t base_emis_cap = 0;
 
     PointState point; // point sources: rate tables, medium, tracer scratch
 

@@ -479,6 +479,12 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
         for (int l = 0; l < 3; ++l) FTTE_HIP(c, hipMalloc((void **)&c->base_kappa[l], sizeof(double) * per_base));
         c->base_kappa_cap = per_base;
     }
+    const int emit = c->emit_mode;
+    if (emit && c->base_emis_cap < per_base) {
+        for (int l = 0; l < 3; ++l) if (c->base_emis[l]) { FTTE_HIP(c, hipFree(c->base_emis[l])); c->base_emis[l] = nullptr; }
+        for (int l = 0; l < 3; ++l) FTTE_HIP(c, hipMalloc((void **)&c->base_emis[l], sizeof(double) * per_base));
+        c->base_emis_cap = per_base;
+    }
     if (c->acc_cap < (size_t)nnu * (size_t)ncell) {
         for (int l = 0; l < 3; ++l)
             for (int s = 0; s < kMaxAcc; ++s)
@@ -506,6 +512,7 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
             const BrickPlan::Group &Hg = P.groups[g];
             const DirPlan &D0 = P.dirs[Hg.dirs[0]];
             G[g].kappa = c->base_kappa[Hg.layout];
+            G[g].emis = emit ? c->base_emis[Hg.layout] : nullptr;
             G[g].J = c->acc[Hg.layout][Hg.acc];
             G[g].org = D0.org; G[g].si = D0.si; G[g].sv = D0.sv; G[g].su = D0.su;
             G[g].ndir = (int)Hg.dirs.size();
@@ -543,6 +550,11 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
         if (launch_cell_major(c->kappa[0], c->amr_kappa, ncell, nnu, stream, H.cells, (long)H.ncells)) return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
         c->kappa_ready[3] = true; c->amr_kappa_form = 1;
     }
+    if (emit) { // the emissivity / source function of the boxes' leaves, cell-major like their opacities; new every iteration
+        if ((rc = ensure(c, &c->amr_emis, &c->amr_emis_cap, (size_t)nnu * (size_t)std::max<int64_t>(H.ncells, 1)))) return rc;
+        if (launch_cell_major(c->emis[0], c->amr_emis, ncell, nnu, stream, H.cells, (long)H.ncells)) return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
+        c->emis_ready[3] = false; // (the forest path for the whole tree keeps every leaf there)
+    }
 
     while (c->timing.size() < 1) {
         LaunchTiming t;
@@ -570,6 +582,7 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
             L.vface_off = P.vface_off; L.iface_off = P.iface_off; L.uqface_off = P.uqface_off;
             L.n = n; L.ntasks = (int)(off[l + 1] - off[l]); L.nnu = nnu; L.nu0 = 0; L.chunk = P.chunk;
             L.up = P.up; L.vp = P.vp; L.uw = P.uw; L.ut = P.ut; L.nslot = P.nslot;
+            L.emit = emit;
             L.math = kMath;
             const int lrc = launch_brick(L, P.max_dirs, c->brick_waves, q, masked != 0);
             if (lrc) return fail(c, lrc == -1 ? FTTE_ERR_ARG : FTTE_ERR_NO_DEVICE, "brick kernel launch failed");
@@ -598,9 +611,9 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
     }
     AmrLevelRec A;
     std::memset(&A, 0, sizeof A);
-    A.kappa = c->amr_kappa; A.emis = nullptr;
+    A.kappa = c->amr_kappa; A.emis = emit ? c->amr_emis : nullptr;
     A.group_stride = 1; A.cell_stride = nnu;
-    A.emit = 0;
+    A.emit = emit;
     A.uvb = c->d_uvb;
     A.ncell = ncell; A.nnu = nnu;
     A.cells = H.cells; A.ncells = H.ncells;
@@ -630,6 +643,13 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
         for (int l = 1; l < 3; ++l)
             if (P.nacc[l] && launch_to_layout(l, c->base_kappa[0], c->base_kappa[l], n, nnu, (long)nbase, stream))
                 return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
+        if (emit) { // and their emissivity / source function
+            if (launch_base_cells(c->emis[0], c->d_leaf_of_base, c->base_emis[0], (long)nbase, (long)ncell, nnu, stream))
+                return fail(c, FTTE_ERR_NO_DEVICE, "base-cell kernel launch failed");
+            for (int l = 1; l < 3; ++l)
+                if (P.nacc[l] && launch_to_layout(l, c->base_emis[0], c->base_emis[l], n, nnu, (long)nbase, stream))
+                    return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
+        }
         for (int l = 0; l < 3; ++l)
             for (int s = 0; s < P.nacc[l]; ++s) FTTE_HIP(c, hipMemsetAsync(c->acc[l][s], 0, sizeof(double) * per_base, stream));
         FTTE_HIP(c, hipMemsetAsync(J_dev, 0, sizeof(double) * (size_t)nnu * ncell, stream));
@@ -684,7 +704,8 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
     std::vector<uintptr_t> sig = {(uintptr_t)J_dev, (uintptr_t)stream, (uintptr_t)nnu, (uintptr_t)nh, (uintptr_t)c->kappa[0], (uintptr_t)c->amr_kappa,
                                   (uintptr_t)c->d_faces, (uintptr_t)c->amr_Iout, (uintptr_t)c->amr_mean, (uintptr_t)c->d_bgroups, (uintptr_t)c->d_btasks,
                                   (uintptr_t)c->d_amr_dirs, (uintptr_t)c->d_amr_tables, (uintptr_t)c->d_uvb, (uintptr_t)c->d_leaf_of_base, (uintptr_t)H.cells,
-                                  (uintptr_t)c->brick_waves};
+                                  (uintptr_t)c->brick_waves, (uintptr_t)emit, (uintptr_t)c->emis[0], (uintptr_t)c->amr_emis,
+                                  (uintptr_t)c->base_emis[0], (uintptr_t)c->base_emis[1], (uintptr_t)c->base_emis[2]};
     for (int l = 0; l < 3; ++l) { sig.push_back((uintptr_t)c->base_kappa[l]); for (int s2 = 0; s2 < P.nacc[l]; ++s2) sig.push_back((uintptr_t)c->acc[l][s2]); }
     FTTE_HIP(c, hipEventRecord(Tm.start, stream));
     bool replayed = false;

@@ -165,6 +165,41 @@ def test_several_clusters_of_refined_cells_get_boxes_of_their_own():
     assert np.allclose(J_all, J_forest, rtol=SUM_RTOL, atol=0)
 
 
+@pytest.mark.parametrize("which", ["source", "eta"])
+def test_hybrid_with_emission(which):
+    """A source function (the build's own form) or the reference's disabled emissivity term on a refined cell array:
+    the hybrid sweep carries it through bricks (whole and cut), forests and the hand-overs between them.  Every izone bit for bit
+    against the oracle's tree sweep with the same term; many directions against the forest path; radiative equilibrium (S = inflow)
+    is a fixed point."""
+    n = 64
+    blocks = [(30 + a, 31 + b, 33 + c) for a in range(3) for b in range(2) for c in range(4)]
+    level, kappa, uvb = patch_case(n, blocks, 1, 2, seed=17)
+    rng = np.random.default_rng(4)
+    X = rng.random(kappa.shape) * (2e-21 if which == "source" else 2e-21 * kappa.mean())
+    kw = dict(src=X) if which == "source" else dict(eta=X)
+    with rt.DiffuseTransfer() as e:
+        e.set_grid(n, level, 1.0)
+        e.set_opacity(kappa)
+        (e.set_source_function if which == "source" else e.set_emissivity)(X)
+        for p, t in one_per_izone()[::3]:
+            phi, theta, w = np.array([p]), np.array([t]), np.array([0.37])
+            J = e.transport(phi, theta, w, uvb)
+            ref = O.sweep_tree(n, level, kappa, 1.0, phi, theta, w, uvb, arith=O.ARITH_DEVICE, **kw)
+            assert np.array_equal(J, ref), f"izone {O.fold_direction(p, t)[2]}"
+        assert e.counter("hybrid_boxes") == 1
+        phi, theta, w = O.healpix_directions(2)
+        J_hybrid = e.transport(phi, theta, w, uvb)
+        e.set_option("hybrid", 0)
+        J_forest = e.transport(phi, theta, w, uvb)
+        assert np.allclose(J_hybrid, J_forest, rtol=SUM_RTOL, atol=0)
+        if which == "source":
+            e.set_option("hybrid", 1)
+            e.set_source_function(np.repeat(uvb[:, None], len(level), 1))
+            Jeq = e.transport(phi, theta, w, uvb)
+            assert e.counter("hybrid_boxes") == 1
+            assert np.allclose(Jeq, uvb[:, None] * w.sum(), rtol=64 * EPS, atol=0)
+
+
 def test_launches_replayed_from_a_captured_graph():
     """Option "graph": the hybrid sweep's launches (three streams, forks and joins) captured once into a hipGraph and replayed while
     nothing they name changes; new opacities and a new J array go through.  Same bits as the launches issued one by one."""
