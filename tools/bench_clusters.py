@@ -40,6 +40,9 @@ for hybrid in (1, 0):
     eng.set_option("hybrid", hybrid)
     if "--no-graph" in sys.argv:
         eng.set_option("graph", 0)
+    for opt in sys.argv[1:]:
+        if opt.startswith("--") and "=" in opt:      # e.g. --chunk=8 --pipelines=2
+            eng.set_option(opt[2:].split("=")[0], int(opt.split("=")[1]))
     for it in range(4):
         t0 = time.perf_counter()
         eng.set_opacity_device(nnu, kappa.data_ptr())
