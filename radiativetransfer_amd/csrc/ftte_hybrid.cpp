@@ -217,10 +217,10 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
     H.most_boxes = most_boxes;
     if (!H.worthwhile) return FTTE_OK;
 
-    // Halves: the forests stream records at the memory system's rate while the brick stages of a 128^3 grid are short launches
-    // that leave most of it idle, so the sweep runs as two pipelines (bricks - forests - bricks each) on two streams.  What the
-    // groups of one accumulator write is ordered by their launches, so an accumulator's groups stay together; halves are
-    // balanced by direction count.
+    // Pipelines ("halves" in the names below): the forests stream records at the memory system's rate while the brick stages of a
+    // 128^3 grid are short launches that leave most of it idle, so the sweep runs as up to four independent sequences (bricks -
+    // forests - bricks ...) on streams of their own.  What the groups of one accumulator write is ordered by their launches, so
+    // an accumulator's groups stay together; the pipelines are balanced by direction count.
     std::vector<int> half_of_group(P.groups.size(), 0);
     H.nhalves = 1;
     if (c->halves > 1 && P.nacc[0] + P.nacc[1] + P.nacc[2] >= 2) {
@@ -245,8 +245,9 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
         for (int d = 0; d < ndir; ++d) H.half_dirs[(size_t)half_of_dir[(size_t)d]].push_back(d);
     }
 
-    // tasks: the bricks outside the boxes.  Phase 1: those that do not lie behind their group's box (no tile index at or beyond
-    // the box's first one in all three directions); phase 3: the others.  Within a phase stage by stage as in a plain sweep.
+    // tasks: the bricks outside the boxes, and what the boxes leave of the bricks they cut through.  Phase 0: what lies behind no
+    // box (no brick index at or beyond a box's first one on all three axes); phase k: what needs the forests up to pass k - 1.
+    // Within a phase stage by stage as in a plain sweep.
     int max_offset = 0;
     for (const auto &G : P.groups) max_offset = std::max(max_offset, G.offset);
     const int per_phase = P.ntu + P.ntv + P.nti - 2 + max_offset;
