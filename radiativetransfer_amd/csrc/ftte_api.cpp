@@ -296,6 +296,9 @@ int ftte_set_option(ftte_ctx *c, const char *key, int value)
         if (value != 0 && value != 1) return fail(c, FTTE_ERR_ARG, "hybrid must be 0 (a refined cell array goes through the forest path as a whole) or 1 (bricks outside a box around the refined cells)");
         c->hybrid = value;
         c->hplan.valid = false;
+    } else if (!std::strcmp(key, "hybrid_slots")) {
+        if (value != 0 && value != 1) return fail(c, FTTE_ERR_ARG, "hybrid_slots must be 0 or 1");
+        c->hybrid_slots = value;
     } else if (!std::strcmp(key, "graph")) {
         if (value != 0 && value != 1) return fail(c, FTTE_ERR_ARG, "graph must be 0 (every launch of the hybrid sweep issued every time) or 1 (captured once, replayed)");
         c->use_graph = value;

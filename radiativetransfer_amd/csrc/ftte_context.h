@@ -196,6 +196,7 @@ struct ftte_ctx {
 
     // Hybrid sweep of a refined cell array: bricks outside a box around the refined cells, the segment forest inside it
     int hybrid = 1;                       // option: 0 = the whole tree through the forest path
+    int hybrid_slots = 1;                 // option "slots": 0 = a phase of brick stages per pass even with several passes
     int use_graph = 0;                    // option "graph": replay the hybrid sweep's launches from a captured hipGraph (measured slower)
     int forest_batch = 0;                 // option: most directions per forest batch (0: what the path and the memory allow)
     int hybrid_lanes = 1;                 // option "box_lanes": along u the boxes of the hybrid sweep end on multiples of this many lanes
@@ -209,6 +210,8 @@ struct ftte_ctx {
         size_t phase1_stages = 0;         // stage lists per phase
         hipGraphExec_t graph_exec = nullptr; // the launches of one sweep, captured (hybrid_sweep)
         std::vector<uintptr_t> graph_sig;    // what they name: J, the buffers, the tables
+        bool slots = false;               // several passes: launch lists by slot (earliest launch a brick's inputs allow), not by phase
+        std::vector<std::vector<int>> pass_at; // [pipeline][pass] the list in front of which the pass's forests are launched
         int most_boxes = 0;               // boxes of the izone that has most
         int npass = 1;                    // passes of the forests (boxes behind other boxes wait for the bricks in between); the
                                           // bricks run in npass + 1 phases: before pass 0, after pass 0, ..., after the last

@@ -182,7 +182,7 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
     // short bricks: the box is widened by one brick on every side, and what lies inside it costs several times a brick's bytes
     const int chunk = std::min(c->chunk > 0 ? c->chunk : 4, n);
     const int gmax = c->group > 0 ? c->group : (nnu >= 2 ? 3 : 2);
-    std::vector<double> key = {c->box, (double)chunk, (double)gmax, (double)c->share, (double)c->halves, (double)c->hybrid_lanes};
+    std::vector<double> key = {c->box, (double)chunk, (double)gmax, (double)c->share, (double)c->halves, (double)c->hybrid_lanes, (double)c->hybrid_slots};
     key.insert(key.end(), phi, phi + ndir);
     key.insert(key.end(), theta, theta + ndir);
     key.insert(key.end(), w, w + ndir);
@@ -216,6 +216,20 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
     H.npass = top_level + 1;
     H.most_boxes = most_boxes;
     if (!H.worthwhile) return FTTE_OK;
+
+    // Several passes: every brick gets the earliest launch its own inputs allow ("slots", below) instead of a phase per pass,
+    // which needs accumulators that are not shared between groups (the proof that two groups of one accumulator never meet in a
+    // launch rests on launch = stage + offset).  36 accumulators of a 128^3 base grid are 5 GB and 1 ms of merge.
+    H.slots = H.npass > 1 && c->hybrid_slots;
+    if (H.slots) {
+        int per_layout[3] = {0, 0, 0};
+        for (const auto &G : P.groups) ++per_layout[G.layout];
+        if (per_layout[0] > kMaxAcc || per_layout[1] > kMaxAcc || per_layout[2] > kMaxAcc) H.slots = false;
+    }
+    if (H.slots) {
+        P.nacc[0] = P.nacc[1] = P.nacc[2] = 0;
+        for (auto &G : P.groups) { G.acc = P.nacc[G.layout]++; G.offset = 0; }
+    }
 
     // Pipelines ("halves" in the names below): the forests stream records at the memory system's rate while the brick stages of a
     // 128^3 grid are short launches that leave most of it idle, so the sweep runs as up to four independent sequences (bricks -
@@ -251,12 +265,7 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
     int max_offset = 0;
     for (const auto &G : P.groups) max_offset = std::max(max_offset, G.offset);
     const int per_phase = P.ntu + P.ntv + P.nti - 2 + max_offset;
-    H.nlist = (size_t)(H.npass + 1) * (size_t)per_phase; // phase 0 before the first pass of the forests, phase k after pass k - 1
-    const size_t nlist = (size_t)H.nhalves * H.nlist;
     H.phase1_stages = (size_t)per_phase;
-    auto list_of = [&](size_t g, int phase, int tu, int tv, int ti, int offset) {
-        return (size_t)half_of_group[g] * H.nlist + (size_t)phase * (size_t)per_phase + (size_t)(tu + tv + ti + offset);
-    };
     // What a group sweeps of brick (tu, tv, ti): nothing (a box holds it), all of it, or -- a box cuts through it along u -- the
     // lanes on the near side of that box and / or those on the far side.  Every piece runs in the phase after the last pass it
     // depends on: 1 + the highest level among the boxes it lies behind (phase 0: behind none).
@@ -283,6 +292,106 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
         return count;
     };
     const size_t nb = (size_t)P.ntu * P.ntv * P.nti;
+    auto brick_index = [&](int tu, int tv, int ti) { return ((size_t)ti * P.ntv + tv) * P.ntu + tu; };
+
+    // ---- slots (several passes).  A piece's slot is the first launch after everything it takes rays from: the pieces of the three
+    // bricks upstream that share lanes with it, and the forests of the boxes directly upstream of it (pass k of a pipeline is
+    // issued in front of the launches of slot pass_at[k], which lies behind every piece that feeds a box of level k in that
+    // pipeline).  Level after level, because a pass's place needs the slots of its feeders and its consumers' slots need its place.
+    std::vector<std::vector<int32_t>> slot(P.groups.size());
+    H.pass_at.assign((size_t)H.nhalves, std::vector<int>((size_t)H.npass, 0));
+    int nslots = 0;
+    if (H.slots) {
+        auto box_over = [&](const std::vector<HybridBox> &BX, int tu, int tv, int ti, int lane_lo, int lane_hi) -> int {
+            for (size_t x = 0; x < BX.size(); ++x) {
+                const HybridBox &B = BX[x];
+                if (tv >= B.lo[1] && tv <= B.hi[1] && ti >= B.lo[2] && ti <= B.hi[2] && B.ulo <= 64 * tu + 1 + lane_hi && B.uhi >= 64 * tu + 1 + lane_lo) return (int)x;
+            }
+            return -1;
+        };
+        for (size_t g = 0; g < P.groups.size(); ++g) slot[g].assign(2 * nb, -1);
+        for (int k = 0; k <= H.npass; ++k) {
+            for (size_t g = 0; g < P.groups.size(); ++g) {
+                const std::vector<HybridBox> &BX = boxes[g];
+                const std::vector<int> &at = H.pass_at[(size_t)half_of_group[g]];
+                std::vector<int32_t> &S = slot[g];
+                for (int ti = 0; ti < P.nti; ++ti)
+                    for (int tv = 0; tv < P.ntv; ++tv)
+                        for (int tu = 0; tu < P.ntu; ++tu) {
+                            Piece pc[2];
+                            const int np = pieces_of(BX, tu, tv, ti, pc);
+                            for (int q = 0; q < np; ++q) {
+                                int32_t &mine = S[2 * brick_index(tu, tv, ti) + (size_t)q];
+                                if (mine >= 0) continue;
+                                int s2 = 0;
+                                bool known = true;
+                                auto after_pass = [&](int x) { if (BX[(size_t)x].level >= k) known = false; else s2 = std::max(s2, at[(size_t)BX[(size_t)x].level]); };
+                                // the brick on the near side along u, or (lanes that start inside the brick) the box there
+                                if (pc[q].lane_lo > 0) after_pass(pc[q].box);
+                                else if (tu > 0) {
+                                    Piece up[2];
+                                    const int nu2 = pieces_of(BX, tu - 1, tv, ti, up);
+                                    if (nu2 > 0 && up[nu2 - 1].lane_hi == 63) {
+                                        const int32_t v = S[2 * brick_index(tu - 1, tv, ti) + (size_t)(nu2 - 1)];
+                                        if (v < 0) known = false; else s2 = std::max(s2, v + 1);
+                                    } else { const int x = box_over(BX, tu - 1, tv, ti, 63, 63); if (x >= 0) after_pass(x); }
+                                }
+                                // the bricks below along v and the march axis: their pieces that share lanes, and the box between them
+                                for (int axis = 1; axis <= 2; ++axis) {
+                                    const int nv = axis == 1 ? tv - 1 : tv, ni = axis == 2 ? ti - 1 : ti;
+                                    if (nv < 0 || ni < 0) continue;
+                                    Piece up[2];
+                                    const int nu2 = pieces_of(BX, tu, nv, ni, up);
+                                    for (int r = 0; r < nu2; ++r)
+                                        if (up[r].lane_lo <= pc[q].lane_hi && up[r].lane_hi >= pc[q].lane_lo) {
+                                            const int32_t v = S[2 * brick_index(tu, nv, ni) + (size_t)r];
+                                            if (v < 0) known = false; else s2 = std::max(s2, v + 1);
+                                        }
+                                    const int x = box_over(BX, tu, nv, ni, pc[q].lane_lo, pc[q].lane_hi);
+                                    if (x >= 0) after_pass(x);
+                                }
+                                if (known) mine = s2;
+                            }
+                        }
+            }
+            if (k == H.npass) break;
+            // where pass k goes: behind every piece that hands rays to a box of level k
+            for (size_t g = 0; g < P.groups.size(); ++g) {
+                const std::vector<HybridBox> &BX = boxes[g];
+                int &at = H.pass_at[(size_t)half_of_group[g]][(size_t)k];
+                if (k > 0) at = std::max(at, H.pass_at[(size_t)half_of_group[g]][(size_t)k - 1]);
+                for (int ti = 0; ti < P.nti; ++ti)
+                    for (int tv = 0; tv < P.ntv; ++tv)
+                        for (int tu = 0; tu < P.ntu; ++tu) {
+                            Piece pc[2];
+                            const int np = pieces_of(BX, tu, tv, ti, pc);
+                            for (int q = 0; q < np; ++q) {
+                                bool feeds = false;
+                                if (pc[q].lane_hi < 63) feeds = BX[(size_t)pc[q].box].level == k; // lanes that end inside the brick: at a box
+                                else if (tu + 1 < P.ntu) { const int x = box_over(BX, tu + 1, tv, ti, 0, 0); feeds = x >= 0 && BX[(size_t)x].level == k; }
+                                if (!feeds && tv + 1 < P.ntv) { const int x = box_over(BX, tu, tv + 1, ti, pc[q].lane_lo, pc[q].lane_hi); feeds = x >= 0 && BX[(size_t)x].level == k; }
+                                if (!feeds && ti + 1 < P.nti) { const int x = box_over(BX, tu, tv, ti + 1, pc[q].lane_lo, pc[q].lane_hi); feeds = x >= 0 && BX[(size_t)x].level == k; }
+                                if (!feeds) continue;
+                                const int32_t v = slot[g][2 * brick_index(tu, tv, ti) + (size_t)q];
+                                if (v < 0) { free_hybrid(c); return fail(c, FTTE_ERR_STATE, "hybrid plan: a brick that feeds a box waits for a later pass"); }
+                                at = std::max(at, v + 1);
+                            }
+                        }
+            }
+        }
+        for (size_t g = 0; g < P.groups.size(); ++g)
+            for (int32_t v : slot[g]) nslots = std::max(nslots, v + 1);
+        for (auto &at : H.pass_at) for (int v : at) nslots = std::max(nslots, v);
+    }
+    // the launch lists of a pipeline: a piece's slot, or (one pass, or slots switched off) a phase per pass, in it the stages of a
+    // plain sweep: phase 0 before the first pass of the forests, phase k after pass k - 1
+    H.nlist = H.slots ? (size_t)std::max(nslots, 1) : (size_t)(H.npass + 1) * (size_t)per_phase;
+    if (!H.slots) for (auto &at : H.pass_at) for (int k = 0; k < H.npass; ++k) at[(size_t)k] = (k + 1) * per_phase;
+    const size_t nlist = (size_t)H.nhalves * H.nlist;
+    auto list_of = [&](size_t g, int phase, int tu, int tv, int ti, int offset, int q) {
+        if (H.slots) return (size_t)half_of_group[g] * H.nlist + (size_t)slot[g][2 * brick_index(tu, tv, ti) + (size_t)q];
+        return (size_t)half_of_group[g] * H.nlist + (size_t)phase * (size_t)per_phase + (size_t)(tu + tv + ti + offset);
+    };
     std::vector<std::vector<size_t>> first(3 * (size_t)kMaxAcc);
     auto brick_of = [&](const BrickPlan::Group &G, int tu, int tv, int ti) {
         const DirPlan &D0 = P.dirs[G.dirs[0]];
@@ -300,7 +409,7 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
                     Piece pc[2];
                     const int np = pieces_of(boxes[g], tu, tv, ti, pc);
                     for (int q = 0; q < np; ++q)
-                        if (pc[q].masked) cut[list_of(g, pc[q].phase, tu, tv, ti, P.groups[g].offset)] = 1;
+                        if (pc[q].masked) cut[list_of(g, pc[q].phase, tu, tv, ti, P.groups[g].offset, q)] = 1;
                 }
     H.stage_off.assign(2 * nlist + 1, 0);
     for (size_t g = 0; g < P.groups.size(); ++g) {
@@ -313,7 +422,7 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
                     Piece pc[2];
                     const int np = pieces_of(boxes[g], tu, tv, ti, pc);
                     for (int q = 0; q < np; ++q) {
-                        const size_t l = list_of(g, pc[q].phase, tu, tv, ti, G.offset);
+                        const size_t l = list_of(g, pc[q].phase, tu, tv, ti, G.offset, q);
                         ++H.stage_off[(cut[l] ? nlist : 0) + l + 1];
                         size_t &f = F[brick_of(G, tu, tv, ti)];
                         f = std::min(f, l);
@@ -333,7 +442,7 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
                     Piece pc[2];
                     const int np = pieces_of(boxes[g], tu, tv, ti, pc);
                     for (int q = 0; q < np; ++q) {
-                        const size_t l = list_of(g, pc[q].phase, tu, tv, ti, G.offset);
+                        const size_t l = list_of(g, pc[q].phase, tu, tv, ti, G.offset, q);
                         BrickTask T;
                         T.tv = (int16_t)(cut[l] ? tv | (pc[q].box << kBrickBoxShift) : tv);
                         T.group = (int16_t)(cut[l] ? (int)g | (pc[q].lane_hi << kBrickLaneHiShift) : (int)g);
@@ -659,28 +768,32 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
             FTTE_HIP(c, hipEventRecord(c->ev_fork, stream));
             for (int r = 1; r < nh; ++r) FTTE_HIP(c, hipStreamWaitEvent(qs[r], c->ev_fork, 0));
         }
-        // issued phase by phase, alternating between the streams, so that none waits for the host to finish with the others:
-        // bricks of phase 0, forests pass 0, bricks of phase 1, ..., the means into J, the bricks behind the last boxes
-        const size_t per_phase = H.phase1_stages;
-        for (int pass = 0; pass < H.npass; ++pass) {
-            for (int h = 0; h < H.nhalves; ++h)
-                if ((rc = brick_stages(h, (size_t)pass * per_phase, (size_t)(pass + 1) * per_phase, qs[nh > 1 ? h : 0]))) return rc;
-            if (H.npass == 1) break; // one pass: launch_forests below does it batch by batch
-            for (int r = 0; r < nh; ++r)
-                if ((rc = launch_forest_pass(c, qs[r], runs[(size_t)r], 0, (size_t)pass, A))) return rc;
-        }
-        for (int r = 0; r < nh; ++r) {
-            hipEvent_t before = (nh > 1 && r > 0) ? c->ev_combine[r - 1] : nullptr, after = (nh > 1 && r + 1 < nh) ? c->ev_combine[r] : nullptr;
-            if (H.npass == 1) {
-                if ((rc = launch_forests(c, qs[r], runs[(size_t)r], A, J_dev, false, false, before, after))) return rc;
-            } else { // (several passes: every direction of the run is resident, one batch)
-                if (before) FTTE_HIP(c, hipStreamWaitEvent(qs[r], before, 0));
-                if ((rc = launch_forest_combine(c, qs[r], runs[(size_t)r], 0, A, J_dev, false))) return rc;
-                if (after) FTTE_HIP(c, hipEventRecord(after, qs[r]));
+        // Issued list by list, alternating between the streams, so that none waits for the host to finish with the others.  In
+        // front of list pass_at[k] of a pipeline its forests of pass k; behind the last pass the means into J.
+        for (size_t l = 0; l <= H.nlist; ++l) {
+            for (int h = 0; h < H.nhalves; ++h) {
+                const int r = nh > 1 ? h : 0;
+                for (int pass = 0; pass < H.npass; ++pass) {
+                    if ((size_t)H.pass_at[(size_t)h][(size_t)pass] != l || (nh == 1 && h > 0)) continue;
+                    hipEvent_t before = (nh > 1 && r > 0) ? c->ev_combine[r - 1] : nullptr, after = (nh > 1 && r + 1 < nh) ? c->ev_combine[r] : nullptr;
+                    if (H.npass == 1) { // one pass: batch by batch, each with its means
+                        if ((rc = launch_forests(c, qs[r], runs[(size_t)r], A, J_dev, false, false, before, after))) return rc;
+                        continue;
+                    }
+                    // (several passes: every direction of the run is resident, one batch)
+                    if ((rc = launch_forest_pass(c, qs[r], runs[(size_t)r], 0, (size_t)pass, A))) return rc;
+                }
+                if (l < H.nlist && (rc = brick_stages(h, l, l + 1, qs[r]))) return rc;
             }
         }
-        for (int h = 0; h < H.nhalves; ++h)
-            if ((rc = brick_stages(h, (size_t)H.npass * per_phase, H.nlist, qs[nh > 1 ? h : 0]))) return rc;
+        // several passes: the means into J when everything is issued, pipeline after pipeline (a pipeline's last pass may come
+        // earlier or later than another's, and the events that order the additions must be recorded before they are waited for)
+        if (H.npass > 1)
+            for (int r = 0; r < nh; ++r) {
+                if (nh > 1 && r > 0) FTTE_HIP(c, hipStreamWaitEvent(qs[r], c->ev_combine[r - 1], 0));
+                if ((rc = launch_forest_combine(c, qs[r], runs[(size_t)r], 0, A, J_dev, false))) return rc;
+                if (nh > 1 && r + 1 < nh) FTTE_HIP(c, hipEventRecord(c->ev_combine[r], qs[r]));
+            }
         for (int r = 1; r < nh; ++r) {
             FTTE_HIP(c, hipEventRecord(c->lane_done[(size_t)r - 1], qs[r]));
             FTTE_HIP(c, hipStreamWaitEvent(stream, c->lane_done[(size_t)r - 1], 0));
