@@ -34,7 +34,7 @@ phi, theta, w = ang[:, 0].copy(), ang[:, 1].copy(), np.full(ndir, 1.0 / ndir)
 J = torch.empty((nnu, ncell), dtype=torch.float64, device="cuda:0")
 print(f"{ncell} leaves: {n}^3 base grid, {k} clusters of 4^3 refined base cells", flush=True)
 ref = None
-for hybrid in (1, 0):
+for hybrid in ((1,) if "--hybrid-only" in sys.argv else (1, 0)):
     eng = rt.DiffuseTransfer(device=0)
     eng.set_grid(n, level, 3.0e22)
     eng.set_option("hybrid", hybrid)
