@@ -297,7 +297,7 @@ int ftte_set_option(ftte_ctx *c, const char *key, int value)
         c->hybrid = value;
         c->hplan.valid = false;
     } else if (!std::strcmp(key, "hybrid_slots")) {
-        if (value != 0 && value != 1) return fail(c, FTTE_ERR_ARG, "hybrid_slots must be 0 or 1");
+        if (value < 0 || value > 2) return fail(c, FTTE_ERR_ARG, "hybrid_slots must be 0 (phases), 1 (slots where there are several passes) or 2 (slots always)");
         c->hybrid_slots = value;
     } else if (!std::strcmp(key, "graph")) {
         if (value != 0 && value != 1) return fail(c, FTTE_ERR_ARG, "graph must be 0 (every launch of the hybrid sweep issued every time) or 1 (captured once, replayed)");

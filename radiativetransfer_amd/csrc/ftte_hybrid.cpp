@@ -220,7 +220,7 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
     // Several passes: every brick gets the earliest launch its own inputs allow ("slots", below) instead of a phase per pass,
     // which needs accumulators that are not shared between groups (the proof that two groups of one accumulator never meet in a
     // launch rests on launch = stage + offset).  36 accumulators of a 128^3 base grid are 5 GB and 1 ms of merge.
-    H.slots = H.npass > 1 && c->hybrid_slots;
+    H.slots = (H.npass > 1 && c->hybrid_slots) || c->hybrid_slots == 2;
     if (H.slots) {
         int per_layout[3] = {0, 0, 0};
         for (const auto &G : P.groups) ++per_layout[G.layout];
