@@ -250,6 +250,18 @@ def test_call_order_and_refusals(engine):
         with pytest.raises(rt.FtteError) as err:
             e.set_option("rows", 5)
         assert err.value.status == "FTTE_ERR_ARG"
+        # every option refuses what it cannot mean, and unknown names
+        for key, bad in (("engine", 3), ("chunk", -1), ("group", 9), ("share", 3), ("lanes", 0), ("brick_waves", 5), ("dataflow", 3),
+                         ("team", 2), ("hybrid", 2), ("pipelines", 5), ("box_lanes", 3), ("forest_batch", -1), ("graph", 2),
+                         ("hybrid_slots", 3), ("no such option", 1)):
+            with pytest.raises(rt.FtteError) as err:
+                e.set_option(key, bad)
+            assert err.value.status == "FTTE_ERR_ARG", key
+        for key, good in (("engine", 2), ("chunk", 8), ("group", 2), ("share", 1), ("lanes", 3), ("brick_waves", 3), ("dataflow", 0),
+                          ("team", 0), ("hybrid", 1), ("pipelines", 2), ("box_lanes", 16), ("forest_batch", 7), ("graph", 0),
+                          ("hybrid_slots", 1)):
+            e.set_option(key, good)
+        assert e.counter("hybrid_boxes") == 0 and e.counter("hybrid_passes") == 0 and e.counter("no such counter") == -1
 
 
 # ---- refined cell arrays (setRaysRefined / findNeighbours / transport with the coarse-neighbour rule) -----------------
