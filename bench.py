@@ -69,6 +69,7 @@ def parse():
     ap.add_argument("--chunk", type=int, default=0, help="bricks: layers per brick; 0 = library default")
     ap.add_argument("--group", type=int, default=0, help="bricks: directions per group; 0 = library default")
     ap.add_argument("--brick-waves", type=int, default=0, help="bricks: waves per SIMD the kernel is compiled for")
+    ap.add_argument("--pair-waves", type=int, default=0, help="pair kernel (--team 2): workgroups per SIMD it is built for (2..4)")
     ap.add_argument("--team", type=int, default=-1, help="bricks: 1 one wavefront per direction (default), 0 one wavefront per group")
     ap.add_argument("--share", type=int, default=-1, help="bricks: accumulator sharing 0/1/2")
     ap.add_argument("--dataflow", type=int, default=-1, help="bricks: 1 one launch with flags (default where the grid allows), 0 a launch per stage")
@@ -264,6 +265,8 @@ def main():
         eng.set_option("brick_waves", a.brick_waves)
     if a.team >= 0:
         eng.set_option("team", a.team)
+    if a.pair_waves:
+        eng.set_option("pair_waves", a.pair_waves)
     if a.share >= 0:
         eng.set_option("share", a.share)
     if a.lanes:

@@ -319,8 +319,11 @@ int ftte_set_option(ftte_ctx *c, const char *key, int value)
         if (value < 1 || value > 16) return fail(c, FTTE_ERR_ARG, "lanes (streams the brick sweep spreads its frequency groups over) must be 1..16");
         c->lanes = value;
     } else if (!std::strcmp(key, "team")) {
-        if (value != 0 && value != 1) return fail(c, FTTE_ERR_ARG, "team must be 0 (one wavefront sweeps a group's directions in turn) or 1 (one wavefront per direction)");
+        if (value < 0 || value > 2) return fail(c, FTTE_ERR_ARG, "team must be 0 (one wavefront sweeps a group's directions in turn), 1 (one wavefront per direction) or 2 (two wavefronts per brick, four rows each)");
         c->team = value;
+    } else if (!std::strcmp(key, "pair_waves")) {
+        if (value < 2 || value > 4) return fail(c, FTTE_ERR_ARG, "pair_waves (workgroups of two wavefronts per SIMD the pair kernel is built for) must be 2..4");
+        c->pair_waves = value;
     } else if (!std::strcmp(key, "share")) {
         if (value < 0 || value > 2) return fail(c, FTTE_ERR_ARG, "share (groups sharing a J accumulator) must be 0 (none), 1 (passes of one izone) or 2 (and izone pairs)");
         c->share = value;

@@ -59,39 +59,41 @@ __device__ __forceinline__ double brick_segment(const ftte_consts &K, double &I,
     return ftte_segment_emit(&K, &I, kap * dpath, EMIT == 1 ? x : 0.0, EMIT == 2 ? x : 0.0);
 }
 
-template <int SHAPE, int EMIT>
-__device__ __forceinline__ void brick_step(const ftte_consts &K, double (&cur)[kBrickRows], const double (&kap)[kBrickRows],
-                                           const double (&xs)[EMIT ? kBrickRows : 1],
-                                           double (&Jacc)[kBrickRows], bool third_first, double d0, double d1, double d2,
+template <int SHAPE, int EMIT, int RW = kBrickRows>
+__device__ __forceinline__ void brick_step(const ftte_consts &K, double (&cur)[RW], const double (&kap)[RW],
+                                           const double (&xs)[EMIT ? RW : 1],
+                                           double (&Jacc)[RW], bool third_first, double d0, double d1, double d2,
                                            double w, double uvb, gcbyte *uin, gbyte *uout, gcbyte *vin, gbyte *vout, int lane, bool through = false,
-                                           bool same_launch = false, int take_lane = 0, int hand_lane = 63, bool active = true)
+                                           bool same_launch = false, int take_lane = 0, int hand_lane = 63, bool active = true,
+                                           const double *carry_in = nullptr, double *carry_out = nullptr)
 {
     // take_lane / hand_lane / active: a brick that sweeps only the lanes take_lane .. hand_lane (hybrid sweep of a refined cell
     // array: the others belong to the segment forest).  The rays waiting in `uin` then enter lane take_lane, lane hand_lane hands
     // its rays to `uout`, and only active lanes write to the v-face.  Defaults: the whole brick, nothing added to the code.
     constexpr bool HAS_U = SHAPE == RC_TWO_U || SHAPE == RC_THREE_U || SHAPE == RC_THREE_V;
     constexpr bool HAS_V = SHAPE == RC_TWO_V || SHAPE == RC_THREE_U || SHAPE == RC_THREE_V;
-    double ui[kBrickRows];
+    double ui[RW];
     double carry = uvb; // the ray that moves up from the row below (row 0: from the brick below)
     if (HAS_U) {
 #pragma unroll
-        for (int r = 0; r < kBrickRows; ++r) ui[r] = uvb;
+        for (int r = 0; r < RW; ++r) ui[r] = uvb;
         if (uin) { // one address for the whole wave
             if (same_launch) { // dataflow: written by a brick of this launch, so not through the scalar cache
 #pragma unroll
-                for (int r = 0; r < kBrickRows; ++r) ui[r] = *(gcdouble *)(uin + 8 * r);
+                for (int r = 0; r < RW; ++r) ui[r] = *(gcdouble *)(uin + 8 * r);
             } else { // written by an earlier launch: scalar loads, the values wait in scalar registers
                 const __attribute__((address_space(4))) double *us = (const __attribute__((address_space(4))) double *)(unsigned long)uin;
 #pragma unroll
-                for (int r = 0; r < kBrickRows; ++r) ui[r] = us[r];
+                for (int r = 0; r < RW; ++r) ui[r] = us[r];
             }
         }
     }
     if (HAS_V && vin) carry = *(gcdouble *)(vin + 8 * lane);
+    if (HAS_V && carry_in) carry = carry_in[lane]; // pair kernel: the wavefront below left it in LDS
     const bool hands_u = HAS_U && uout != nullptr && lane == hand_lane;
 
 #pragma unroll
-    for (int r = 0; r < kBrickRows; ++r) {
+    for (int r = 0; r < RW; ++r) {
         double I = cur[r];
         const double m0 = brick_segment<EMIT>(K, I, kap[r], xs[EMIT ? r : 0], d0); // xy piece, in the ray's own cell
         double acc = m0;
@@ -140,6 +142,7 @@ __device__ __forceinline__ void brick_step(const ftte_consts &K, double (&cur)[k
         asm volatile("" : "+v"(Jacc[r]));
         __builtin_amdgcn_sched_barrier(0); // rows in program order: interleaved they multiply the live registers
     }
+    if (HAS_V && carry_out) carry_out[lane] = carry; // pair kernel: for the wavefront above
     if (HAS_V && vout && active) { // the top row's ray goes on in the brick above
         if (through) __hip_atomic_store((double *)(vout + 8 * lane), carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else *(gdouble *)(vout + 8 * lane) = carry;
@@ -372,6 +375,167 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
     }
 }
 
+// The same brick swept by a PAIR of wavefronts: wave 0 the brick's lower four rows, wave 1 the upper four, one (layer,
+// layer apart.  A ray that moves up out of row 3 waits in LDS for the wave above, which takes it one layer later: one
+// barrier per layer couples the two, and each wave holds half the rays, opacities and sums (so more of them fit a SIMD).
+// The arithmetic and the order of every cell's sum are those of brick_kernel.
+// grid: ntasks * nnu workgroups of 128 threads; dynamic LDS: 2 x (max_dirs - 1) x 2 KB of parked rays + 2 x max_dirs x 512 B of hand-over
+template <int WAVES>
+__global__ void __launch_bounds__(128, WAVES) brick_pair_kernel(const BrickLaunch L, int max_dirs)
+{
+    extern __shared__ double pair_lds[];
+    constexpr int R = kBrickRows, H = kBrickRows / 2;
+    using cgroup = const __attribute__((address_space(4))) BrickGroup;
+    using clayer = const __attribute__((address_space(4))) LayerRec;
+    const int lane = threadIdx.x & 63;
+    const int wv = uniform((int)(threadIdx.x >> 6));
+    double *state = pair_lds + (size_t)wv * (max_dirs - 1) * H * 64; // this wave's parked rays
+    double *handover = pair_lds + (size_t)2 * (max_dirs - 1) * H * 64; // [step parity][lane]
+    const int nnu = L.nnu;
+    const int nu = L.nu0 + blockIdx.x % nnu;
+    const BrickTask T = L.tasks[blockIdx.x / nnu];
+    const int tu = uniform((int)T.tu), tv = uniform((int)T.tv), ti = uniform((int)T.ti) & (kBrickAccumulate - 1);
+    const bool accumulate = (uniform((int)T.ti) & kBrickAccumulate) != 0;
+    cgroup *G = (cgroup *)(L.groups + uniform((int)T.group));
+    const int n = L.n, chunk = L.chunk, up = L.up, vp = L.vp;
+    const int ndir = G->ndir;
+    const double uvb = L.uvb[nu];
+
+    const int sv = G->sv, si = G->si;
+    const bool mirror_u = G->su < 0;
+    const long org = G->org;
+    gcbyte *kbase = (gcbyte *)(G->kappa + (long)nu * L.group_stride + org);
+    gbyte *jbase = (gbyte *)(G->J + (long)nu * L.group_stride + org);
+
+    const int cu = 64 * tu + lane + 1;
+    const int cv0 = R * tv + H * wv + 1; // this wave's first row
+    const int cuc = cu < n ? cu : n;
+    const unsigned off0 = 8u * (unsigned)(mirror_u ? n + 1 - cuc : cuc);
+    const bool own_lane = cu <= n;
+    const long row_bytes = 8l * sv;
+    const int i0 = ti * chunk + 1;
+    const int i1 = (i0 + chunk - 1 < n) ? i0 + chunk - 1 : n;
+
+    const bool has_u_in = tu > 0, has_u_out = 64 * (tu + 1) < n;
+    const bool has_v_in = tv > 0 && wv == 0, has_v_out = R * (tv + 1) < n && wv == 1;
+    const bool has_i_in = ti > 0, has_i_out = i1 < n;
+    const long fnu = (long)nu * L.face_stride;
+    const int uw = L.uw, ut = L.ut;
+    const int ns = L.nslot, sl = ti % ns;
+    const long u_out = ((long)(tu * ns + sl) * chunk) * uw + ut * tv + H * wv;
+    const long u_in = ((long)((tu - 1) * ns + sl) * chunk) * uw + ut * tv + H * wv;
+    const long v_out = L.vface_off + ((long)(tv * ns + sl) * chunk) * up + 64 * tu;
+    const long v_in = L.vface_off + ((long)((tv - 1) * ns + sl) * chunk) * up + 64 * tu;
+    const long i_in = L.iface_off + ((long)sl * vp + R * tv + H * wv) * up + 64 * tu + lane;
+    const long i_out = L.iface_off + ((long)((ti + 1) % ns) * vp + R * tv + H * wv) * up + 64 * tu + lane;
+
+    int p0 = (ndir - (i0 - 1) % ndir) % ndir;
+    double cur[H];
+    {
+        gcdouble *f = (gcdouble *)(G->dir[p0].faces + fnu);
+#pragma unroll
+        for (int r = 0; r < H; ++r) cur[r] = has_i_in ? f[i_in + (long)r * up] : uvb;
+    }
+    for (int k = 0; k + 1 < ndir; ++k) {
+        int d = p0 + 1 + k;
+        d = d >= ndir ? d - ndir : d;
+        gcdouble *f = (gcdouble *)(G->dir[d].faces + fnu);
+#pragma unroll
+        for (int r = 0; r < H; ++r) state[(k * H + r) * 64 + lane] = has_i_in ? f[i_in + (long)r * up] : uvb;
+    }
+
+    double kap_next[H], kap[H], Jacc[H];
+    const double xs[1] = {0.0};
+    {
+        gcbyte *kplane = kbase + 8l * i0 * si;
+#pragma unroll
+        for (int r = 0; r < H; ++r) {
+            const int row = (cv0 + r < n) ? cv0 + r : n;
+            kap_next[r] = *(gcdouble *)(kplane + row * row_bytes + off0);
+            kap[r] = 0.0;
+            Jacc[r] = 0.0;
+        }
+    }
+    // wave 0 crosses layer i0 + it, wave 1 the layer before: what moves up out of row 3 waits a layer in LDS
+    const int nlayers = i1 - i0 + 1;
+    for (int it = 0; it <= nlayers; ++it) {
+        const int il = it - wv;
+        if (il >= 0 && il < nlayers) {
+            const int i = i0 + il;
+            gbyte *jplane = jbase + 8l * i * si;
+#pragma unroll
+            for (int r = 0; r < H; ++r) { kap[r] = kap_next[r]; Jacc[r] = 0.0; }
+            if (accumulate && own_lane) {
+#pragma unroll
+                for (int r = 0; r < H; ++r)
+                    if (cv0 + r <= n) Jacc[r] = __builtin_nontemporal_load((gcdouble *)(jplane + (cv0 + r) * row_bytes + off0));
+            }
+            if (i < i1) {
+                gcbyte *kplane = kbase + 8l * (i + 1) * si;
+#pragma unroll
+                for (int r = 0; r < H; ++r) {
+                    const int row = (cv0 + r < n) ? cv0 + r : n;
+                    kap_next[r] = *(gcdouble *)(kplane + row * row_bytes + off0);
+                }
+            }
+            double *hand = handover + (size_t)(il & 1) * max_dirs * 64;
+            for (int j = 0; j < ndir; ++j) {
+                int d = p0 + j;
+                d = d >= ndir ? d - ndir : d;
+                if (j) {
+#pragma unroll
+                    for (int r = 0; r < H; ++r) {
+                        const double parked = state[((j - 1) * H + r) * 64 + lane];
+                        state[((j - 1) * H + r) * 64 + lane] = cur[r];
+                        cur[r] = parked;
+                    }
+                }
+                clayer *rp = (clayer *)(G->dir[d].layers) + (i - 1);
+                const double d0 = rp->dpath[0], d1 = rp->dpath[1], d2 = rp->dpath[2];
+                const int rc = rp->info & 7;
+                const double w = G->dir[d].w;
+                gbyte *f = (gbyte *)(G->dir[d].faces + fnu);
+                gcbyte *uin = has_u_in ? (gcbyte *)f + 8 * (u_in + (long)il * uw) : nullptr;
+                gbyte *uout = has_u_out ? f + 8 * (u_out + (long)il * uw) : nullptr;
+                gcbyte *vin = has_v_in ? (gcbyte *)f + 8 * (v_in + (long)il * up) : nullptr;
+                gbyte *vout = has_v_out ? f + 8 * (v_out + (long)il * up) : nullptr;
+                const double *cin = wv ? hand + j * 64 : nullptr;
+                double *cout = wv ? nullptr : hand + j * 64;
+                const bool third_first = rc == RC_THREE_U_SWAP || rc == RC_THREE_V_SWAP;
+                switch (rc) {
+                case RC_ONE: brick_step<RC_ONE, 0, H>(L.math, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, false, false, 0, 63, true, cin, cout); break;
+                case RC_TWO_U: brick_step<RC_TWO_U, 0, H>(L.math, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, false, false, 0, 63, true, cin, cout); break;
+                case RC_TWO_V: brick_step<RC_TWO_V, 0, H>(L.math, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, false, false, 0, 63, true, cin, cout); break;
+                case RC_THREE_U:
+                case RC_THREE_U_SWAP:
+                    brick_step<RC_THREE_U, 0, H>(L.math, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, false, false, 0, 63, true, cin, cout);
+                    break;
+                default:
+                    brick_step<RC_THREE_V, 0, H>(L.math, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, false, false, 0, 63, true, cin, cout);
+                    break;
+                }
+            }
+            p0 = p0 ? p0 - 1 : ndir - 1;
+            if (own_lane) {
+#pragma unroll
+                for (int r = 0; r < H; ++r)
+                    if (cv0 + r <= n) __builtin_nontemporal_store(Jacc[r], (gdouble *)(jplane + (cv0 + r) * row_bytes + off0));
+            }
+        }
+        __syncthreads(); // the layer's hand-overs are in LDS before the wave above starts that layer
+    }
+
+    if (has_i_out) { // p0 is in registers, p0 + 1 + k in slot k
+        for (int q = 0; q < ndir; ++q) {
+            int d = p0 + q;
+            d = d >= ndir ? d - ndir : d;
+            gdouble *f = (gdouble *)(G->dir[d].faces + fnu);
+#pragma unroll
+            for (int r = 0; r < H; ++r) f[i_out + (long)r * up] = q ? state[((q - 1) * H + r) * 64 + lane] : cur[r];
+        }
+    }
+}
+
 // The same brick swept by a TEAM: one wavefront per direction of the group, all in one workgroup.  Each wave keeps its
 // direction's rays in registers for the whole chunk (no state in LDS, one code path), crosses the layer with brick_step,
 // and leaves its cells' contributions in LDS; after one barrier per layer the waves add the contributions up in direction
@@ -525,6 +689,21 @@ int launch_brick_team(const BrickLaunch &L, int max_dirs, int waves, hipStream_t
     case 2: hipLaunchKernelGGL((brick_team_kernel<2>), grid, block, lds, stream, L); break;
     case 3: hipLaunchKernelGGL((brick_team_kernel<3>), grid, block, lds, stream, L); break;
     case 4: hipLaunchKernelGGL((brick_team_kernel<4>), grid, block, lds, stream, L); break;
+    default: return -1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_brick_pair(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stream)
+{
+    if (L.ntasks <= 0) return 0;
+    if (max_dirs < 1 || max_dirs > kBrickMaxDirs || L.emit || L.ticket != nullptr) return -1;
+    const dim3 grid((unsigned)L.ntasks * (unsigned)L.nnu);
+    const size_t lds = ((size_t)(max_dirs - 1) * kBrickRows * 64 + 2 * max_dirs * 64) * sizeof(double) + (size_t)lds_pad();
+    switch (waves) {
+    case 2: hipLaunchKernelGGL((brick_pair_kernel<2>), grid, dim3(128), lds, stream, L, max_dirs); break;
+    case 3: hipLaunchKernelGGL((brick_pair_kernel<3>), grid, dim3(128), lds, stream, L, max_dirs); break;
+    case 4: hipLaunchKernelGGL((brick_pair_kernel<4>), grid, dim3(128), lds, stream, L, max_dirs); break;
     default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;

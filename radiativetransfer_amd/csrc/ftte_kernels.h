@@ -15,6 +15,7 @@ int launch_sweep(const LaunchRec &L, int rows, int waves, int stack, int nnu, hi
 int launch_brick(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stream, bool masked = false);
 // the same stage by teams: one wavefront per direction of a group in one workgroup
 int launch_brick_team(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stream);
+int launch_brick_pair(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stream); // two wavefronts per brick, four rows each
 // cell-array order -> layout 1 ([jc][ic][kc]) or 2 ([kc][ic][jc]); nnu groups, group_stride apart
 int launch_to_layout(int layout, const double *src, double *dst, int n, int nnu, long group_stride, hipStream_t stream);
 // J (cell-array order) = acc[0] + acc[1] + ... in list order; layout[a] in {0,1,2}

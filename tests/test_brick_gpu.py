@@ -17,12 +17,12 @@ EPS = np.finfo(np.float64).eps
 SUM_RTOL = 64 * EPS
 
 
-@pytest.fixture(params=["team", "solo"])
+@pytest.fixture(params=["team", "solo", "pair"])
 def bricks(engine, request):
     """Both forms of the brick kernel: a team of wavefronts, one per direction of a group (the default), and one wavefront
     that takes the group's directions in turn."""
     engine.set_option("engine", 2)
-    engine.set_option("team", 1 if request.param == "team" else 0)
+    engine.set_option("team", {"team": 1, "solo": 0, "pair": 2}[request.param])
     yield engine
     for key, value in (("engine", 0), ("team", 0), ("chunk", 0), ("group", 0), ("share", 2), ("lanes", 2)):
         engine.set_option(key, value)
