@@ -53,14 +53,14 @@ __device__ __forceinline__ double shift_up_inject(double x, double in0)
 // (nullptr: the domain boundary, the inflow enters there); uout/vout: where this brick's leaving rays go (nullptr: they
 // leave the domain or nobody is there).
 template <int EMIT>
-__device__ __forceinline__ double brick_segment(const ftte_consts &K, double &I, double kap, double x, double dpath)
+__device__ __forceinline__ double brick_segment(const ftte_consts &K, double lead, double &I, double kap, double x, double dpath)
 {
-    if (EMIT == 0) return ftte_segment(&K, &I, kap * dpath);
+    if (EMIT == 0) return ftte_segment_lead(&K, lead, &I, kap * dpath);
     return ftte_segment_emit(&K, &I, kap * dpath, EMIT == 1 ? x : 0.0, EMIT == 2 ? x : 0.0);
 }
 
 template <int SHAPE, int EMIT, int RW = kBrickRows>
-__device__ __forceinline__ void brick_step(const ftte_consts &K, double (&cur)[RW], const double (&kap)[RW],
+__device__ __forceinline__ void brick_step(const ftte_consts &K, double lead, double (&cur)[RW], const double (&kap)[RW],
                                            const double (&xs)[EMIT ? RW : 1],
                                            double (&Jacc)[RW], bool third_first, double d0, double d1, double d2,
                                            double w, double uvb, gcbyte *uin, gbyte *uout, gcbyte *vin, gbyte *vout, int lane, bool through = false,
@@ -95,7 +95,7 @@ __device__ __forceinline__ void brick_step(const ftte_consts &K, double (&cur)[R
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
         double I = cur[r];
-        const double m0 = brick_segment<EMIT>(K, I, kap[r], xs[EMIT ? r : 0], d0); // xy piece, in the ray's own cell
+        const double m0 = brick_segment<EMIT>(K, lead, I, kap[r], xs[EMIT ? r : 0], d0); // xy piece, in the ray's own cell
         double acc = m0;
         if (SHAPE == RC_ONE) {
             cur[r] = I;
@@ -104,38 +104,50 @@ __device__ __forceinline__ void brick_step(const ftte_consts &K, double (&cur)[R
             if (hands_u) { if (through) __hip_atomic_store((double *)(uout + 8 * r), I, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *(gdouble *)(uout + 8 * r) = I; }
             I = shift_up_inject(I, ui[r]);
             if (take_lane) I = lane == take_lane ? ui[r] : I;
-            acc += brick_segment<EMIT>(K, I, kap[r], xs[EMIT ? r : 0], d1);
+            acc += brick_segment<EMIT>(K, lead, I, kap[r], xs[EMIT ? r : 0], d1);
             cur[r] = I;
             Jacc[r] += ftte_cell_mean(acc, 2, w);
         } else if (SHAPE == RC_TWO_V) {
             double b = carry;
             carry = I;
-            acc += brick_segment<EMIT>(K, b, kap[r], xs[EMIT ? r : 0], d1);
+            acc += brick_segment<EMIT>(K, lead, b, kap[r], xs[EMIT ? r : 0], d1);
             cur[r] = b;
             Jacc[r] += ftte_cell_mean(acc, 2, w);
         } else if (SHAPE == RC_THREE_U) { // 2nd piece one column on, 3rd one row on
             if (hands_u) { if (through) __hip_atomic_store((double *)(uout + 8 * r), I, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *(gdouble *)(uout + 8 * r) = I; }
             I = shift_up_inject(I, ui[r]);
             if (take_lane) I = lane == take_lane ? ui[r] : I;
-            const double m1 = brick_segment<EMIT>(K, I, kap[r], xs[EMIT ? r : 0], d1);
+            const double m1 = brick_segment<EMIT>(K, lead, I, kap[r], xs[EMIT ? r : 0], d1);
             double c = carry;
             carry = I;
-            const double m2 = brick_segment<EMIT>(K, c, kap[r], xs[EMIT ? r : 0], d2);
+            const double m2 = brick_segment<EMIT>(K, lead, c, kap[r], xs[EMIT ? r : 0], d2);
             // reference order: xy + xz + yz, whatever the chain order (transportRoutinesModule.f90:695-941)
-            acc += third_first ? m2 : m1;
-            acc += third_first ? m1 : m2;
+            if (third_first) { // one layer record for the wavefront: a scalar branch instead of four selects
+                acc += m2;
+                acc += m1;
+                asm volatile("" : "+v"(acc));
+            } else {
+                acc += m1;
+                acc += m2;
+            }
             cur[r] = c;
             Jacc[r] += ftte_cell_mean(acc, 3, w);
         } else { // RC_THREE_V: 2nd piece one row on, 3rd one column on
             double b = carry;
             carry = I;
-            const double m1 = brick_segment<EMIT>(K, b, kap[r], xs[EMIT ? r : 0], d1);
+            const double m1 = brick_segment<EMIT>(K, lead, b, kap[r], xs[EMIT ? r : 0], d1);
             if (hands_u) { if (through) __hip_atomic_store((double *)(uout + 8 * r), b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *(gdouble *)(uout + 8 * r) = b; }
             b = shift_up_inject(b, ui[r]);
             if (take_lane) b = lane == take_lane ? ui[r] : b;
-            const double m2 = brick_segment<EMIT>(K, b, kap[r], xs[EMIT ? r : 0], d2);
-            acc += third_first ? m2 : m1;
-            acc += third_first ? m1 : m2;
+            const double m2 = brick_segment<EMIT>(K, lead, b, kap[r], xs[EMIT ? r : 0], d2);
+            if (third_first) { // one layer record for the wavefront: a scalar branch instead of four selects
+                acc += m2;
+                acc += m1;
+                asm volatile("" : "+v"(acc));
+            } else {
+                acc += m1;
+                acc += m2;
+            }
             cur[r] = b;
             Jacc[r] += ftte_cell_mean(acc, 3, w);
         }
@@ -187,6 +199,8 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
     const int n = L.n, chunk = L.chunk, up = L.up, vp = L.vp;
     const int ndir = G->ndir;
     const double uvb = L.uvb[nu];
+    double lead = L.math.c[9]; // the exponential's leading coefficient, in a vector register for the whole run (ftte_math.h)
+    asm volatile("" : "+v"(lead));
 
     const int sv = G->sv, si = G->si;
     const bool mirror_u = G->su < 0;
@@ -325,15 +339,15 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
             gbyte *vout = has_v_out ? f + 8 * (v_out + (long)il * up) : nullptr;
             const bool third_first = rc == RC_THREE_U_SWAP || rc == RC_THREE_V_SWAP;
             switch (rc) {
-            case RC_ONE: brick_step<RC_ONE, EMIT>(L.math, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW, lane_lo, lane_hi, !MASKED || own_lane); break;
-            case RC_TWO_U: brick_step<RC_TWO_U, EMIT>(L.math, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW, lane_lo, lane_hi, !MASKED || own_lane); break;
-            case RC_TWO_V: brick_step<RC_TWO_V, EMIT>(L.math, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW, lane_lo, lane_hi, !MASKED || own_lane); break;
+            case RC_ONE: brick_step<RC_ONE, EMIT>(L.math, lead, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW, lane_lo, lane_hi, !MASKED || own_lane); break;
+            case RC_TWO_U: brick_step<RC_TWO_U, EMIT>(L.math, lead, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW, lane_lo, lane_hi, !MASKED || own_lane); break;
+            case RC_TWO_V: brick_step<RC_TWO_V, EMIT>(L.math, lead, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW, lane_lo, lane_hi, !MASKED || own_lane); break;
             case RC_THREE_U:
             case RC_THREE_U_SWAP:
-                brick_step<RC_THREE_U, EMIT>(L.math, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW, lane_lo, lane_hi, !MASKED || own_lane);
+                brick_step<RC_THREE_U, EMIT>(L.math, lead, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW, lane_lo, lane_hi, !MASKED || own_lane);
                 break;
             default:
-                brick_step<RC_THREE_V, EMIT>(L.math, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW, lane_lo, lane_hi, !MASKED || own_lane);
+                brick_step<RC_THREE_V, EMIT>(L.math, lead, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW, lane_lo, lane_hi, !MASKED || own_lane);
                 break;
             }
         }
@@ -400,6 +414,8 @@ __global__ void __launch_bounds__(128, WAVES) brick_pair_kernel(const BrickLaunc
     const int n = L.n, chunk = L.chunk, up = L.up, vp = L.vp;
     const int ndir = G->ndir;
     const double uvb = L.uvb[nu];
+    double lead = L.math.c[9]; // the exponential's leading coefficient, in a vector register for the whole run (ftte_math.h)
+    asm volatile("" : "+v"(lead));
 
     const int sv = G->sv, si = G->si;
     const bool mirror_u = G->su < 0;
@@ -503,15 +519,15 @@ __global__ void __launch_bounds__(128, WAVES) brick_pair_kernel(const BrickLaunc
                 double *cout = wv ? nullptr : hand + j * 64;
                 const bool third_first = rc == RC_THREE_U_SWAP || rc == RC_THREE_V_SWAP;
                 switch (rc) {
-                case RC_ONE: brick_step<RC_ONE, 0, H>(L.math, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, false, false, 0, 63, true, cin, cout); break;
-                case RC_TWO_U: brick_step<RC_TWO_U, 0, H>(L.math, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, false, false, 0, 63, true, cin, cout); break;
-                case RC_TWO_V: brick_step<RC_TWO_V, 0, H>(L.math, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, false, false, 0, 63, true, cin, cout); break;
+                case RC_ONE: brick_step<RC_ONE, 0, H>(L.math, lead, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, false, false, 0, 63, true, cin, cout); break;
+                case RC_TWO_U: brick_step<RC_TWO_U, 0, H>(L.math, lead, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, false, false, 0, 63, true, cin, cout); break;
+                case RC_TWO_V: brick_step<RC_TWO_V, 0, H>(L.math, lead, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, false, false, 0, 63, true, cin, cout); break;
                 case RC_THREE_U:
                 case RC_THREE_U_SWAP:
-                    brick_step<RC_THREE_U, 0, H>(L.math, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, false, false, 0, 63, true, cin, cout);
+                    brick_step<RC_THREE_U, 0, H>(L.math, lead, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, false, false, 0, 63, true, cin, cout);
                     break;
                 default:
-                    brick_step<RC_THREE_V, 0, H>(L.math, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, false, false, 0, 63, true, cin, cout);
+                    brick_step<RC_THREE_V, 0, H>(L.math, lead, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, false, false, 0, 63, true, cin, cout);
                     break;
                 }
             }
@@ -561,6 +577,8 @@ __global__ void __launch_bounds__(64 * kBrickMaxDirs, WAVES) brick_team_kernel(c
     if (d >= ndir) return; // a smaller group in a launch sized for the largest: the barrier counts live waves only
     const int n = L.n, chunk = L.chunk, up = L.up, vp = L.vp;
     const double uvb = L.uvb[nu];
+    double lead = L.math.c[9]; // the exponential's leading coefficient, in a vector register for the whole run (ftte_math.h)
+    asm volatile("" : "+v"(lead));
 
     const int sv = G->sv, si = G->si;
     const bool mirror_u = G->su < 0;
@@ -637,15 +655,15 @@ __global__ void __launch_bounds__(64 * kBrickMaxDirs, WAVES) brick_team_kernel(c
         const bool third_first = rc == RC_THREE_U_SWAP || rc == RC_THREE_V_SWAP;
         const double no_xs[1] = {0.0};
         switch (rc) {
-        case RC_ONE: brick_step<RC_ONE, 0>(L.math, cur, kap, no_xs, Jc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane); break;
-        case RC_TWO_U: brick_step<RC_TWO_U, 0>(L.math, cur, kap, no_xs, Jc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane); break;
-        case RC_TWO_V: brick_step<RC_TWO_V, 0>(L.math, cur, kap, no_xs, Jc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane); break;
+        case RC_ONE: brick_step<RC_ONE, 0>(L.math, lead, cur, kap, no_xs, Jc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane); break;
+        case RC_TWO_U: brick_step<RC_TWO_U, 0>(L.math, lead, cur, kap, no_xs, Jc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane); break;
+        case RC_TWO_V: brick_step<RC_TWO_V, 0>(L.math, lead, cur, kap, no_xs, Jc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane); break;
         case RC_THREE_U:
         case RC_THREE_U_SWAP:
-            brick_step<RC_THREE_U, 0>(L.math, cur, kap, no_xs, Jc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane);
+            brick_step<RC_THREE_U, 0>(L.math, lead, cur, kap, no_xs, Jc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane);
             break;
         default:
-            brick_step<RC_THREE_V, 0>(L.math, cur, kap, no_xs, Jc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane);
+            brick_step<RC_THREE_V, 0>(L.math, lead, cur, kap, no_xs, Jc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane);
             break;
         }
         if (ndir == 1) { // nobody to add up with

@@ -109,14 +109,23 @@ typedef struct {
 
 /* e = exp(-tau), g = (1-exp(-tau))/tau  (g(0) = 1).  tau >= 0 expected; a
  * negative tau (unphysical opacity) still evaluates, up to overflow. */
+FTTE_HD void ftte_attenuation_lead(const ftte_consts *K, double lead, double tau, double *e_out, double *g_out);
 FTTE_HD void ftte_attenuation(const ftte_consts *K, double tau, double *e_out, double *g_out)
+{
+    ftte_attenuation_lead(K, K->c[9], tau, e_out, g_out);
+}
+
+/* `lead`: the polynomial's leading coefficient, K->c[9], handed in by the caller.  A device kernel that keeps it in a vector
+ * register for its whole run saves the move every first Horner step otherwise starts with (an instruction reads one scalar
+ * operand: c9 * r + c8 with both coefficients in scalar registers needs one of them copied first). */
+FTTE_HD void ftte_attenuation_lead(const ftte_consts *K, double lead, double tau, double *e_out, double *g_out)
 {
     const double x = FTTE_FMAX(-tau, K->x_floor);
     const double nf = FTTE_RINT(x * K->log2e);
     double r = FTTE_FMA(nf, -K->ln2_hi, x);
     r = FTTE_FMA(nf, -K->ln2_lo, r);
 
-    double q = K->c[9];
+    double q = lead;
     q = FTTE_FMA(q, r, K->c[8]);
     q = FTTE_FMA(q, r, K->c[7]);
     q = FTTE_FMA(q, r, K->c[6]);
@@ -143,16 +152,24 @@ FTTE_HD void ftte_attenuation(const ftte_consts *K, double tau, double *e_out, d
 /* One segment: advances the ray intensity and returns the path-mean intensity
  * the cell receives from it.  Iout == 0 (underflow) yields a zero mean, as the
  * reference's (Iin-0)/log(Iin/0) does. */
-FTTE_HD double ftte_segment(const ftte_consts *K, double *I, double tau)
+FTTE_HD double ftte_segment_lead(const ftte_consts *K, double lead, double *I, double tau)
 {
     double e, g;
-    ftte_attenuation(K, tau, &e, &g);
+    ftte_attenuation_lead(K, lead, tau, &e, &g);
     const double Iin = *I;
     const double Iout = Iin * e;
     *I = Iout;
     double mean = Iin * g;
-    if (FTTE_ANY(Iout == 0.0)) mean = (Iout == 0.0) ? 0.0 : mean; /* underflow: rare enough to branch on per wave */
+    if (FTTE_ANY(Iout == 0.0)) { /* underflow: rare enough to branch on per wave */
+        mean = (Iout == 0.0) ? 0.0 : mean;
+        FTTE_KEEP(mean); /* a branch, not a pair of selects every lane pays for */
+    }
     return mean;
+}
+
+FTTE_HD double ftte_segment(const ftte_consts *K, double *I, double tau)
+{
+    return ftte_segment_lead(K, K->c[9], I, tau);
 }
 
 /* log(1 + t) for t >= 0, accurate also for tiny t (where forming 1 + t first would lose t's low bits):
