@@ -70,7 +70,7 @@ def parse():
     ap.add_argument("--group", type=int, default=0, help="bricks: directions per group; 0 = library default")
     ap.add_argument("--brick-waves", type=int, default=0, help="bricks: waves per SIMD the kernel is compiled for")
     ap.add_argument("--pair-waves", type=int, default=0, help="pair kernel (--team 2): workgroups per SIMD it is built for (2..4)")
-    ap.add_argument("--team", type=int, default=-1, help="bricks: 1 one wavefront per direction (default), 0 one wavefront per group")
+    ap.add_argument("--team", type=int, default=-1, help="bricks: 0 one wavefront per group (default), 1 one wavefront per direction, 2 two wavefronts per brick")
     ap.add_argument("--share", type=int, default=-1, help="bricks: accumulator sharing 0/1/2")
     ap.add_argument("--dataflow", type=int, default=-1, help="bricks: 1 one launch with flags (default where the grid allows), 0 a launch per stage")
     ap.add_argument("--lanes", type=int, default=0, help="bricks: streams the frequency groups are spread over")

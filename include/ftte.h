@@ -315,8 +315,9 @@ long long ftte_counter(const ftte_ctx *ctx, const char *name);
  *     "brick_waves" bricks: waves per SIMD the kernel is compiled for, 2..4
  *     "dataflow"    bricks: 0 a launch per stage (default), 1 one launch whose bricks wait for each other, 2 the same with
  *                   write-through stores
- *     "team"        bricks: 1 = one wavefront per direction of a group instead of one per group; 2 = two wavefronts per brick,
- *                   four rows each ("pair_waves": workgroups per SIMD that form is compiled for, 2..4)
+ *     "team"        bricks: 0 = one wavefront per brick, 1 = one wavefront per direction of a group, 2 = two wavefronts per
+ *                   brick, four rows each ("pair_waves": workgroups per SIMD that form is compiled for, 2..4); -1 (default):
+ *                   2 with up to four frequency groups on this GPU, else 0
  *     "rows", "stack", "slots", "waves"  tiles: rays per lane (4, 8, 16), wavefronts per workgroup (1, 2, 4, 8), directions in flight
  *                   per launch (1..16), waves per SIMD (2..6); built variants rows x stack = 4x{1,4,8}, 8x{1,2,4}, 16x1
  *   refined cell arrays

@@ -319,7 +319,7 @@ int ftte_set_option(ftte_ctx *c, const char *key, int value)
         if (value < 1 || value > 16) return fail(c, FTTE_ERR_ARG, "lanes (streams the brick sweep spreads its frequency groups over) must be 1..16");
         c->lanes = value;
     } else if (!std::strcmp(key, "team")) {
-        if (value < 0 || value > 2) return fail(c, FTTE_ERR_ARG, "team must be 0 (one wavefront sweeps a group's directions in turn), 1 (one wavefront per direction) or 2 (two wavefronts per brick, four rows each)");
+        if (value < -1 || value > 2) return fail(c, FTTE_ERR_ARG, "team must be -1 (by the number of frequency groups: 2 up to four, else 0), 0 (one wavefront sweeps a group's directions in turn), 1 (one wavefront per direction) or 2 (two wavefronts per brick, four rows each)");
         c->team = value;
     } else if (!std::strcmp(key, "pair_waves")) {
         if (value < 2 || value > 4) return fail(c, FTTE_ERR_ARG, "pair_waves (workgroups of two wavefronts per SIMD the pair kernel is built for) must be 2..4");
@@ -385,7 +385,7 @@ int ftte_diffuse_iteration(ftte_ctx *c, int nnu, const double *kappa, int ndir, 
     if (rc) return rc;
     if (nnu < 1 || !kappa || !J || ndir < 0 || (ndir > 0 && (!phi || !theta || !w)) || !uvb)
         return fail(c, FTTE_ERR_ARG, "ftte_diffuse_iteration: bad argument");
-    const bool lanes_apply = !c->use_forest && c->engine != 1 && !c->emit_mode && !c->team && !c->dataflow && ndir > 0 && c->lanes >= 2 &&
+    const bool lanes_apply = !c->use_forest && c->engine != 1 && !c->emit_mode && brick_form(c, nnu) != 1 && !c->dataflow && ndir > 0 && c->lanes >= 2 &&
                              nnu >= c->lanes;
     if (!lanes_apply) {
         if ((rc = ftte_set_opacity(c, nnu, kappa))) return rc;

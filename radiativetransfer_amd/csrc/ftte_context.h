@@ -135,7 +135,7 @@ struct ftte_ctx {
 
     // which organisation sweeps a uniform grid: 0 = the default = 2 = cell-fixed bricks (brick_kernel), 1 = ray-following tiles
     // (sweep_kernel)
-    int engine = 0, chunk = 0, group = 0, brick_waves = 4, pair_waves = 4, share = 2, team = 0, lanes = 2; // chunk, group: 0 = by the parallelism (build_brick_plan)
+    int engine = 0, chunk = 0, group = 0, brick_waves = 4, pair_waves = 4, share = 2, team = -1, lanes = 2; // chunk, group: 0 = by the parallelism (build_brick_plan)
     std::vector<hipStream_t> lane_stream;   // extra streams of the brick sweep (frequency groups are independent)
     std::vector<hipEvent_t> pipe_up;        // ftte_diffuse_iteration: lane k's opacities have arrived
     bool stage_used[2] = {false, false};    // the pinned staging block has a transfer recorded on stage_ev
@@ -267,6 +267,17 @@ struct ftte_ctx {
         chem_temperature_set = false;
     }
 };
+
+// Which form of the brick kernel sweeps: 0 one wavefront per brick, 1 a wavefront per direction, 2 a pair of wavefronts per brick.
+// Option "team" = -1 (the default) leaves it to the parallelism: with four frequency groups or fewer on this GPU (a rank of a
+// frequency-sharded run) the stages are narrow, and the pair form's twice as many wavefronts fill them better (2.6 / 3.8 / 5.8 %
+// at 4 / 2 / 1 groups); at eight the single wavefront is 2 % ahead.  Emission and the dataflow launch are built for form 0 only.
+inline int brick_form(const ftte_ctx *c, int nnu)
+{
+    if (c->emit_mode) return 0;
+    if (c->team >= 0) return c->team;
+    return (nnu <= 4 && !c->dataflow) ? 2 : 0;
+}
 
 
 namespace ftte {

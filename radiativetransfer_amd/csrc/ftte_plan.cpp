@@ -311,8 +311,9 @@ int build_brick_plan(ftte_ctx *c, int ndir, const double *phi, const double *the
     // tasks, and with few frequency groups on this GPU (a rank of a frequency-sharded run) shorter bricks and smaller
     // groups keep the stages wide enough; the groups are then dealt to the streams instead of the frequency groups.
     const int chunk = std::min(c->chunk > 0 ? c->chunk : (nnu >= 4 ? 16 : nnu >= 2 ? 8 : 4), n);
-    const int gmax = c->group > 0 ? c->group : (nnu >= 2 ? 3 : 2);
-    const int want_dataflow = (c->dataflow && n % 64 == 0 && n % kBrickRows == 0 && n % chunk == 0 && !c->team && !c->emit_mode) ? 1 : 0;
+    const int form = brick_form(c, nnu);
+    const int gmax = c->group > 0 ? c->group : (nnu >= 2 || form == 2 ? 3 : 2);
+    const int want_dataflow = (c->dataflow && n % 64 == 0 && n % kBrickRows == 0 && n % chunk == 0 && form == 0 && !c->emit_mode) ? 1 : 0;
     const int want_glanes = want_dataflow ? 1 : (nnu >= c->lanes ? 1 : c->lanes);
     if (P.valid && P.n == n && P.chunk == chunk && P.gmax == gmax && P.share == c->share && P.want_glanes == want_glanes &&
         P.want_dataflow == want_dataflow && P.box == c->box &&

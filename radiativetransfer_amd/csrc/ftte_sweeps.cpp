@@ -585,8 +585,9 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
                 L.up = P.up; L.vp = P.vp; L.uw = P.uw; L.ut = P.ut; L.nslot = P.nslot;
                 L.emit = c->emit_mode;
                 L.math = kMath;
-                const int lrc = (c->team == 2 && !c->emit_mode) ? launch_brick_pair(L, P.max_dirs, c->pair_waves, q)
-                              : (c->team && !c->emit_mode) ? launch_brick_team(L, P.max_dirs, c->brick_waves, q) : launch_brick(L, P.max_dirs, c->brick_waves, q);
+                const int form = brick_form(c, nnu);
+                const int lrc = form == 2 ? launch_brick_pair(L, P.max_dirs, c->pair_waves, q)
+                              : form == 1 ? launch_brick_team(L, P.max_dirs, c->brick_waves, q) : launch_brick(L, P.max_dirs, c->brick_waves, q);
                 if (lrc) return fail(c, lrc == -1 ? FTTE_ERR_ARG : FTTE_ERR_NO_DEVICE, "brick kernel launch failed");
             }
             if (lane_ends) { // this lane's J: merged as soon as its stages are done, and on its way back (pinned arrays) behind that

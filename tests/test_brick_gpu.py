@@ -24,7 +24,7 @@ def bricks(engine, request):
     engine.set_option("engine", 2)
     engine.set_option("team", {"team": 1, "solo": 0, "pair": 2}[request.param])
     yield engine
-    for key, value in (("engine", 0), ("team", 0), ("chunk", 0), ("group", 0), ("share", 2), ("lanes", 2)):
+    for key, value in (("engine", 0), ("team", -1), ("chunk", 0), ("group", 0), ("share", 2), ("lanes", 2)):
         engine.set_option(key, value)
 
 
