@@ -18,6 +18,39 @@ using gcdouble = const __attribute__((address_space(1))) double;
 using gdouble = __attribute__((address_space(1))) double;
 
 __device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+// A wave-uniform address the compiler is to keep in scalar registers and use as the base of a load or store whose lane part is a
+// 32-bit offset (`global_load v, v_offset, s[base]`): left to itself it folds the lane's offset into a 64-bit vector address that it
+// then carries, and advances, in vector registers and vector instructions.
+// (the base passes through an empty asm and stays scalar; the caller passes the offset through `here()` once per run of accesses,
+// so that its extension to 64 bits stays next to them, where instruction selection can fold it, instead of being hoisted out of
+// the loop as a 64-bit vector value)
+__device__ __forceinline__ gcbyte *lane_address(gcbyte *base, unsigned offset) { asm volatile("" : "+s"(base)); return base + offset; }
+__device__ __forceinline__ gbyte *lane_address(gbyte *base, unsigned offset) { asm volatile("" : "+s"(base)); return base + offset; }
+__device__ __forceinline__ unsigned here(unsigned offset) { asm volatile("" : "+v"(offset)); return offset; }
+__device__ __forceinline__ long here(long step) { asm volatile("" : "+s"(step)); return step; }
+
+// One value per row of a brick for this lane: rows `step` bytes apart from `row` on, the lane `off` bytes into its row.  A whole
+// brick (nrows == ROWS) walks the rows with one scalar addition each; the ragged last brick of a grid that is no multiple of the
+// brick repeats its last row's address for the rows it lacks.
+template <int ROWS, bool NT>
+__device__ __forceinline__ void load_rows(double (&dst)[ROWS], gcbyte *row, unsigned off, long step, int nrows)
+{
+    if (nrows == ROWS) {
+        off = here(off);
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            dst[r] = NT ? __builtin_nontemporal_load((gcdouble *)lane_address(row, off)) : *(gcdouble *)lane_address(row, off);
+            row += step;
+        }
+    } else {
+        off = here(off);
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            dst[r] = NT ? __builtin_nontemporal_load((gcdouble *)lane_address(row, off)) : *(gcdouble *)lane_address(row, off);
+            row += r + 1 < nrows ? step : 0;
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // Cell-fixed bricks (ftte_internal.h: BrickGroup, BrickTask, BrickLaunch).
@@ -288,35 +321,20 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
 
     // the opacity of the brick's cells, one layer ahead of the layer being crossed
     double kap_next[R];
-    {
-        gcbyte *kplane = kbase + 8l * i0 * si;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int row = (cv0 + r < n) ? cv0 + r : n;
-            kap_next[r] = *(gcdouble *)(kplane + row * row_bytes + off0);
-
-        }
-    }
+    // (row addresses are walked with scalar additions; the rows a ragged last brick lacks repeat its last row's address for loads
+    // and are skipped by stores)
+    const int nrows = n - cv0 + 1 < R ? n - cv0 + 1 : R;
+    const long row0 = cv0 * row_bytes;
+    load_rows<R, false>(kap_next, kbase + 8l * i0 * si + row0, off0, row_bytes, nrows);
     for (int i = i0; i <= i1; ++i) {
         const int il = i - i0;
         double kap[R], xs[EMIT ? R : 1], Jacc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) { kap[r] = kap_next[r]; Jacc[r] = 0.0; if (EMIT) { const int row = (cv0 + r < n) ? cv0 + r : n; xs[r] = *(gcdouble *)(xbase + 8l * i * si + row * row_bytes + off0); } }
         gbyte *jplane = jbase + 8l * i * si;
-        if (accumulate && own_lane) { // what the groups before this one left in these cells
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (cv0 + r <= n) Jacc[r] = __builtin_nontemporal_load((gcdouble *)(jplane + (cv0 + r) * row_bytes + off0));
-        }
-        if (i < i1) {
-            gcbyte *kplane = kbase + 8l * (i + 1) * si;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int row = (cv0 + r < n) ? cv0 + r : n;
-                kap_next[r] = *(gcdouble *)(kplane + row * row_bytes + off0);
-
-            }
-        }
+        const long rstep = here(row_bytes); // (per layer: the seven steps of a ragged brick are then not kept, and spilled, for the whole run)
+        if (accumulate) load_rows<R, true>(Jacc, (gcbyte *)jplane + row0, off0, rstep, nrows); // what the groups before this one left in these cells
+        if (i < i1) load_rows<R, false>(kap_next, kbase + 8l * (i + 1) * si + row0, off0, rstep, nrows);
         for (int j = 0; j < ndir; ++j) {
             int d = p0 + j;
             d = d >= ndir ? d - ndir : d;
@@ -354,12 +372,16 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
         p0 = p0 ? p0 - 1 : ndir - 1;
         // the group's contribution to J of this layer's cells: stored once, read only by the merge
         if (own_lane) {
+            gbyte *jrow = jplane + row0;
+            const unsigned off = here(off0);
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (cv0 + r <= n) {
-                    if (through) __hip_atomic_store((double *)(jplane + (cv0 + r) * row_bytes + off0), Jacc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    else __builtin_nontemporal_store(Jacc[r], (gdouble *)(jplane + (cv0 + r) * row_bytes + off0));
+            for (int r = 0; r < R; ++r) {
+                if (r < nrows) {
+                    if (through) __hip_atomic_store((double *)(jrow + off0), Jacc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else __builtin_nontemporal_store(Jacc[r], (gdouble *)lane_address(jrow, off));
                 }
+                jrow += rstep;
+            }
         }
     }
 
