@@ -97,6 +97,26 @@ def test_bricks_equal_tiles_on_the_full_direction_set(engine, n, chunk):
     assert 0 < J_bricks.min() and np.all(J_bricks <= uvb[:, None] * (1 + SUM_RTOL))
 
 
+def test_one_wavefront_and_a_pair_per_brick_same_bits(engine):
+    """The pair form splits a brick's rows between two wavefronts and changes nothing else: the same bits as one wavefront per
+    brick, on whole and ragged grids, with shared accumulators (96 directions in groups of three)."""
+    phi, theta, w = O.healpix_directions(2)
+    engine.set_option("engine", 2)
+    try:
+        for n in (64, 70):
+            kappa, uvb, box = synthetic.uniform_workload(n, 3, seed=5, tau_median=0.2)
+            engine.set_uniform_grid(n, box)
+            engine.set_opacity(kappa)
+            J = {}
+            for form in (0, 2):
+                engine.set_option("team", form)
+                J[form] = engine.transport(phi, theta, w, uvb)
+            assert np.array_equal(J[0], J[2]), n
+    finally:
+        engine.set_option("team", -1)
+        engine.set_option("engine", 0)
+
+
 def test_launch_records_account_for_every_update(bricks):
     n, nnu = 70, 2
     kappa, uvb, box = synthetic.uniform_workload(n, nnu, seed=2, tau_median=0.3)
