@@ -484,16 +484,12 @@ __global__ void __launch_bounds__(128, WAVES) brick_pair_kernel(const BrickLaunc
 
     double kap_next[H], kap[H], Jacc[H];
     const double xs[1] = {0.0};
-    {
-        gcbyte *kplane = kbase + 8l * i0 * si;
+    // rows of this wave inside the grid (the upper wave of a ragged last brick may have none: it then reads row n throughout)
+    const int nrows = n - cv0 + 1 < H ? (n - cv0 + 1 > 0 ? n - cv0 + 1 : 0) : H;
+    const long row0 = (cv0 < n ? cv0 : n) * row_bytes;
 #pragma unroll
-        for (int r = 0; r < H; ++r) {
-            const int row = (cv0 + r < n) ? cv0 + r : n;
-            kap_next[r] = *(gcdouble *)(kplane + row * row_bytes + off0);
-            kap[r] = 0.0;
-            Jacc[r] = 0.0;
-        }
-    }
+    for (int r = 0; r < H; ++r) { kap[r] = 0.0; Jacc[r] = 0.0; }
+    load_rows<H, false>(kap_next, kbase + 8l * i0 * si + row0, off0, row_bytes, nrows);
     // wave 0 crosses layer i0 + it, wave 1 the layer before: what moves up out of row 3 waits a layer in LDS
     const int nlayers = i1 - i0 + 1;
     for (int it = 0; it <= nlayers; ++it) {
@@ -503,19 +499,9 @@ __global__ void __launch_bounds__(128, WAVES) brick_pair_kernel(const BrickLaunc
             gbyte *jplane = jbase + 8l * i * si;
 #pragma unroll
             for (int r = 0; r < H; ++r) { kap[r] = kap_next[r]; Jacc[r] = 0.0; }
-            if (accumulate && own_lane) {
-#pragma unroll
-                for (int r = 0; r < H; ++r)
-                    if (cv0 + r <= n) Jacc[r] = __builtin_nontemporal_load((gcdouble *)(jplane + (cv0 + r) * row_bytes + off0));
-            }
-            if (i < i1) {
-                gcbyte *kplane = kbase + 8l * (i + 1) * si;
-#pragma unroll
-                for (int r = 0; r < H; ++r) {
-                    const int row = (cv0 + r < n) ? cv0 + r : n;
-                    kap_next[r] = *(gcdouble *)(kplane + row * row_bytes + off0);
-                }
-            }
+            const long rstep = here(row_bytes);
+            if (accumulate) load_rows<H, true>(Jacc, (gcbyte *)jplane + row0, off0, rstep, nrows);
+            if (i < i1) load_rows<H, false>(kap_next, kbase + 8l * (i + 1) * si + row0, off0, rstep, nrows);
             double *hand = handover + (size_t)(il & 1) * max_dirs * 64;
             for (int j = 0; j < ndir; ++j) {
                 int d = p0 + j;
@@ -555,9 +541,13 @@ __global__ void __launch_bounds__(128, WAVES) brick_pair_kernel(const BrickLaunc
             }
             p0 = p0 ? p0 - 1 : ndir - 1;
             if (own_lane) {
+                gbyte *jrow = jplane + row0;
+                const unsigned off = here(off0);
 #pragma unroll
-                for (int r = 0; r < H; ++r)
-                    if (cv0 + r <= n) __builtin_nontemporal_store(Jacc[r], (gdouble *)(jplane + (cv0 + r) * row_bytes + off0));
+                for (int r = 0; r < H; ++r) {
+                    if (r < nrows) __builtin_nontemporal_store(Jacc[r], (gdouble *)lane_address(jrow, off));
+                    jrow += rstep;
+                }
             }
         }
         __syncthreads(); // the layer's hand-overs are in LDS before the wave above starts that layer
