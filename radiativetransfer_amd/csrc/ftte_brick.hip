@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
 // barrier per layer couples the two, and each wave holds half the rays, opacities and sums (so more of them fit a SIMD).
 // The arithmetic and the order of every cell's sum are those of brick_kernel.
 // grid: ntasks * nnu workgroups of 128 threads; dynamic LDS: 2 x (max_dirs - 1) x 2 KB of parked rays + 2 x max_dirs x 512 B of hand-over
-template <int WAVES>
+template <int WAVES, int EMIT>
 __global__ void __launch_bounds__(128, WAVES) brick_pair_kernel(const BrickLaunch L, int max_dirs)
 {
     extern __shared__ double pair_lds[];
@@ -444,6 +444,7 @@ __global__ void __launch_bounds__(128, WAVES) brick_pair_kernel(const BrickLaunc
     const long org = G->org;
     gcbyte *kbase = (gcbyte *)(G->kappa + (long)nu * L.group_stride + org);
     gbyte *jbase = (gbyte *)(G->J + (long)nu * L.group_stride + org);
+    gcbyte *xbase = EMIT ? (gcbyte *)(G->emis + (long)nu * L.group_stride + org) : nullptr;
 
     const int cu = 64 * tu + lane + 1;
     const int cv0 = R * tv + H * wv + 1; // this wave's first row
@@ -483,7 +484,7 @@ __global__ void __launch_bounds__(128, WAVES) brick_pair_kernel(const BrickLaunc
     }
 
     double kap_next[H], kap[H], Jacc[H];
-    const double xs[1] = {0.0};
+    double xs[EMIT ? H : 1] = {};
     // rows of this wave inside the grid (the upper wave of a ragged last brick may have none: it then reads row n throughout)
     const int nrows = n - cv0 + 1 < H ? (n - cv0 + 1 > 0 ? n - cv0 + 1 : 0) : H;
     const long row0 = (cv0 < n ? cv0 : n) * row_bytes;
@@ -500,6 +501,7 @@ __global__ void __launch_bounds__(128, WAVES) brick_pair_kernel(const BrickLaunc
 #pragma unroll
             for (int r = 0; r < H; ++r) { kap[r] = kap_next[r]; Jacc[r] = 0.0; }
             const long rstep = here(row_bytes);
+            if (EMIT) load_rows<EMIT ? H : 1, false>(xs, xbase + 8l * i * si + row0, off0, rstep, nrows); // the layer's emissivities or source functions
             if (accumulate) load_rows<H, true>(Jacc, (gcbyte *)jplane + row0, off0, rstep, nrows);
             if (i < i1) load_rows<H, false>(kap_next, kbase + 8l * (i + 1) * si + row0, off0, rstep, nrows);
             double *hand = handover + (size_t)(il & 1) * max_dirs * 64;
@@ -527,15 +529,15 @@ __global__ void __launch_bounds__(128, WAVES) brick_pair_kernel(const BrickLaunc
                 double *cout = wv ? nullptr : hand + j * 64;
                 const bool third_first = rc == RC_THREE_U_SWAP || rc == RC_THREE_V_SWAP;
                 switch (rc) {
-                case RC_ONE: brick_step<RC_ONE, 0, H>(L.math, lead, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, false, false, 0, 63, true, cin, cout); break;
-                case RC_TWO_U: brick_step<RC_TWO_U, 0, H>(L.math, lead, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, false, false, 0, 63, true, cin, cout); break;
-                case RC_TWO_V: brick_step<RC_TWO_V, 0, H>(L.math, lead, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, false, false, 0, 63, true, cin, cout); break;
+                case RC_ONE: brick_step<RC_ONE, EMIT, H>(L.math, lead, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, false, false, 0, 63, true, cin, cout); break;
+                case RC_TWO_U: brick_step<RC_TWO_U, EMIT, H>(L.math, lead, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, false, false, 0, 63, true, cin, cout); break;
+                case RC_TWO_V: brick_step<RC_TWO_V, EMIT, H>(L.math, lead, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, false, false, 0, 63, true, cin, cout); break;
                 case RC_THREE_U:
                 case RC_THREE_U_SWAP:
-                    brick_step<RC_THREE_U, 0, H>(L.math, lead, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, false, false, 0, 63, true, cin, cout);
+                    brick_step<RC_THREE_U, EMIT, H>(L.math, lead, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, false, false, 0, 63, true, cin, cout);
                     break;
                 default:
-                    brick_step<RC_THREE_V, 0, H>(L.math, lead, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, false, false, 0, 63, true, cin, cout);
+                    brick_step<RC_THREE_V, EMIT, H>(L.math, lead, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, false, false, 0, 63, true, cin, cout);
                     break;
                 }
             }
@@ -727,13 +729,17 @@ int launch_brick_team(const BrickLaunch &L, int max_dirs, int waves, hipStream_t
 int launch_brick_pair(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stream)
 {
     if (L.ntasks <= 0) return 0;
-    if (max_dirs < 1 || max_dirs > kBrickMaxDirs || L.emit || L.ticket != nullptr) return -1;
+    if (max_dirs < 1 || max_dirs > kBrickMaxDirs || L.ticket != nullptr) return -1;
     const dim3 grid((unsigned)L.ntasks * (unsigned)L.nnu);
     const size_t lds = ((size_t)(max_dirs - 1) * kBrickRows * 64 + 2 * max_dirs * 64) * sizeof(double) + (size_t)lds_pad();
-    switch (waves) {
-    case 2: hipLaunchKernelGGL((brick_pair_kernel<2>), grid, dim3(128), lds, stream, L, max_dirs); break;
-    case 3: hipLaunchKernelGGL((brick_pair_kernel<3>), grid, dim3(128), lds, stream, L, max_dirs); break;
-    case 4: hipLaunchKernelGGL((brick_pair_kernel<4>), grid, dim3(128), lds, stream, L, max_dirs); break;
+    // emission: the log-mean's own division and polynomials (ftte_segment_emit) need the registers of three workgroups per SIMD
+    if (L.emit == 1) hipLaunchKernelGGL((brick_pair_kernel<3, 1>), grid, dim3(128), lds, stream, L, max_dirs);
+    else if (L.emit == 2) hipLaunchKernelGGL((brick_pair_kernel<3, 2>), grid, dim3(128), lds, stream, L, max_dirs);
+    else if (L.emit) return -1;
+    else switch (waves) {
+    case 2: hipLaunchKernelGGL((brick_pair_kernel<2, 0>), grid, dim3(128), lds, stream, L, max_dirs); break;
+    case 3: hipLaunchKernelGGL((brick_pair_kernel<3, 0>), grid, dim3(128), lds, stream, L, max_dirs); break;
+    case 4: hipLaunchKernelGGL((brick_pair_kernel<4, 0>), grid, dim3(128), lds, stream, L, max_dirs); break;
     default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;

@@ -271,12 +271,11 @@ struct ftte_ctx {
 // Which form of the brick kernel sweeps: 0 one wavefront per brick, 1 a wavefront per direction, 2 a pair of wavefronts per brick.
 // Option "team" = -1 (the default) leaves it to the parallelism: with four frequency groups or fewer on this GPU (a rank of a
 // frequency-sharded run) the stages are narrow, and the pair form's twice as many wavefronts fill them better (5 / 7 / 9 %
-// at 4 / 2 / 1 groups); at eight the single wavefront is 1.5 % ahead.  Emission and the dataflow launch are built for form 0 only.
+// at 4 / 2 / 1 groups); at eight the single wavefront is 1.5 % ahead.  The dataflow launch is built for form 0 only.
 inline int brick_form(const ftte_ctx *c, int nnu)
 {
-    if (c->emit_mode) return 0;
-    if (c->team >= 0) return c->team;
-    return (nnu <= 4 && !c->dataflow) ? 2 : 0;
+    const int form = c->team >= 0 ? c->team : ((nnu <= 4 && !c->dataflow) ? 2 : 0);
+    return (c->emit_mode && form == 1) ? 0 : form; // (the team form is built without emission)
 }
 
 

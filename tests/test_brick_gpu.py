@@ -99,7 +99,8 @@ def test_bricks_equal_tiles_on_the_full_direction_set(engine, n, chunk):
 
 def test_one_wavefront_and_a_pair_per_brick_same_bits(engine):
     """The pair form splits a brick's rows between two wavefronts and changes nothing else: the same bits as one wavefront per
-    brick, on whole and ragged grids, with shared accumulators (96 directions in groups of three)."""
+    brick, on whole and ragged grids, with shared accumulators (96 directions in groups of three), without emission and with
+    either form of it."""
     phi, theta, w = O.healpix_directions(2)
     engine.set_option("engine", 2)
     try:
@@ -107,12 +108,18 @@ def test_one_wavefront_and_a_pair_per_brick_same_bits(engine):
             kappa, uvb, box = synthetic.uniform_workload(n, 3, seed=5, tau_median=0.2)
             engine.set_uniform_grid(n, box)
             engine.set_opacity(kappa)
-            J = {}
-            for form in (0, 2):
-                engine.set_option("team", form)
-                J[form] = engine.transport(phi, theta, w, uvb)
-            assert np.array_equal(J[0], J[2]), n
+            for emission in (None, "eta", "source"):
+                if emission:
+                    x = np.random.default_rng(n).uniform(0.1, 2.0, kappa.shape) * uvb[:, None] * (kappa if emission == "eta" else 1.0)
+                    (engine.set_emissivity if emission == "eta" else engine.set_source_function)(x)
+                J = {}
+                for form in (0, 2):
+                    engine.set_option("team", form)
+                    J[form] = engine.transport(phi, theta, w, uvb)
+                assert np.array_equal(J[0], J[2]), (n, emission)
+                engine.set_emissivity(None)
     finally:
+        engine.set_emissivity(None)
         engine.set_option("team", -1)
         engine.set_option("engine", 0)
 

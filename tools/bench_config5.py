@@ -23,6 +23,9 @@ phi, theta, w = ang[:, 0].copy(), ang[:, 1].copy(), np.full(ndir, 1.0 / ndir)
 dev = torch.device("cuda", 0)
 kappa = torch.from_numpy(kappa_host).to(dev)
 eng = rt.DiffuseTransfer(device=0)
+for a in sys.argv[3:]:                                   # library options: --team=2 ...
+    if a.startswith("--") and "=" in a:
+        eng.set_option(a[2:].split("=")[0], int(a.split("=")[1]))
 eng.set_uniform_grid(n, 1.0)
 eng.set_opacity_device(nnu, kappa.data_ptr())
 it = SourceIteration(eng, nnu, n ** 3, phi, theta, w, uvb * 0.0 + 1e-30, eps, 1e-21 * s_nu ** 0.5)
