@@ -752,14 +752,14 @@ int launch_brick(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stre
     const dim3 grid((unsigned)L.ntasks * (unsigned)L.nnu);
     const size_t lds = (size_t)(max_dirs - 1) * kBrickRows * 64 * sizeof(double) + (size_t)lds_pad(); // pad: diagnostic knob "ldspad"
     const bool flow = L.ticket != nullptr;
-    if (masked && !flow && L.emit) { // (the emission forms hold 179 registers with the lane range: two waves per SIMD, as without it)
+    if (masked && !flow && L.emit) { // (the emission forms hold 162 registers with the lane range, as without it: three waves per SIMD)
         if (L.emit == 1) hipLaunchKernelGGL((brick_kernel<2, 1, false, true>), grid, dim3(64), lds, stream, L);
         else hipLaunchKernelGGL((brick_kernel<2, 2, false, true>), grid, dim3(64), lds, stream, L);
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
     if (masked) {
         if (flow) return -1; // the hybrid sweep issues a launch per stage
-        hipLaunchKernelGGL((brick_kernel<3, 0, false, true>), grid, dim3(64), lds, stream, L); // (128 registers would spill 16)
+        hipLaunchKernelGGL((brick_kernel<3, 0, false, true>), grid, dim3(64), lds, stream, L); // (126 registers since the trimming: four waves per SIMD in fact)
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
     // emission: the log-mean's own division and polynomials need more registers than three waves per SIMD leave

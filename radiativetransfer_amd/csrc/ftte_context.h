@@ -274,7 +274,7 @@ struct ftte_ctx {
 // at 4 / 2 / 1 groups); at eight the single wavefront is 1.5 % ahead.  The dataflow launch is built for form 0 only.
 inline int brick_form(const ftte_ctx *c, int nnu)
 {
-    // (with emission the pair form is ahead at eight groups as well, 64.8 against 65.5 ms: 103 instead of 165 VGPRs)
+    // (with emission the pair form is ahead at eight groups as well, 64.8 against 65.5 ms: 103 instead of 162 VGPRs)
     const int form = c->team >= 0 ? c->team : (((nnu <= 4 || c->emit_mode) && !c->dataflow) ? 2 : 0);
     return (c->emit_mode && form == 1) ? 0 : form; // (the team form is built without emission)
 }

@@ -398,7 +398,7 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
         const int bu = D0.su < 0 ? P.ntu - 1 - tu : tu, bv = D0.sv < 0 ? P.ntv - 1 - tv : tv, bi = D0.si < 0 ? P.nti - 1 - ti : ti;
         return ((size_t)bi * P.ntv + bv) * P.ntu + bu;
     };
-    // Two sets of lists in one task array, [whole lists][masked lists]: the masked kernel (more registers, three waves per SIMD)
+    // Two sets of lists in one task array, [whole lists][masked lists]: the masked kernel (a lane range per task)
     // takes every brick of a stage in which some brick is cut by a box -- two launches per stage would run one after the other,
     // and a launch of a few bricks lasts as long as one of many --, the plain kernel the stages without.
     std::vector<uint8_t> cut(nlist, 0);
