@@ -109,18 +109,24 @@ typedef struct {
 
 /* e = exp(-tau), g = (1-exp(-tau))/tau  (g(0) = 1).  tau >= 0 expected; a
  * negative tau (unphysical opacity) still evaluates, up to overflow. */
-FTTE_HD void ftte_attenuation_lead(const ftte_consts *K, double lead, double tau, double *e_out, double *g_out);
+FTTE_HD int ftte_attenuation_lead(const ftte_consts *K, double lead, double tau, double *e_out, double *g_out);
 FTTE_HD void ftte_attenuation(const ftte_consts *K, double tau, double *e_out, double *g_out)
 {
-    ftte_attenuation_lead(K, K->c[9], tau, e_out, g_out);
+    (void)ftte_attenuation_lead(K, K->c[9], tau, e_out, g_out);
 }
 
 /* `lead`: the polynomial's leading coefficient, K->c[9], handed in by the caller.  A device kernel that keeps it in a vector
  * register for its whole run saves the move every first Horner step otherwise starts with (an instruction reads one scalar
- * operand: c9 * r + c8 with both coefficients in scalar registers needs one of them copied first). */
-FTTE_HD void ftte_attenuation_lead(const ftte_consts *K, double lead, double tau, double *e_out, double *g_out)
+ * operand: c9 * r + c8 with both coefficients in scalar registers needs one of them copied first).
+ *
+ * Returns whether any lane of the wavefront (on the host: this evaluation) left the thin range tau < ln2/2, where n = 0,
+ * exp(-tau) = exp(r) needs no scaling and g is the polynomial itself.  Everything the other lanes need -- the scaling by 2^n,
+ * the floor at exp(-1000) = 0, the division -- is done behind that one test, so a wavefront of thin segments (five in six of
+ * the benchmark's) executes the range reduction, twelve fused multiply-adds and the test, and nothing else.  The values are
+ * those of the straightforward form x = max(-tau, x_floor), e = ldexp(exp(r), n), g = n ? (1 - e)/tau : expm1(r)/r. */
+FTTE_HD int ftte_attenuation_lead(const ftte_consts *K, double lead, double tau, double *e_out, double *g_out)
 {
-    const double x = FTTE_FMAX(-tau, K->x_floor);
+    const double x = -tau;
     const double nf = FTTE_RINT(x * K->log2e);
     double r = FTTE_FMA(nf, -K->ln2_hi, x);
     r = FTTE_FMA(nf, -K->ln2_lo, r);
@@ -136,31 +142,38 @@ FTTE_HD void ftte_attenuation_lead(const ftte_consts *K, double lead, double tau
     q = FTTE_FMA(q, r, K->c[1]);
     q = FTTE_FMA(q, r, K->c[0]);
 
-    const double g0 = FTTE_FMA(r, q, 1.0);  /* expm1(r)/r */
-    const double e0 = FTTE_FMA(r, g0, 1.0); /* exp(r)     */
-    const int n = (int)nf;
-    const double e = FTTE_LDEXP(e0, n);
-    *e_out = e;
-    *g_out = g0;
-    if (FTTE_ANY(n != 0)) { /* optically thin wavefronts (tau < ln2/2 in every lane) never divide */
+    double g = FTTE_FMA(r, q, 1.0); /* expm1(r)/r */
+    double e = FTTE_FMA(r, g, 1.0); /* exp(r)     */
+    const int thick = FTTE_ANY(nf != 0.0);
+    if (thick) {
+        /* below x_floor exp(x) is 0 in binary64 (and r, q of such a lane are whatever the reduction of a huge x gives: not used);
+         * n is kept inside the range of an int for it */
+        const int n = (int)FTTE_FMAX(nf, -2048.0);
+        const double scaled = FTTE_LDEXP(e, n); /* n == 0: e itself */
+        e = (x >= K->x_floor) ? scaled : 0.0;
         double gd = FTTE_DIV(1.0 - e, tau); /* n != 0: tau >= ln2/2, 1-e >= 0.29, no cancellation */
         FTTE_KEEP(gd);
-        *g_out = (n == 0) ? g0 : gd;
+        g = (nf == 0.0) ? g : gd;
     }
+    *e_out = e;
+    *g_out = g;
+    return thick;
 }
 
 /* One segment: advances the ray intensity and returns the path-mean intensity
  * the cell receives from it.  Iout == 0 (underflow) yields a zero mean, as the
- * reference's (Iin-0)/log(Iin/0) does. */
+ * reference's (Iin-0)/log(Iin/0) does.  A thin segment (n = 0: exp(-tau) > 0.7) takes a nonzero Iin to a nonzero Iout --
+ * the product with the smallest subnormal still rounds to it --, and with Iin = 0 the mean is 0 as it stands: the fix-up is
+ * needed only where some lane is thick, and sits behind the same test. */
 FTTE_HD double ftte_segment_lead(const ftte_consts *K, double lead, double *I, double tau)
 {
     double e, g;
-    ftte_attenuation_lead(K, lead, tau, &e, &g);
+    const int thick = ftte_attenuation_lead(K, lead, tau, &e, &g);
     const double Iin = *I;
     const double Iout = Iin * e;
     *I = Iout;
     double mean = Iin * g;
-    if (FTTE_ANY(Iout == 0.0)) { /* underflow: rare enough to branch on per wave */
+    if (thick) {
         mean = (Iout == 0.0) ? 0.0 : mean;
         FTTE_KEEP(mean); /* a branch, not a pair of selects every lane pays for */
     }
