@@ -301,7 +301,8 @@ int ftte_host_unregister(ftte_ctx *ctx, void *ptr);
  * ftte_set_grid with an unchanged list keeps the tree, the plans and the resident medium), "plan_builds" (tiled-sweep
  * planner), "forest_builds" (per-direction segment forests of a refined cell array); of the hybrid sweep's current plan, "hybrid_boxes"
  * (boxes around clusters of refined cells, of the izone that has most) and "hybrid_passes" (passes their forests are swept in), 0
- * when the last sweep did not take the hybrid path.  -1 for an unknown name. */
+ * when the last sweep did not take the hybrid path; "brick_form": the form of the brick kernel the last uniform-grid sweep of the
+ * brick engine took (option "team": 0, 1, 2; -1 before the first).  -1 for an unknown name. */
 long long ftte_counter(const ftte_ctx *ctx, const char *name);
 
 /* Tuning knobs.  0 means "automatic" where noted.  Results do not depend on any of them except through the order in which the

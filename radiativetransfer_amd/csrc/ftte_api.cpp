@@ -442,6 +442,7 @@ long long ftte_counter(const ftte_ctx *c, const char *name)
     if (!std::strcmp(name, "forest_builds")) return c->n_forest_builds;
     if (!std::strcmp(name, "hybrid_boxes")) return (c->hplan.valid && c->hplan.worthwhile) ? c->hplan.most_boxes : 0;
     if (!std::strcmp(name, "hybrid_passes")) return (c->hplan.valid && c->hplan.worthwhile) ? c->hplan.npass : 0;
+    if (!std::strcmp(name, "brick_form")) return c->last_brick_form;
     return -1;
 }
 

@@ -135,7 +135,7 @@ struct ftte_ctx {
 
     // which organisation sweeps a uniform grid: 0 = the default = 2 = cell-fixed bricks (brick_kernel), 1 = ray-following tiles
     // (sweep_kernel)
-    int engine = 0, chunk = 0, group = 0, brick_waves = 4, pair_waves = 4, share = 2, team = -1, lanes = 2; // chunk, group: 0 = by the parallelism (build_brick_plan)
+    int engine = 0, chunk = 0, group = 0, brick_waves = 4, pair_waves = 4, last_brick_form = -1, share = 2, team = -1, lanes = 2; // chunk, group: 0 = by the parallelism (build_brick_plan)
     std::vector<hipStream_t> lane_stream;   // extra streams of the brick sweep (frequency groups are independent)
     std::vector<hipEvent_t> pipe_up;        // ftte_diffuse_iteration: lane k's opacities have arrived
     bool stage_used[2] = {false, false};    // the pinned staging block has a transfer recorded on stage_ev

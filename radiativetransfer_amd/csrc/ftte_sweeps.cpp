@@ -586,6 +586,7 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
                 L.emit = c->emit_mode;
                 L.math = kMath;
                 const int form = brick_form(c, nnu);
+                c->last_brick_form = form;
                 const int lrc = form == 2 ? launch_brick_pair(L, P.max_dirs, c->pair_waves, q)
                               : form == 1 ? launch_brick_team(L, P.max_dirs, c->brick_waves, q) : launch_brick(L, P.max_dirs, c->brick_waves, q);
                 if (lrc) return fail(c, lrc == -1 ? FTTE_ERR_ARG : FTTE_ERR_NO_DEVICE, "brick kernel launch failed");

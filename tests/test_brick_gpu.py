@@ -124,6 +124,27 @@ def test_one_wavefront_and_a_pair_per_brick_same_bits(engine):
         engine.set_option("engine", 0)
 
 
+def test_form_of_the_brick_kernel_follows_the_frequency_groups(engine):
+    """Left to itself (option team = -1) the library sweeps with a pair of wavefronts per brick up to four frequency groups, with
+    one above, and with the pair whenever there is emission."""
+    n = 32
+    phi, theta, w = O.healpix_directions(1)
+    engine.set_option("engine", 2)
+    try:
+        for nnu, emission, form in ((2, False, 2), (4, False, 2), (5, False, 0), (8, False, 0), (8, True, 2)):
+            kappa, uvb, box = synthetic.uniform_workload(n, nnu, seed=3, tau_median=0.2)
+            engine.set_uniform_grid(n, box)
+            engine.set_opacity(kappa)
+            engine.set_source_function(np.full_like(kappa, 1e-22) if emission else None)
+            J = engine.transport(phi, theta, w, uvb)
+            assert engine.counter("brick_form") == form, (nnu, emission)
+            src = {"src": np.full_like(kappa, 1e-22)} if emission else {}
+            assert np.allclose(J, O.sweep_uniform(n, kappa, box, phi, theta, w, uvb, arith=O.ARITH_DEVICE, **src), rtol=SUM_RTOL, atol=0)
+    finally:
+        engine.set_source_function(None)
+        engine.set_option("engine", 0)
+
+
 def test_launch_records_account_for_every_update(bricks):
     n, nnu = 70, 2
     kappa, uvb, box = synthetic.uniform_workload(n, nnu, seed=2, tau_median=0.3)
