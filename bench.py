@@ -69,6 +69,7 @@ def parse():
     ap.add_argument("--chunk", type=int, default=0, help="bricks: layers per brick; 0 = library default")
     ap.add_argument("--group", type=int, default=0, help="bricks: directions per group; 0 = library default")
     ap.add_argument("--brick-waves", type=int, default=0, help="bricks: waves per SIMD the kernel is compiled for")
+    ap.add_argument("--tiled", type=int, default=-1, help="bricks: 1 opacities and accumulators stored brick by brick, 0 as frames (default)")
     ap.add_argument("--pair-waves", type=int, default=0, help="pair kernel (--team 2): workgroups per SIMD it is built for (2..4)")
     ap.add_argument("--team", type=int, default=-1, help="bricks: 0 one wavefront per group (default), 1 one wavefront per direction, 2 two wavefronts per brick")
     ap.add_argument("--share", type=int, default=-1, help="bricks: accumulator sharing 0/1/2")
@@ -267,6 +268,8 @@ def main():
         eng.set_option("team", a.team)
     if a.pair_waves:
         eng.set_option("pair_waves", a.pair_waves)
+    if a.tiled >= 0:
+        eng.set_option("tiled", a.tiled)
     if a.share >= 0:
         eng.set_option("share", a.share)
     if a.lanes:

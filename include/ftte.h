@@ -316,6 +316,8 @@ long long ftte_counter(const ftte_ctx *ctx, const char *name);
  *     "brick_waves" bricks: waves per SIMD the kernel is compiled for, 2..4
  *     "dataflow"    bricks: 0 a launch per stage (default), 1 one launch whose bricks wait for each other, 2 the same with
  *                   write-through stores
+ *     "tiled"       bricks: 1 = opacities and accumulators stored brick by brick (a brick's layer in one piece; grids of whole
+ *                   bricks), 2 = the whole brick in one piece; same results, measured without gain; 0 = in frames (default)
  *     "team"        bricks: 0 = one wavefront per brick, 1 = one wavefront per direction of a group, 2 = two wavefronts per
  *                   brick, four rows each ("pair_waves": workgroups per SIMD that form is compiled for, 2..4); -1 (default):
  *                   2 with up to four frequency groups on this GPU, else 0

@@ -68,6 +68,7 @@ int ftte_destroy(ftte_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (int l = 0; l < 3; ++l) {
         if (c->kappa[l]) (void)hipFree(c->kappa[l]);
+        if (c->kappa_tiled[l]) (void)hipFree(c->kappa_tiled[l]);
         if (c->emis[l]) (void)hipFree(c->emis[l]);
         for (int s = 0; s < kMaxAcc; ++s) if (c->acc[l][s]) (void)hipFree(c->acc[l][s]);
     }
@@ -155,6 +156,7 @@ int ftte_set_grid(ftte_ctx *c, int nx, int ny, int nz, int64_t ncell, const int3
         (void)hipStreamSynchronize(c->stream);
         for (int l = 0; l < 3; ++l) {
             if (c->kappa[l]) { (void)hipFree(c->kappa[l]); c->kappa[l] = nullptr; }
+            if (c->kappa_tiled[l]) { (void)hipFree(c->kappa_tiled[l]); c->kappa_tiled[l] = nullptr; }
             if (c->emis[l]) { (void)hipFree(c->emis[l]); c->emis[l] = nullptr; }
             for (int s = 0; s < kMaxAcc; ++s) if (c->acc[l][s]) { (void)hipFree(c->acc[l][s]); c->acc[l][s] = nullptr; }
         }
@@ -176,6 +178,7 @@ int ftte_set_grid(ftte_ctx *c, int nx, int ny, int nz, int64_t ncell, const int3
     c->leaf_level.assign(level, level + ncell);
     c->n = nx; c->ncell = ncell; c->box = box_cm; c->grid_set = true;
     c->kappa_ready[0] = c->kappa_ready[1] = c->kappa_ready[2] = c->kappa_ready[3] = false;
+    ++c->n_kappa_sets;
     c->plan.valid = false;
     c->bplan.valid = false;
     c->tree = std::move(tree);
@@ -195,6 +198,7 @@ int ftte_set_opacity(ftte_ctx *c, int nnu, const double *kappa)
     if ((rc = upload(c, c->kappa[0], kappa, sizeof(double) * nnu * c->ncell))) return rc;
     c->nnu = nnu;
     c->kappa_ready[0] = true; c->kappa_ready[1] = c->kappa_ready[2] = c->kappa_ready[3] = false;
+    ++c->n_kappa_sets;
     return FTTE_OK;
 }
 
@@ -210,6 +214,7 @@ int ftte_set_opacity_device(ftte_ctx *c, int nnu, const double *kappa_dev)
     FTTE_HIP(c, hipStreamSynchronize(c->stream)); // the sweep may run on another stream: the copy must have landed
     c->nnu = nnu;
     c->kappa_ready[0] = true; c->kappa_ready[1] = c->kappa_ready[2] = c->kappa_ready[3] = false;
+    ++c->n_kappa_sets;
     return FTTE_OK;
 }
 
@@ -237,6 +242,7 @@ int ftte_set_species(ftte_ctx *c, int nnu, const double *HI, const double *HeI, 
     if (lrc) return fail(c, FTTE_ERR_NO_DEVICE, "ftte_set_species: kernel launch failed");
     c->nnu = nnu;
     c->kappa_ready[0] = true; c->kappa_ready[1] = c->kappa_ready[2] = c->kappa_ready[3] = false;
+    ++c->n_kappa_sets;
     return FTTE_OK;
 }
 
@@ -321,6 +327,9 @@ int ftte_set_option(ftte_ctx *c, const char *key, int value)
     } else if (!std::strcmp(key, "team")) {
         if (value < -1 || value > 2) return fail(c, FTTE_ERR_ARG, "team must be -1 (by the number of frequency groups: 2 up to four, else 0), 0 (one wavefront sweeps a group's directions in turn), 1 (one wavefront per direction) or 2 (two wavefronts per brick, four rows each)");
         c->team = value;
+    } else if (!std::strcmp(key, "tiled")) {
+        if (value < 0 || value > 2) return fail(c, FTTE_ERR_ARG, "tiled must be 0 (default), 1 (bricks: opacities and accumulators stored brick by brick where the grid is made of whole bricks: a brick's layer in one piece) or 2 (the whole brick in one piece)");
+        c->tiled_opt = value;
     } else if (!std::strcmp(key, "pair_waves")) {
         if (value < 2 || value > 4) return fail(c, FTTE_ERR_ARG, "pair_waves (workgroups of two wavefronts per SIMD the pair kernel is built for) must be 2..4");
         c->pair_waves = value;
@@ -397,11 +406,13 @@ int ftte_diffuse_iteration(ftte_ctx *c, int nnu, const double *kappa, int ndir, 
     if ((rc = ensure_kappa(c, nnu))) return rc;
     c->nnu = nnu;
     c->kappa_ready[0] = c->kappa_ready[1] = c->kappa_ready[2] = c->kappa_ready[3] = false;
+    ++c->n_kappa_sets;
     const size_t elems = (size_t)nnu * c->ncell;
     if ((rc = ensure(c, &c->host_J_dev, &c->host_J_cap, elems))) return rc;
     const HostPipe pipe{kappa, J};
     if ((rc = brick_sweep(c, ndir, phi, theta, w, uvb, c->host_J_dev, c->stream, &pipe))) {
         c->kappa_ready[0] = c->kappa_ready[1] = c->kappa_ready[2] = false;
+        ++c->n_kappa_sets;
         return rc;
     }
     return wait_sweep(c); // J is in the caller's array on return
@@ -848,6 +859,7 @@ int ftte_compute_opacities(ftte_ctx *c, int nnu, const double *beta)
     if (lrc) return fail(c, FTTE_ERR_NO_DEVICE, "ftte_compute_opacities: kernel launch failed");
     c->nnu = nnu;
     c->kappa_ready[0] = true; c->kappa_ready[1] = c->kappa_ready[2] = c->kappa_ready[3] = false;
+    ++c->n_kappa_sets;
     return FTTE_OK;
 }
 

@@ -246,7 +246,8 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
     const int cu = 64 * tu + lane + 1;
     const int cv0 = R * tv + 1;
     const int cuc = cu < n ? cu : n;
-    const unsigned off0 = 8u * (unsigned)(mirror_u ? n + 1 - cuc : cuc);
+    const bool tiled = L.tiled != 0; // brick-ordered kappa and J (BrickLaunch::tiled): the lane's place in its row of the brick
+    const unsigned off0 = tiled ? 8u * (unsigned)(mirror_u ? 63 - lane : lane) : 8u * (unsigned)(mirror_u ? n + 1 - cuc : cuc);
     const bool own_lane = cu <= n && (!MASKED || (lane >= lane_lo && lane <= lane_hi));
     const long row_bytes = 8l * sv;
     const int i0 = ti * chunk + 1;
@@ -324,7 +325,7 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
     // (row addresses are walked with scalar additions; the rows a ragged last brick lacks repeat its last row's address for loads
     // and are skipped by stores)
     const int nrows = n - cv0 + 1 < R ? n - cv0 + 1 : R;
-    const long row0 = cv0 * row_bytes;
+    const long row0 = tiled ? 8l * ((long)tu * G->bu + (long)tv * G->bv + (long)ti * G->bi) : cv0 * row_bytes;
     load_rows<R, false>(kap_next, kbase + 8l * i0 * si + row0, off0, row_bytes, nrows);
     for (int i = i0; i <= i1; ++i) {
         const int il = i - i0;
@@ -449,7 +450,8 @@ __global__ void __launch_bounds__(128, WAVES) brick_pair_kernel(const BrickLaunc
     const int cu = 64 * tu + lane + 1;
     const int cv0 = R * tv + H * wv + 1; // this wave's first row
     const int cuc = cu < n ? cu : n;
-    const unsigned off0 = 8u * (unsigned)(mirror_u ? n + 1 - cuc : cuc);
+    const bool tiled = L.tiled != 0;
+    const unsigned off0 = tiled ? 8u * (unsigned)(mirror_u ? 63 - lane : lane) : 8u * (unsigned)(mirror_u ? n + 1 - cuc : cuc);
     const bool own_lane = cu <= n;
     const long row_bytes = 8l * sv;
     const int i0 = ti * chunk + 1;
@@ -487,7 +489,7 @@ __global__ void __launch_bounds__(128, WAVES) brick_pair_kernel(const BrickLaunc
     double xs[EMIT ? H : 1] = {};
     // rows of this wave inside the grid (the upper wave of a ragged last brick may have none: it then reads row n throughout)
     const int nrows = n - cv0 + 1 < H ? (n - cv0 + 1 > 0 ? n - cv0 + 1 : 0) : H;
-    const long row0 = (cv0 < n ? cv0 : n) * row_bytes;
+    const long row0 = tiled ? 8l * ((long)tu * G->bu + (long)tv * G->bv + (long)ti * G->bi) + (long)(H * wv) * row_bytes : (cv0 < n ? cv0 : n) * row_bytes;
 #pragma unroll
     for (int r = 0; r < H; ++r) { kap[r] = 0.0; Jacc[r] = 0.0; }
     load_rows<H, false>(kap_next, kbase + 8l * i0 * si + row0, off0, row_bytes, nrows);

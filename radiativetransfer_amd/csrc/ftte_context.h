@@ -120,6 +120,12 @@ struct ftte_ctx {
     int nnu = 0;
     double *kappa[3] = {nullptr, nullptr, nullptr}; // layouts 0,1,2
     bool kappa_ready[4] = {false, false, false, false}; // [3]: the cell-major copy of the forest path
+    // the opacities once more in brick order (BrickLaunch::tiled), per axis order; valid while kappa_tiled_from is the count of
+    // opacity changes (n_kappa_sets) they were made at
+    double *kappa_tiled[3] = {nullptr, nullptr, nullptr};
+    long long kappa_tiled_from[3] = {-1, -1, -1}, n_kappa_sets = 0;
+    int kappa_tiled_chunk[3] = {0, 0, 0}; // layers per piece they were made with (tiled == 2), else 0
+    int tiled_opt = 0; // option "tiled" (measured: no gain)
     int amr_kappa_form = 0;  // what that copy holds: 0 every leaf in cell-array order, 1 the leaves of the hybrid plan's list
     size_t kappa_cap = 0; // elements per layout buffer
 

@@ -99,6 +99,8 @@ struct BrickGroup {
     int64_t org;         // as DirRec
     int32_t si, sv, su;
     int32_t ndir;
+    int32_t bu, bv;      // brick-ordered storage (BrickLaunch::tiled): elements from a brick to the next one along u, along v
+    int64_t bi;          // tiled == 2 (a whole brick in one piece): what a step to the next brick along the march adds beyond chunk * si
 };
 
 // ti: chunk index; bit 14 set (kBrickAccumulate): another group that shares this group's accumulator has been through this
@@ -136,6 +138,11 @@ struct BrickLaunch {
     const int32_t *deps;
     uint32_t epoch;
     int32_t pad_;
+    // kappa and the accumulators stored brick by brick: the eight rows of a brick's layer in one piece of 4 KB, the pieces of a
+    // layer in brick order (v, then u), layers as in the frame.  Whole bricks only (n a multiple of 64 and of kBrickRows).  The
+    // group's org, sv, bu, bv are then those of this order (tiled_index, ftte_kernels.hip); si is the same in both.  tiled == 2: the
+    // `chunk` layers of a brick follow each other as well (the whole brick in one piece of chunk x 4 KB; n a multiple of the chunk).
+    int32_t tiled, pad2_;
     ftte_consts math;
 };
 

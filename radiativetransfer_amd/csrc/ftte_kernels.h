@@ -17,10 +17,10 @@ int launch_brick(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stre
 int launch_brick_team(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stream);
 int launch_brick_pair(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stream); // two wavefronts per brick, four rows each
 // cell-array order -> layout 1 ([jc][ic][kc]) or 2 ([kc][ic][jc]); nnu groups, group_stride apart
-int launch_to_layout(int layout, const double *src, double *dst, int n, int nnu, long group_stride, hipStream_t stream);
+int launch_to_layout(int layout, const double *src, double *dst, int n, int nnu, long group_stride, hipStream_t stream, bool tiled = false, int tchunk = 0); // tiled: brick order (BrickLaunch::tiled), layout 0 too; tchunk: layers per piece
 // J (cell-array order) = acc[0] + acc[1] + ... in list order; layout[a] in {0,1,2}
 int launch_merge(const double *const *acc, const int *layout, int count, double *J, int n, int nnu, long group_stride,
-                 bool accumulate, hipStream_t stream, const int32_t *leaf_of_base = nullptr, long j_stride = 0);
+                 bool accumulate, hipStream_t stream, const int32_t *leaf_of_base = nullptr, long j_stride = 0, bool tiled = false, int tchunk = 0);
 // hybrid sweep of a refined cell array: leaf-ordered values -> values of the base cells; the rays leaving the forest's region
 int launch_base_cells(const double *leaf_values, const int32_t *leaf_of_base, double *base_values, long nbase, long ncell, int nnu,
                       hipStream_t stream);

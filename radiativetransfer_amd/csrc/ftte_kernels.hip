@@ -392,20 +392,37 @@ int launch_sweep(const LaunchRec &L, int rows, int waves, int stack, int nnu, hi
 // march axis is always the slowest and a sweep plane is always made of contiguous rows.
 // ------------------------------------------------------------------------------------------------
 
-// dst[jc][ic][kc] = src[ic][jc][kc]   (rows of n doubles move as they are)
+// Brick order (BrickLaunch::tiled): element (a, b, c) of a frame [a][b][c] -- a the march axis, c contiguous -- when the eight rows
+// b of a brick's layer are kept in one piece of 8 x 64 doubles, the pieces of a layer in the order of the bricks (along b, then
+// along c).  n a multiple of 64 (and so of kBrickRows).
+// chunk > 0: the `chunk` layers of a brick follow each other too (the brick in one piece; n a multiple of chunk).
+__device__ __forceinline__ long tiled_index(int n, int a, int b, int c, int chunk = 0)
+{
+    const long piece = 64 * kBrickRows, in_piece = (b % kBrickRows) * 64 + c % 64;
+    if (chunk > 0)
+        return ((((long)(a / chunk) * (n / kBrickRows) + b / kBrickRows) * (n / 64) + c / 64) * chunk + a % chunk) * piece + in_piece;
+    return (((long)a * (n / kBrickRows) + b / kBrickRows) * (n / 64) + c / 64) * piece + in_piece;
+}
+
+// dst[jc][ic][kc] = src[ic][jc][kc]   (rows of n doubles move as they are); layout 0: the rows stay where they are and only the
+// brick order (tiled) moves them
+template <bool tiled>
 __global__ void __launch_bounds__(256) to_layout1_kernel(const double *__restrict__ src, double *__restrict__ dst, int n,
-                                                         long group_stride)
+                                                         long group_stride, int layout, int tchunk)
 {
     const long g = blockIdx.z;
     const int ic = blockIdx.y / n, jc = blockIdx.y % n;
     const double *s = src + g * group_stride + ((long)ic * n + jc) * n;
-    double *d = dst + g * group_stride + ((long)jc * n + ic) * n;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) d[k] = s[k];
+    const int a = layout == 1 ? jc : ic, b = layout == 1 ? ic : jc;
+    double *d = dst + g * group_stride;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
+        d[tiled ? tiled_index(n, a, b, k, tchunk) : ((long)a * n + b) * n + k] = s[k];
 }
 
 // dst[kc][ic][jc] = src[ic][jc][kc]   (per ic plane, a 32x32 tiled transpose through LDS)
+template <bool tiled>
 __global__ void __launch_bounds__(256) to_layout2_kernel(const double *__restrict__ src, double *__restrict__ dst, int n,
-                                                         long group_stride)
+                                                         long group_stride, int tchunk)
 {
     __shared__ double tile[32][33];
     const long g = blockIdx.z / n;
@@ -413,22 +430,25 @@ __global__ void __launch_bounds__(256) to_layout2_kernel(const double *__restric
     const int j0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
     const double *s = src + g * group_stride + (long)ic * n * n;
-    double *d = dst + g * group_stride + (long)ic * n;
+    double *d = dst + g * group_stride;
     for (int r = ty; r < 32; r += 8)
         if (j0 + r < n && k0 + tx < n) tile[r][tx] = s[(long)(j0 + r) * n + k0 + tx];
     __syncthreads();
     for (int r = ty; r < 32; r += 8)
-        if (k0 + r < n && j0 + tx < n) d[(long)(k0 + r) * n * n + j0 + tx] = tile[tx][r];
+        if (k0 + r < n && j0 + tx < n) d[tiled ? tiled_index(n, k0 + r, ic, j0 + tx, tchunk) : ((long)(k0 + r) * n + ic) * n + j0 + tx] = tile[tx][r];
 }
 
-int launch_to_layout(int layout, const double *src, double *dst, int n, int nnu, long group_stride, hipStream_t stream)
+int launch_to_layout(int layout, const double *src, double *dst, int n, int nnu, long group_stride, hipStream_t stream, bool tiled, int tchunk)
 {
-    if (layout == 1) {
+    if (tiled && (n % 64 != 0 || n % kBrickRows != 0 || (tchunk > 0 && n % tchunk != 0))) return -1;
+    if (layout == 1 || (layout == 0 && tiled)) {
         const dim3 grid((n + 255) / 256, n * n, nnu);
-        hipLaunchKernelGGL(to_layout1_kernel, grid, dim3(256), 0, stream, src, dst, n, group_stride);
+        if (tiled) hipLaunchKernelGGL(to_layout1_kernel<true>, grid, dim3(256), 0, stream, src, dst, n, group_stride, layout, tchunk);
+        else hipLaunchKernelGGL(to_layout1_kernel<false>, grid, dim3(256), 0, stream, src, dst, n, group_stride, layout, tchunk);
     } else if (layout == 2) {
         const dim3 grid((n + 31) / 32, (n + 31) / 32, n * nnu);
-        hipLaunchKernelGGL(to_layout2_kernel, grid, dim3(256), 0, stream, src, dst, n, group_stride);
+        if (tiled) hipLaunchKernelGGL(to_layout2_kernel<true>, grid, dim3(256), 0, stream, src, dst, n, group_stride, tchunk);
+        else hipLaunchKernelGGL(to_layout2_kernel<false>, grid, dim3(256), 0, stream, src, dst, n, group_stride, tchunk);
     } else return -1;
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -444,8 +464,10 @@ struct MergeRec {
 // accumulate != 0: J += the accumulators (the additions continue the sequence of an earlier partial merge)
 // leaf_of_base != nullptr (hybrid sweep of a refined cell array): the accumulators are arrays over the BASE cells (group stride
 // n^3) and J is in cell-array order (group stride j_stride): element (ic, jc, kc) goes to its leaf, refined base cells are skipped.
+// tiled: the accumulators are in brick order (tiled_index)
+template <bool tiled>
 __global__ void __launch_bounds__(256) merge_kernel(const MergeRec M, double *__restrict__ J, int n, long group_stride, int accumulate,
-                                                    const int32_t *__restrict__ leaf_of_base, long j_stride)
+                                                    const int32_t *__restrict__ leaf_of_base, long j_stride, int tchunk)
 {
     __shared__ double tile[32][33];
     const long g = blockIdx.z / n;
@@ -468,7 +490,8 @@ __global__ void __launch_bounds__(256) merge_kernel(const MergeRec M, double *__
             __syncthreads();
             for (int q = 0; q < 4; ++q) {
                 const int r = ty + 8 * q; // kc offset
-                if (k0 + r < n && j0 + tx < n) tile[r][tx] = __builtin_nontemporal_load(&s[((long)(k0 + r) * n + ic) * n + j0 + tx]);
+                if (k0 + r < n && j0 + tx < n)
+                    tile[r][tx] = __builtin_nontemporal_load(&s[tiled ? tiled_index(n, k0 + r, ic, j0 + tx, tchunk) : ((long)(k0 + r) * n + ic) * n + j0 + tx]);
             }
             __syncthreads();
         }
@@ -477,8 +500,8 @@ __global__ void __launch_bounds__(256) merge_kernel(const MergeRec M, double *__
             const int jc = j0 + r, kc = k0 + tx;
             if (jc >= n || kc >= n) continue;
             double v;
-            if (M.layout[a] == 0) v = __builtin_nontemporal_load(&s[((long)ic * n + jc) * n + kc]);
-            else if (M.layout[a] == 1) v = __builtin_nontemporal_load(&s[((long)jc * n + ic) * n + kc]);
+            if (M.layout[a] == 0) v = __builtin_nontemporal_load(&s[tiled ? tiled_index(n, ic, jc, kc, tchunk) : ((long)ic * n + jc) * n + kc]);
+            else if (M.layout[a] == 1) v = __builtin_nontemporal_load(&s[tiled ? tiled_index(n, jc, ic, kc, tchunk) : ((long)jc * n + ic) * n + kc]);
             else v = tile[tx][r];
             sum[q] = have ? sum[q] + v : v;
         }
@@ -497,14 +520,15 @@ __global__ void __launch_bounds__(256) merge_kernel(const MergeRec M, double *__
 }
 
 int launch_merge(const double *const *acc, const int *layout, int count, double *J, int n, int nnu, long group_stride,
-                 bool accumulate, hipStream_t stream, const int32_t *leaf_of_base, long j_stride)
+                 bool accumulate, hipStream_t stream, const int32_t *leaf_of_base, long j_stride, bool tiled, int tchunk)
 {
     if (count > 3 * kMaxAcc) return -1;
     MergeRec M;
     M.count = count;
     for (int a = 0; a < count; ++a) { M.acc[a] = acc[a]; M.layout[a] = layout[a]; }
     const dim3 grid((n + 31) / 32, (n + 31) / 32, n * nnu);
-    hipLaunchKernelGGL(merge_kernel, grid, dim3(256), 0, stream, M, J, n, group_stride, accumulate ? 1 : 0, leaf_of_base, j_stride);
+    if (tiled) hipLaunchKernelGGL(merge_kernel<true>, grid, dim3(256), 0, stream, M, J, n, group_stride, accumulate ? 1 : 0, leaf_of_base, j_stride, tchunk);
+    else hipLaunchKernelGGL(merge_kernel<false>, grid, dim3(256), 0, stream, M, J, n, group_stride, accumulate ? 1 : 0, leaf_of_base, j_stride, tchunk);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

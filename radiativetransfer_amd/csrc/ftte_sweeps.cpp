@@ -10,6 +10,7 @@ int ensure_kappa(ftte_ctx *c, int nnu)
     if (c->kappa[0] && c->kappa_cap >= need) return FTTE_OK;
     for (int l = 0; l < 3; ++l) {
         if (c->kappa[l]) { FTTE_HIP(c, hipFree(c->kappa[l])); c->kappa[l] = nullptr; }
+        if (c->kappa_tiled[l]) { FTTE_HIP(c, hipFree(c->kappa_tiled[l])); c->kappa_tiled[l] = nullptr; }
         if (c->emis[l]) { FTTE_HIP(c, hipFree(c->emis[l])); c->emis[l] = nullptr; }
     }
     c->emit_mode = 0; // sized by the old number of groups: has to be set again
@@ -410,11 +411,27 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
     // other's sweeps anyway.)
     const bool lane_ends = pipe != nullptr;
     bool lane_layout[3] = {false, false, false};
+    // Brick order for the opacities and the accumulators (BrickLaunch::tiled, option "tiled"): a brick's layer is then one piece of
+    // 4 KB instead of eight rows of 512 B a row of the frame apart.  A kernel that does nothing but these loads and stores gets a
+    // third more out of the memory system that way (tools/membench.hip); the sweep gets nothing (31.66 against 31.67 ms), so the
+    // option is off by default.  For grids made of whole bricks, device-resident opacities, the forms of the kernel that know it;
+    // costs one more copy of the opacities per axis order.
+    const bool tiled = c->tiled_opt && !pipe && !c->emit_mode && n % 64 == 0 && n % kBrickRows == 0 && brick_form(c, nnu) != 1 &&
+                       (c->tiled_opt == 1 || n % P.chunk == 0);
+    const int tchunk = tiled && c->tiled_opt == 2 ? P.chunk : 0; // 2: a whole brick in one piece
     // accumulators and the opacity in the layouts the groups march through
     for (int l = 0; l < 3; ++l) {
         for (int s = 0; s < P.nacc[l]; ++s)
             if (!c->acc[l][s]) FTTE_HIP(c, hipMalloc((void **)&c->acc[l][s], sizeof(double) * c->acc_cap));
-        if (P.nacc[l] && !c->kappa_ready[l]) {
+        if (P.nacc[l] && tiled) {
+            if (c->kappa_tiled_from[l] != c->n_kappa_sets || c->kappa_tiled_chunk[l] != tchunk) {
+                if (!c->kappa_tiled[l]) FTTE_HIP(c, hipMalloc((void **)&c->kappa_tiled[l], sizeof(double) * c->kappa_cap));
+                if (launch_to_layout(l, c->kappa[0], c->kappa_tiled[l], n, nnu, (long)c->ncell, stream, true, tchunk))
+                    return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
+                c->kappa_tiled_from[l] = c->n_kappa_sets;
+                c->kappa_tiled_chunk[l] = tchunk;
+            }
+        } else if (P.nacc[l] && !c->kappa_ready[l]) {
             if (!c->kappa[l]) FTTE_HIP(c, hipMalloc((void **)&c->kappa[l], sizeof(double) * c->kappa_cap));
             if (!lane_ends) {
                 if (launch_to_layout(l, c->kappa[0], c->kappa[l], n, nnu, (long)c->ncell, stream))
@@ -452,10 +469,29 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
         for (size_t g = 0; g < P.groups.size(); ++g) {
             const BrickPlan::Group &H = P.groups[g];
             const DirPlan &D0 = P.dirs[H.dirs[0]];
-            G[g].kappa = c->kappa[H.layout];
+            G[g].kappa = tiled ? c->kappa_tiled[H.layout] : c->kappa[H.layout];
             G[g].emis = c->emit_mode ? c->emis[H.layout] : nullptr;
             G[g].J = c->acc[H.layout][H.acc];
             G[g].org = D0.org; G[g].si = D0.si; G[g].sv = D0.sv; G[g].su = D0.su;
+            if (tiled) { // cell (brick tu, tv; row r; lane; layer i) at org + i * si + tu * bu + tv * bv + r * sv + lane (63 - lane mirrored)
+                const int64_t ntu = n / 64, ntv = n / kBrickRows, piece = 64 * kBrickRows;
+                G[g].sv = D0.sv > 0 ? 64 : -64;
+                G[g].bu = (int32_t)(D0.su > 0 ? piece : -piece);
+                G[g].bv = (int32_t)(D0.sv > 0 ? ntu * piece : -ntu * piece);
+                G[g].org = (int64_t)(D0.si > 0 ? -1 : n) * n * n + (D0.sv > 0 ? 0 : (ntv - 1) * ntu * piece + (kBrickRows - 1) * 64) +
+                           (D0.su > 0 ? 0 : (ntu - 1) * piece);
+                if (tchunk) { // layer i = chunk * ti + il + 1 at org + i * si + ti * bi: si = +-piece inside the brick
+                    const int64_t nti = n / tchunk, brick = piece * tchunk;
+                    G[g].si = (int32_t)(D0.si > 0 ? piece : -piece);
+                    G[g].bu = (int32_t)(D0.su > 0 ? brick : -brick);
+                    G[g].bv = (int32_t)(D0.sv > 0 ? ntu * brick : -ntu * brick);
+                    const int64_t step_i = D0.si > 0 ? ntv * ntu * brick : -ntv * ntu * brick;
+                    G[g].bi = step_i - (int64_t)tchunk * G[g].si;
+                    // i = 1 (ti = 0, il = 0): the first layer of brick 0 (si > 0) or the last layer of the last brick (si < 0)
+                    G[g].org = (D0.si > 0 ? -piece : (nti - 1) * ntv * ntu * brick + (int64_t)tchunk * piece) +
+                               (D0.sv > 0 ? 0 : (ntv - 1) * ntu * brick + (kBrickRows - 1) * 64) + (D0.su > 0 ? 0 : (ntu - 1) * brick);
+                }
+            }
             G[g].ndir = (int)H.dirs.size();
             for (size_t q = 0; q < H.dirs.size(); ++q) {
                 const int d = H.dirs[q];
@@ -542,6 +578,7 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
             L.emit = c->emit_mode;
             L.ticket = c->d_bsync; L.error = c->d_bsync + 1; L.done = c->d_bdone; L.deps = c->d_bdeps; L.epoch = ++c->bepoch; L.pad_ = c->dataflow == 2 ? 1 : 0;
             L.math = kMath;
+            L.tiled = tiled ? 1 : 0;
             const int lrc = launch_brick(L, P.max_dirs, c->brick_waves, stream);
             if (lrc) return fail(c, lrc == -1 ? FTTE_ERR_ARG : FTTE_ERR_NO_DEVICE, "brick kernel launch failed");
             FTTE_HIP(c, hipMemcpyAsync(c->h_berror, c->d_bsync + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -585,6 +622,7 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
                 L.up = P.up; L.vp = P.vp; L.uw = P.uw; L.ut = P.ut; L.nslot = P.nslot;
                 L.emit = c->emit_mode;
                 L.math = kMath;
+                L.tiled = tiled ? 1 : 0;
                 const int form = brick_form(c, nnu);
                 c->last_brick_form = form;
                 const int lrc = form == 2 ? launch_brick_pair(L, P.max_dirs, c->pair_waves, q)
@@ -597,7 +635,7 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
                 int layouts[3 * kMaxAcc], count = 0;
                 for (int l = 0; l < 3; ++l)
                     for (int s2 = 0; s2 < P.nacc[l]; ++s2) { accs[count] = c->acc[l][s2] + slice0; layouts[count++] = l; }
-                if (launch_merge(accs, layouts, count, J_dev + slice0, n, nu1 - nu0, (long)c->ncell, false, q))
+                if (launch_merge(accs, layouts, count, J_dev + slice0, n, nu1 - nu0, (long)c->ncell, false, q, nullptr, 0, tiled, tchunk))
                     return fail(c, FTTE_ERR_NO_DEVICE, "merge kernel launch failed");
                 if (pipe && is_registered(c, pipe->J + slice0, slice_bytes))
                     FTTE_HIP(c, hipMemcpyAsync(pipe->J + slice0, J_dev + slice0, slice_bytes, hipMemcpyDeviceToHost, q));
@@ -616,6 +654,7 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
                 if ((rc = download_on(c, q, pipe->J + slice0, J_dev + slice0, slice_bytes))) return rc;
             }
             c->kappa_ready[0] = true; // every lane has brought its groups
+            ++c->n_kappa_sets;
         }
         if (lane_ends) {
             for (int l = 1; l < 3; ++l) if (lane_layout[l]) c->kappa_ready[l] = true; // ... and transposed them
@@ -631,7 +670,7 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
         for (int l = 0; l < 3; ++l)
             for (int s = 0; s < P.nacc[l]; ++s) { accs[count] = c->acc[l][s]; layouts[count++] = l; }
         if (count) {
-            if (launch_merge(accs, layouts, count, J_dev, n, nnu, (long)c->ncell, false, stream))
+            if (launch_merge(accs, layouts, count, J_dev, n, nnu, (long)c->ncell, false, stream, nullptr, 0, tiled, tchunk))
                 return fail(c, FTTE_ERR_NO_DEVICE, "merge kernel launch failed");
         } else FTTE_HIP(c, hipMemsetAsync(J_dev, 0, sizeof(double) * (size_t)nnu * c->ncell, stream)); // no directions
     }

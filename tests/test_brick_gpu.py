@@ -124,6 +124,45 @@ def test_one_wavefront_and_a_pair_per_brick_same_bits(engine):
         engine.set_option("engine", 0)
 
 
+@pytest.mark.parametrize("n", [64, 128])
+def test_brick_order_and_frame_order_same_bits(engine, n):
+    """On grids made of whole bricks the library can keep the opacities and the accumulators brick by brick (option tiled):
+    another place for every number, the same numbers.  All 24 izones (every combination of mirrored axes and axis orders) one by
+    one against the oracle, bit for bit; the full direction set with shared accumulators against the frame order, bit for bit, for
+    one wavefront per brick and for a pair, with one launch per stage and with one launch for the sweep."""
+    kappa, uvb, box = synthetic.uniform_workload(n, 3, seed=n, tau_median=0.25)
+    engine.set_option("engine", 2)
+    try:
+        engine.set_uniform_grid(n, box)
+        engine.set_opacity(kappa)
+        if n == 64:
+            for tiled in (1, 2):
+                engine.set_option("tiled", tiled)
+                for p, t in one_per_izone():
+                    phi, theta, w = np.array([p]), np.array([t]), np.array([0.37])
+                    J = engine.transport(phi, theta, w, uvb)
+                    assert np.array_equal(J, O.sweep_uniform(n, kappa, box, phi, theta, w, uvb, arith=O.ARITH_DEVICE)), (tiled, O.fold_direction(p, t)[2])
+        phi, theta, w = O.healpix_directions(2)
+        for form, dataflow in ((0, 0), (2, 0), (0, 2)):
+            engine.set_option("team", form)
+            engine.set_option("dataflow", dataflow)
+            J = {}
+            for tiled in (1, 2, 0):
+                engine.set_option("tiled", tiled)
+                J[tiled] = engine.transport(phi, theta, w, uvb)
+            assert np.array_equal(J[0], J[1]) and np.array_equal(J[0], J[2]), (form, dataflow)
+        # new opacities: the brick-ordered copies follow
+        engine.set_option("tiled", 1)
+        engine.set_opacity(2.0 * kappa)
+        J2 = engine.transport(phi, theta, w, uvb)
+        engine.set_option("tiled", 0)
+        assert np.array_equal(J2, engine.transport(phi, theta, w, uvb))
+        assert not np.array_equal(J2, J[1])
+    finally:
+        for key, value in (("tiled", 0), ("team", -1), ("dataflow", 0), ("engine", 0)):
+            engine.set_option(key, value)
+
+
 def test_form_of_the_brick_kernel_follows_the_frequency_groups(engine):
     """Left to itself (option team = -1) the library sweeps with a pair of wavefronts per brick up to four frequency groups, with
     one above, and with the pair whenever there is emission."""

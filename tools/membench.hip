@@ -56,8 +56,72 @@ template <int VEC> __global__ void __launch_bounds__(256) readonly(const double 
     if (s == 123.456) out[0] = s;
 }
 
+// The brick kernel's way of asking for the same bytes: one wavefront per workgroup takes a brick of 64 x 8 x `chunk` cells of an
+// (n+2)^3 frame and, layer after layer, loads its eight rows of k and of j (512 B each, a row of the frame apart), adds, and stores the
+// rows of j -- no arithmetic to speak of, no dependencies between bricks, `lds` bytes of dynamic LDS to set the residency.
+__global__ void __launch_bounds__(64) bricks(const double *__restrict__ k, double *__restrict__ j, int n, int chunk, int nnu, int rmw_j, int tiled)
+{
+    extern __shared__ double pad[];
+    const int ntu = n / 64, ntv = n / 8, nti = n / chunk;
+    long b = blockIdx.x;
+    const int nu = (int)(b % nnu); b /= nnu;
+    const int tu = (int)(b % ntu); b /= ntu;
+    const int tv = (int)(b % ntv); b /= ntv;
+    const int ti = (int)b;
+    if (ti >= nti) return;
+    // tiled 0: the frame as the library keeps it; 1: a brick's layer in one piece of 4 KB (rows 512 B apart), the layers a plane of
+    // such pieces apart; 2: the whole brick in one piece
+    long row = n + 2, plane = row * row, group = plane * row;
+    long base = nu * group + (long)(ti * chunk + 1) * plane + (long)(tv * 8 + 1) * row + tu * 64 + 1 + threadIdx.x;
+    if (tiled == 1) { row = 64; plane = (long)ntu * ntv * 512; base = nu * group + (long)(ti * chunk) * plane + ((long)tv * ntu + tu) * 512 + threadIdx.x; }
+    if (tiled == 2) { row = 64; plane = 512; base = nu * group + (((long)ti * ntv + tv) * ntu + tu) * 512l * chunk + threadIdx.x; }
+    double next[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) next[r] = k[base + r * row];
+    for (int i = 0; i < chunk; ++i) {
+        double kap[8], acc[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { kap[r] = next[r]; acc[r] = 0.0; }
+        if (rmw_j)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc[r] = __builtin_nontemporal_load(&j[base + i * plane + r * row]);
+        if (i + 1 < chunk)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) next[r] = k[base + (i + 1) * plane + r * row];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) __builtin_nontemporal_store(acc[r] + kap[r], &j[base + i * plane + r * row]);
+    }
+    if (pad[0] == 123.456) j[0] = 0;
+}
+
 int main()
 {
+    {
+        const int n = 256, nnu = 8;
+        const long cells = (long)(n + 2) * (n + 2) * (n + 2) * nnu;
+        double *k, *j;
+        CHECK(hipMalloc(&k, cells * 8)); CHECK(hipMalloc(&j, cells * 8));
+        CHECK(hipMemset(k, 0, cells * 8)); CHECK(hipMemset(j, 0, cells * 8));
+        hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+        float ms;
+        printf("-- brick pattern: 256^3 x 8 groups, one wavefront per 64 x 8 x chunk brick, all bricks in one launch\n");
+        for (int chunk : {16, 4})
+            for (int rmw_j : {0, 1})
+                for (int tiled : {0, 1, 2}) {
+                    const int lds = 8192;
+                    const unsigned grid = (unsigned)((n / 64) * (n / 8) * (n / chunk) * nnu);
+                    const double bytes = (double)n * n * n * nnu * (rmw_j ? 24.0 : 16.0);
+                    for (int rep = 0; rep < 3; ++rep) {
+                        CHECK(hipEventRecord(a));
+                        hipLaunchKernelGGL(bricks, dim3(grid), dim3(64), lds, 0, k, j, n, chunk, nnu, rmw_j, tiled);
+                        CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+                        CHECK(hipEventElapsedTime(&ms, a, b));
+                        if (rep == 2) printf("chunk %2d %s %-28s %7.3f ms  %6.0f GB/s\n", chunk, rmw_j ? "k,J->J" : "k->J  ", tiled == 0 ? "rows of the frame" : tiled == 1 ? "4 KB per brick and layer" : "the brick in one piece", ms, bytes / ms / 1e6);
+                    }
+                }
+        CHECK(hipFree(k)); CHECK(hipFree(j));
+    }
+
     const long n = 1l << 28; // 2 GiB of doubles per array
     double *k, *j;
     CHECK(hipMalloc(&k, n * 8)); CHECK(hipMalloc(&j, n * 8));
