@@ -412,10 +412,12 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
     }
 }
 
-// The same brick swept by a PAIR of wavefronts: wave 0 the brick's lower four rows, wave 1 the upper four, one (layer,
-// layer apart.  A ray that moves up out of row 3 waits in LDS for the wave above, which takes it one layer later: one
-// barrier per layer couples the two, and each wave holds half the rays, opacities and sums (so more of them fit a SIMD).
-// The arithmetic and the order of every cell's sum are those of brick_kernel.
+// The same brick swept by a PAIR of wavefronts: wave 0 the brick's lower four rows, wave 1 the upper four, one layer apart.
+// A ray that moves up out of row 3 waits in LDS for the wave above, which takes it one layer later: one barrier per layer
+// couples the two, and each wave holds half the rays, opacities and sums (78 VGPRs without emission, 103 with: six and four
+// workgroups' waves per SIMD).  The arithmetic and the order of every cell's sum are those of brick_kernel: same bits.
+// Twice the wavefronts per stage: ahead where the stages are narrow (up to four frequency groups on the GPU) and with emission
+// (brick_form, ftte_context.h).
 // grid: ntasks * nnu workgroups of 128 threads; dynamic LDS: 2 x (max_dirs - 1) x 2 KB of parked rays + 2 x max_dirs x 512 B of hand-over
 template <int WAVES, int EMIT>
 __global__ void __launch_bounds__(128, WAVES) brick_pair_kernel(const BrickLaunch L, int max_dirs)
