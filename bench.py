@@ -71,10 +71,11 @@ def parse():
     ap.add_argument("--brick-waves", type=int, default=0, help="bricks: waves per SIMD the kernel is compiled for")
     ap.add_argument("--tiled", type=int, default=-1, help="bricks: 1 opacities and accumulators stored brick by brick, 0 as frames (default)")
     ap.add_argument("--pair-waves", type=int, default=0, help="pair kernel (--team 2): workgroups per SIMD it is built for (2..4)")
-    ap.add_argument("--team", type=int, default=-1, help="bricks: 0 one wavefront per group (default), 1 one wavefront per direction, 2 two wavefronts per brick")
+    ap.add_argument("--team", type=int, default=-1, help="bricks: 0 one wavefront per brick, 2 two wavefronts per brick; default: by the number of frequency groups")
     ap.add_argument("--share", type=int, default=-1, help="bricks: accumulator sharing 0/1/2")
-    ap.add_argument("--dataflow", type=int, default=-1, help="bricks: 1 one launch with flags (default where the grid allows), 0 a launch per stage")
+    ap.add_argument("--dataflow", type=int, default=-1, help="bricks: 0 a launch per stage (default); 1, 2 one launch for the sweep, bricks wait on flags; 3 one persistent launch with a task queue per XCD")
     ap.add_argument("--lanes", type=int, default=0, help="bricks: streams the frequency groups are spread over")
+    ap.add_argument("--opt", action="append", default=[], help="any other library option, key=value (ftte_set_option)")
     ap.add_argument("--ldspad", type=int, default=0, help="diagnostic: extra dynamic LDS per workgroup (bytes), to cap residency")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks sharing GPU 0 with the collectives on host copies over gloo: exercises this script's multi-rank "
@@ -278,6 +279,9 @@ def main():
         eng.set_option("dataflow", a.dataflow)
     if a.ldspad:
         eng.set_option("ldspad", a.ldspad)
+    for kv in a.opt:
+        key, value = kv.split("=")
+        eng.set_option(key, int(value))
     stream = torch.cuda.current_stream().cuda_stream
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]

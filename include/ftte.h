@@ -50,7 +50,8 @@ typedef enum {
     FTTE_ERR_IZONE = -11,         /* rotateIndices called with izone outside 1..24                 */
     FTTE_ERR_PIXEL = -12,         /* equiSources.f90:2152-2160 'nside/ipix out of range'           */
     FTTE_ERR_RATES = -13,         /* equiSources.f90:3637-3654: a species fraction left [0, 1]     */
-    FTTE_ERR_MEMORY = -14         /* not enough device memory for the request (see message)         */
+    FTTE_ERR_MEMORY = -14,        /* not enough device memory for the request (see message)         */
+    FTTE_ERR_STALLED = -15        /* a one-launch sweep (option "dataflow") stopped making progress; its J is not valid */
 } ftte_status;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
@@ -302,7 +303,7 @@ int ftte_host_unregister(ftte_ctx *ctx, void *ptr);
  * planner), "forest_builds" (per-direction segment forests of a refined cell array); of the hybrid sweep's current plan, "hybrid_boxes"
  * (boxes around clusters of refined cells, of the izone that has most) and "hybrid_passes" (passes their forests are swept in), 0
  * when the last sweep did not take the hybrid path; "brick_form": the form of the brick kernel the last uniform-grid sweep of the
- * brick engine took (option "team": 0, 1, 2; -1 before the first).  -1 for an unknown name. */
+ * brick engine took (option "team": 0 or 2; -1 before the first).  -1 for an unknown name. */
 long long ftte_counter(const ftte_ctx *ctx, const char *name);
 
 /* Tuning knobs.  0 means "automatic" where noted.  Results do not depend on any of them except through the order in which the
@@ -314,11 +315,11 @@ long long ftte_counter(const ftte_ctx *ctx, const char *name);
  *     "share"       bricks: groups sharing a J accumulator: 0 none, 1 the passes of one izone, 2 and izone pairs (default)
  *     "lanes"       bricks: streams the frequency groups (or, with fewer groups than lanes, the direction groups) are spread over
  *     "brick_waves" bricks: waves per SIMD the kernel is compiled for, 2..4
- *     "dataflow"    bricks: 0 a launch per stage (default), 1 one launch whose bricks wait for each other, 2 the same with
- *                   write-through stores
+ *     "dataflow"    bricks: 0 a launch per stage, 1 one launch whose bricks wait for each other, 2 the same with
+ *                   write-through stores, 3 one launch of persistent workgroups with a task queue per XCD
  *     "tiled"       bricks: 1 = opacities and accumulators stored brick by brick (a brick's layer in one piece; grids of whole
  *                   bricks), 2 = the whole brick in one piece; same results, measured without gain; 0 = in frames (default)
- *     "team"        bricks: 0 = one wavefront per brick, 1 = one wavefront per direction of a group, 2 = two wavefronts per
+ *     "team"        bricks: 0 = one wavefront per brick, 2 = two wavefronts per
  *                   brick, four rows each ("pair_waves": workgroups per SIMD that form is compiled for, 2..4); -1 (default):
  *                   2 with up to four frequency groups on this GPU, else 0
  *     "rows", "stack", "slots", "waves"  tiles: rays per lane (4, 8, 16), wavefronts per workgroup (1, 2, 4, 8), directions in flight

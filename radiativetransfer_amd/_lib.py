@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(PKG, "libftte.so")
 STATUS = {
     0: "FTTE_OK", -1: "FTTE_ERR_ARG", -2: "FTTE_ERR_STATE", -3: "FTTE_ERR_NO_DEVICE", -4: "FTTE_ERR_UNSUPPORTED",
     -5: "FTTE_ERR_NOT_CUBIC", -6: "FTTE_ERR_LEVELS", -7: "FTTE_ERR_PHI", -8: "FTTE_ERR_THETA",
-    -9: "FTTE_ERR_DOMINANT_AXIS", -10: "FTTE_ERR_PATTERN", -11: "FTTE_ERR_IZONE", -12: "FTTE_ERR_PIXEL", -13: "FTTE_ERR_RATES", -14: "FTTE_ERR_MEMORY",
+    -9: "FTTE_ERR_DOMINANT_AXIS", -10: "FTTE_ERR_PATTERN", -11: "FTTE_ERR_IZONE", -12: "FTTE_ERR_PIXEL", -13: "FTTE_ERR_RATES", -14: "FTTE_ERR_MEMORY", -15: "FTTE_ERR_STALLED",
 }
 
 

@@ -74,6 +74,7 @@ int ftte_destroy(ftte_ctx *c)
     }
     if (c->d_bdeps) (void)hipFree(c->d_bdeps);
     if (c->d_bdone) (void)hipFree(c->d_bdone);
+    if (c->d_bqueue) (void)hipFree(c->d_bqueue);
     if (c->d_bsync) (void)hipFree(c->d_bsync);
     if (c->h_berror) (void)hipHostFree(c->h_berror);
     if (c->d_blayers) (void)hipFree(c->d_blayers);
@@ -318,14 +319,20 @@ int ftte_set_option(ftte_ctx *c, const char *key, int value)
         if (value < 1 || value > ftte_ctx::kMaxPipes) return fail(c, FTTE_ERR_ARG, "pipelines (independent bricks-forests-bricks sequences of the hybrid sweep, each on a stream of its own) must be 1..4");
         c->halves = value;
         c->hplan.valid = false;
+    } else if (!std::strcmp(key, "ablate")) {
+        if (value < 0 || value > 15) return fail(c, FTTE_ERR_ARG, "ablate is a mask of 4 bits");
+        c->ablate = value;
+    } else if (!std::strcmp(key, "queue_mix")) {
+        if (value < 0 || value > 2) return fail(c, FTTE_ERR_ARG, "queue_mix must be 0, 1 or 2");
+        c->queue_mix = value;
     } else if (!std::strcmp(key, "dataflow")) {
-        if (value < 0 || value > 2) return fail(c, FTTE_ERR_ARG, "dataflow must be 0 (a launch per stage), 1 (one launch, bricks wait for each other) or 2 (the same with write-through stores)");
+        if (value < 0 || value > 3) return fail(c, FTTE_ERR_ARG, "dataflow must be 0 (a launch per stage), 1 (one launch, bricks wait for each other), 2 (the same with write-through stores) or 3 (persistent workgroups, a task queue per XCD)");
         c->dataflow = value;
     } else if (!std::strcmp(key, "lanes")) {
         if (value < 1 || value > 16) return fail(c, FTTE_ERR_ARG, "lanes (streams the brick sweep spreads its frequency groups over) must be 1..16");
         c->lanes = value;
     } else if (!std::strcmp(key, "team")) {
-        if (value < -1 || value > 2) return fail(c, FTTE_ERR_ARG, "team must be -1 (by the number of frequency groups: 2 up to four, else 0), 0 (one wavefront sweeps a group's directions in turn), 1 (one wavefront per direction) or 2 (two wavefronts per brick, four rows each)");
+        if (value < -1 || value > 2 || value == 1) return fail(c, FTTE_ERR_ARG, "team must be -1 (by the number of frequency groups: 2 up to four, else 0), 0 (one wavefront sweeps a group's directions in turn) or 2 (two wavefronts per brick, four rows each); 1 (a wavefront per direction) lost everywhere and is gone");
         c->team = value;
     } else if (!std::strcmp(key, "tiled")) {
         if (value < 0 || value > 2) return fail(c, FTTE_ERR_ARG, "tiled must be 0 (default), 1 (bricks: opacities and accumulators stored brick by brick where the grid is made of whole bricks: a brick's layer in one piece) or 2 (the whole brick in one piece)");

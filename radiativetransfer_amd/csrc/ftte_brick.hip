@@ -81,6 +81,10 @@ __device__ __forceinline__ double shift_up_inject(double x, double in0)
     return __hiloint2double(hi, lo);
 }
 
+// A value another workgroup of THIS launch has stored: past the CU's vector L1, which no other CU's stores refresh (`sc1`: served
+// by the L2).
+__device__ __forceinline__ double fresh(gcbyte *p) { return __hip_atomic_load((gcdouble *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // One direction crosses one layer of the brick.  cur[r]: the ray entering cell (row r, this lane) through its bottom,
 // on return the ray leaving through its top.  uin/vin: where the rays handed over by the brick to the left / below wait
 // (nullptr: the domain boundary, the inflow enters there); uout/vout: where this brick's leaving rays go (nullptr: they
@@ -113,7 +117,7 @@ __device__ __forceinline__ void brick_step(const ftte_consts &K, double lead, do
         if (uin) { // one address for the whole wave
             if (same_launch) { // dataflow: written by a brick of this launch, so not through the scalar cache
 #pragma unroll
-                for (int r = 0; r < RW; ++r) ui[r] = *(gcdouble *)(uin + 8 * r);
+                for (int r = 0; r < RW; ++r) ui[r] = fresh(uin + 8 * r);
             } else { // written by an earlier launch: scalar loads, the values wait in scalar registers
                 const __attribute__((address_space(4))) double *us = (const __attribute__((address_space(4))) double *)(unsigned long)uin;
 #pragma unroll
@@ -121,7 +125,7 @@ __device__ __forceinline__ void brick_step(const ftte_consts &K, double lead, do
             }
         }
     }
-    if (HAS_V && vin) carry = *(gcdouble *)(vin + 8 * lane);
+    if (HAS_V && vin) carry = same_launch ? fresh(vin + 8 * lane) : *(gcdouble *)(vin + 8 * lane);
     if (HAS_V && carry_in) carry = carry_in[lane]; // pair kernel: the wavefront below left it in LDS
     const bool hands_u = HAS_U && uout != nullptr && lane == hand_lane;
 
@@ -197,7 +201,9 @@ __device__ __forceinline__ void brick_step(const ftte_consts &K, double lead, do
 // grid: ntasks * nnu workgroups of one wavefront; dynamic LDS: 4 KB per direction of the largest group
 // MASKED: the tasks sweep a range of lanes only (BrickTask::tu and ::group carry it): the bricks of the hybrid sweep that a box of
 // the segment forest cuts through; where the box's u-faces lie inside a brick, rays cross them through two face rings of their own.
-template <int WAVES, int EMIT, bool FLOW, bool MASKED = false>
+// FLOW: 0 a launch per stage; 1 one launch, a workgroup per brick, tickets from one counter (cross-XCD hand-overs: write-through
+// stores or an L2 write-back per brick); 2 one launch of persistent workgroups, a queue per XCD (BrickLaunch::queue).
+template <int WAVES, int EMIT, int FLOW, bool MASKED = false>
 __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
 {
     extern __shared__ double state[]; // [slot][row][lane]: the rays of the directions that are not in registers
@@ -207,15 +213,41 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
     const int nnu = L.nnu;
     const int lane = threadIdx.x;
     unsigned work = blockIdx.x;
-    if (FLOW) { // dataflow: tasks are taken in list order, whatever order the workgroups start in
+    int queue = 0;
+    unsigned long long waited = 0, began = 0; // polls this workgroup spent waiting; when it started (instrumentation)
+    if (FLOW == 2) began = (unsigned long long)wall_clock64();
+    if (FLOW == 2) { // which XCD is this?  Its queue holds the bricks whose inputs are written behind this XCD's L2
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        queue = L.xcc_queue[xcc & 15u];
+        if (queue < 0) return;
+    }
+  do {
+    if (FLOW == 1) { // dataflow: tasks are taken in list order, whatever order the workgroups start in
         unsigned t = 0;
         if (lane == 0) t = atomicAdd(L.ticket, 1u);
         work = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
         if (work >= (unsigned)L.ntasks * (unsigned)nnu) return;
     }
+    if (FLOW == 2) {
+        unsigned t = 0;
+        if (lane == 0) t = atomicAdd(L.ticket + 32 * queue, 1u);
+        t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+        if (t >= L.qlen[queue]) { // the queue is empty; what this workgroup leaves behind is instrumentation (ftte_counter, FTTE_QUEUE_STATS)
+            if (lane == 0) {
+                uint32_t *stats = L.ticket + 32 * queue;
+                atomicMax((unsigned long long *)(stats + 2), (unsigned long long)wall_clock64());
+                atomicAdd((unsigned long long *)(stats + 4), waited);
+                atomicAdd(stats + 6, 1u);
+                atomicMax((unsigned long long *)(L.error + 2), ~began);
+            }
+            return;
+        }
+        work = L.queue[L.qoff[queue] + t];
+    }
     // dataflow with write-through stores (sc1: the line goes to memory and leaves this XCD's L2) instead of an L2 write-back
     // before the flag
-    const bool through = FLOW && L.pad_ != 0;
+    const bool through = FLOW == 1 && L.pad_ != 0;
     const int nu = L.nu0 + (int)(work % (unsigned)nnu);
     const unsigned task_index = work / (unsigned)nnu;
     const BrickTask T = L.tasks[task_index];
@@ -227,7 +259,7 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
     const int tv_field = uniform((int)T.tv);
     const int tv = MASKED ? tv_field & kBrickTvMask : tv_field, box = MASKED ? (tv_field >> kBrickBoxShift) & kBrickBoxMask : 0;
     const int ti = uniform((int)T.ti) & (kBrickAccumulate - 1);
-    const bool accumulate = (uniform((int)T.ti) & kBrickAccumulate) != 0;
+    const bool accumulate = (uniform((int)T.ti) & kBrickAccumulate) != 0 && !(L.pad2_ & 4);
     cgroup *G = (cgroup *)(L.groups + (MASKED ? group_field & kBrickGroupMask : group_field));
     const int n = L.n, chunk = L.chunk, up = L.up, vp = L.vp;
     const int ndir = G->ndir;
@@ -253,9 +285,12 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
     const int i0 = ti * chunk + 1;
     const int i1 = (i0 + chunk - 1 < n) ? i0 + chunk - 1 : n;
 
-    const bool has_u_in = tu > 0 || lane_lo > 0, has_u_out = 64 * (tu + 1) < n || lane_hi < 63;
-    const bool has_v_in = tv > 0, has_v_out = R * (tv + 1) < n;
-    const bool has_i_in = ti > 0, has_i_out = i1 < n;
+    // (pad2_: diagnostic option "ablate" -- WRONG RESULTS, timing only: bit 0 no rays taken from the left and from below, bit 1 none
+    // handed to the right and above, bit 2 no earlier J read, bit 3 no rays taken from or left for the chunks before and after)
+    const int ablate = L.pad2_;
+    const bool has_u_in = (tu > 0 || lane_lo > 0) && !(ablate & 1), has_u_out = (64 * (tu + 1) < n || lane_hi < 63) && !(ablate & 2);
+    const bool has_v_in = tv > 0 && !(ablate & 1), has_v_out = R * (tv + 1) < n && !(ablate & 2);
+    const bool has_i_in = ti > 0 && !(ablate & 8), has_i_out = i1 < n && !(ablate & 8);
     const long fnu = (long)nu * L.face_stride;
     // element offsets inside a direction's face block (ftte_internal.h)
     const int uw = L.uw, ut = L.ut;
@@ -277,16 +312,32 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
         const int32_t *dep = L.deps + (size_t)task_index * kBrickDeps;
         const unsigned slot = (unsigned)(nu - L.nu0);
         bool failed = false;
-        for (int q = 0; q < kBrickDeps && !failed; ++q) {
+        // (the bound is on time WITHOUT PROGRESS: every 1024 polls the wavefront looks at the ticket counter it draws from, and
+        // starts counting again when that has moved -- somebody has finished a brick meanwhile)
+        const uint32_t *progress = FLOW == 2 ? L.ticket + 32 * queue : L.ticket;
+        unsigned seen = 0;
+        // lane q looks at dependency q: one round trip for all six while they are done, which is the rule
+        bool all_done;
+        {
+            const int32_t dq = lane < kBrickDeps ? dep[lane] : -1;
+            const bool ok = dq < 0 || __hip_atomic_load(L.done + (size_t)(dq < 0 ? 0 : dq) * nnu + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == L.epoch;
+            all_done = __builtin_amdgcn_ballot_w64(!ok) == 0;
+        }
+        for (int q = 0; q < kBrickDeps && !failed && !all_done; ++q) {
             const int32_t dq = uniform(dep[q]);
             if (dq < 0) continue;
             const uint32_t *flag = L.done + (size_t)dq * nnu + slot;
             unsigned spins = 0;
             while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != L.epoch) {
                 __builtin_amdgcn_s_sleep(20);
-                if ((++spins & 1023u) == 0 && (spins >= (1u << 21) || __hip_atomic_load(L.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-                    failed = true;
-                    break;
+                ++waited;
+                if ((++spins & 1023u) == 0) {
+                    const unsigned now = __hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (now != seen) { seen = now; spins = 0; }
+                    if (spins >= (1u << 20) || __hip_atomic_load(L.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                        failed = true;
+                        break;
+                    }
                 }
             }
         }
@@ -294,8 +345,11 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
             if (lane == 0) __hip_atomic_store(L.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (FLOW == 1) { // hand-overs from any XCD: this CU's L1 is emptied, the loads that follow are plain
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        // (FLOW == 2: every load of handed-over bytes below goes past the L1 -- `fresh`, and the non-temporal loads of J)
     }
 
     // The rays of one direction are in registers (`cur`), those of the group's other directions wait in LDS: ndir - 1 slots of
@@ -310,14 +364,14 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
     {
         gcdouble *f = (gcdouble *)(G->dir[p0].faces + fnu);
 #pragma unroll
-        for (int r = 0; r < R; ++r) cur[r] = has_i_in ? f[i_in + (long)r * up] : uvb;
+        for (int r = 0; r < R; ++r) cur[r] = !has_i_in ? uvb : FLOW == 2 ? fresh((gcbyte *)&f[i_in + (long)r * up]) : f[i_in + (long)r * up];
     }
     for (int k = 0; k + 1 < ndir; ++k) {
         int d = p0 + 1 + k;
         d = d >= ndir ? d - ndir : d;
         gcdouble *f = (gcdouble *)(G->dir[d].faces + fnu);
 #pragma unroll
-        for (int r = 0; r < R; ++r) state[(k * R + r) * 64 + lane] = has_i_in ? f[i_in + (long)r * up] : uvb;
+        for (int r = 0; r < R; ++r) state[(k * R + r) * 64 + lane] = !has_i_in ? uvb : FLOW == 2 ? fresh((gcbyte *)&f[i_in + (long)r * up]) : f[i_in + (long)r * up];
     }
 
     // the opacity of the brick's cells, one layer ahead of the layer being crossed
@@ -358,15 +412,15 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
             gbyte *vout = has_v_out ? f + 8 * (v_out + (long)il * up) : nullptr;
             const bool third_first = rc == RC_THREE_U_SWAP || rc == RC_THREE_V_SWAP;
             switch (rc) {
-            case RC_ONE: brick_step<RC_ONE, EMIT>(L.math, lead, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW, lane_lo, lane_hi, !MASKED || own_lane); break;
-            case RC_TWO_U: brick_step<RC_TWO_U, EMIT>(L.math, lead, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW, lane_lo, lane_hi, !MASKED || own_lane); break;
-            case RC_TWO_V: brick_step<RC_TWO_V, EMIT>(L.math, lead, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW, lane_lo, lane_hi, !MASKED || own_lane); break;
+            case RC_ONE: brick_step<RC_ONE, EMIT>(L.math, lead, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW != 0, lane_lo, lane_hi, !MASKED || own_lane); break;
+            case RC_TWO_U: brick_step<RC_TWO_U, EMIT>(L.math, lead, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW != 0, lane_lo, lane_hi, !MASKED || own_lane); break;
+            case RC_TWO_V: brick_step<RC_TWO_V, EMIT>(L.math, lead, cur, kap, xs, Jacc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW != 0, lane_lo, lane_hi, !MASKED || own_lane); break;
             case RC_THREE_U:
             case RC_THREE_U_SWAP:
-                brick_step<RC_THREE_U, EMIT>(L.math, lead, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW, lane_lo, lane_hi, !MASKED || own_lane);
+                brick_step<RC_THREE_U, EMIT>(L.math, lead, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW != 0, lane_lo, lane_hi, !MASKED || own_lane);
                 break;
             default:
-                brick_step<RC_THREE_V, EMIT>(L.math, lead, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW, lane_lo, lane_hi, !MASKED || own_lane);
+                brick_step<RC_THREE_V, EMIT>(L.math, lead, cur, kap, xs, Jacc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane, through, FLOW != 0, lane_lo, lane_hi, !MASKED || own_lane);
                 break;
             }
         }
@@ -401,15 +455,20 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
         }
     }
     if (FLOW) {
-        // publish: every store of this wavefront drained, the XCD's L2 written back, then the flag
+        // publish: every store of this wavefront drained (FLOW == 2: they are in this XCD's L2, where every reader of them looks),
+        // FLOW == 1 without write-through stores: the XCD's L2 written back; then the flag
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!through) {
+        if (FLOW == 1 && !through) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        if (lane == 0)
-            __hip_atomic_store(L.done + (size_t)task_index * nnu + (unsigned)(nu - L.nu0), L.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) {
+            uint32_t *flag = L.done + (size_t)task_index * nnu + (unsigned)(nu - L.nu0);
+            if (FLOW == 2) *(volatile uint32_t *)flag = L.epoch; // a plain store: the line stays in this L2 for the pollers
+            else __hip_atomic_store(flag, L.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
+  } while (FLOW == 2);
 }
 
 // The same brick swept by a PAIR of wavefronts: wave 0 the brick's lower four rows, wave 1 the upper four, one layer apart.
@@ -570,163 +629,17 @@ __global__ void __launch_bounds__(128, WAVES) brick_pair_kernel(const BrickLaunc
     }
 }
 
-// The same brick swept by a TEAM: one wavefront per direction of the group, all in one workgroup.  Each wave keeps its
-// direction's rays in registers for the whole chunk (no state in LDS, one code path), crosses the layer with brick_step,
-// and leaves its cells' contributions in LDS; after one barrier per layer the waves add the contributions up in direction
-// order -- wave d the rows d, d + ndir, ... -- and store the rows of J.  The barrier only couples the waves of a
-// team; the other teams resident on the CU fill the gaps.
-// grid: ntasks * nnu workgroups of 64 * (largest group) threads; dynamic LDS: 2 x 4 KB per wavefront (double buffered)
-template <int WAVES>
-__global__ void __launch_bounds__(64 * kBrickMaxDirs, WAVES) brick_team_kernel(const BrickLaunch L)
+// Which XCC ids does this device have?  Every workgroup of a grid large enough to reach every XCD reports the id it reads.
+__global__ void xcc_census_kernel(unsigned *mask)
 {
-    extern __shared__ double contrib[]; // [parity][direction][row][lane]
-    constexpr int R = kBrickRows;
-    using cgroup = const __attribute__((address_space(4))) BrickGroup;
-    using clayer = const __attribute__((address_space(4))) LayerRec;
-    const int nnu = L.nnu;
-    const int nu = L.nu0 + blockIdx.x % nnu;
-    const BrickTask T = L.tasks[blockIdx.x / nnu];
-    const int tu = uniform((int)T.tu), tv = uniform((int)T.tv), ti = uniform((int)T.ti) & (kBrickAccumulate - 1);
-    const bool accumulate = (uniform((int)T.ti) & kBrickAccumulate) != 0;
-    cgroup *G = (cgroup *)(L.groups + uniform((int)T.group));
-    const int lane = threadIdx.x & 63;
-    const int d = uniform((int)(threadIdx.x >> 6));
-    const int ndir = G->ndir;
-    if (d >= ndir) return; // a smaller group in a launch sized for the largest: the barrier counts live waves only
-    const int n = L.n, chunk = L.chunk, up = L.up, vp = L.vp;
-    const double uvb = L.uvb[nu];
-    double lead = L.math.c[9]; // the exponential's leading coefficient, in a vector register for the whole run (ftte_math.h)
-    asm volatile("" : "+v"(lead));
-
-    const int sv = G->sv, si = G->si;
-    const bool mirror_u = G->su < 0;
-    const long org = G->org;
-    gcbyte *kbase = (gcbyte *)(G->kappa + (long)nu * L.group_stride + org);
-    gbyte *jbase = (gbyte *)(G->J + (long)nu * L.group_stride + org);
-
-    const int cu = 64 * tu + lane + 1;
-    const int cv0 = R * tv + 1;
-    const int cuc = cu < n ? cu : n;
-    const unsigned off0 = 8u * (unsigned)(mirror_u ? n + 1 - cuc : cuc);
-    const bool own_lane = cu <= n;
-    const long row_bytes = 8l * sv;
-    const int i0 = ti * chunk + 1;
-    const int i1 = (i0 + chunk - 1 < n) ? i0 + chunk - 1 : n;
-
-    const bool has_u_in = tu > 0, has_u_out = 64 * (tu + 1) < n;
-    const bool has_v_in = tv > 0, has_v_out = R * (tv + 1) < n;
-    const bool has_i_in = ti > 0, has_i_out = i1 < n;
-    gbyte *f = (gbyte *)(G->dir[d].faces + (long)nu * L.face_stride);
-    clayer *layers = (clayer *)(G->dir[d].layers);
-    const double w = G->dir[d].w;
-    const int uw = L.uw, ut = L.ut;
-    const int ns = L.nslot, sl = ti % ns;
-    const long u_out = ((long)(tu * ns + sl) * chunk) * uw + ut * tv;
-    const long u_in = ((long)((tu - 1) * ns + sl) * chunk) * uw + ut * tv;
-    const long v_out = L.vface_off + ((long)(tv * ns + sl) * chunk) * up + 64 * tu;
-    const long v_in = L.vface_off + ((long)((tv - 1) * ns + sl) * chunk) * up + 64 * tu;
-    const long i_in = L.iface_off + ((long)sl * vp + R * tv) * up + 64 * tu + lane;
-    const long i_out = L.iface_off + ((long)((ti + 1) % ns) * vp + R * tv) * up + 64 * tu + lane;
-
-    // this direction's rays entering the brick's bottom: the inflow, or what the chunk below left
-    double cur[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) cur[r] = has_i_in ? ((gcdouble *)f)[i_in + (long)r * up] : uvb;
-
-    double kap_next[R];
-    {
-        gcbyte *kplane = kbase + 8l * i0 * si;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int row = (cv0 + r < n) ? cv0 + r : n;
-            kap_next[r] = *(gcdouble *)(kplane + row * row_bytes + off0);
-        }
-    }
-    for (int i = i0; i <= i1; ++i) {
-        const int il = i - i0;
-        double kap[R], Jc[R], Jprev[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) { kap[r] = kap_next[r]; Jc[r] = 0.0; Jprev[r] = 0.0; }
-        gbyte *jplane = jbase + 8l * i * si;
-        if (accumulate && own_lane) { // the rows this wave will add up: what the groups before this one left there
-#pragma unroll
-            for (int k = 0; k < R; ++k) {
-                const int r = d + k * ndir;
-                if (r < R && cv0 + r <= n) Jprev[k] = __builtin_nontemporal_load((gcdouble *)(jplane + (cv0 + r) * row_bytes + off0));
-            }
-        }
-        if (i < i1) {
-            gcbyte *kplane = kbase + 8l * (i + 1) * si;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int row = (cv0 + r < n) ? cv0 + r : n;
-                kap_next[r] = *(gcdouble *)(kplane + row * row_bytes + off0);
-            }
-        }
-        clayer *rp = layers + (i - 1);
-        const double d0 = rp->dpath[0], d1 = rp->dpath[1], d2 = rp->dpath[2];
-        const int rc = rp->info & 7;
-        gcbyte *uin = has_u_in ? (gcbyte *)f + 8 * (u_in + (long)il * uw) : nullptr;
-        gbyte *uout = has_u_out ? f + 8 * (u_out + (long)il * uw) : nullptr;
-        gcbyte *vin = has_v_in ? (gcbyte *)f + 8 * (v_in + (long)il * up) : nullptr;
-        gbyte *vout = has_v_out ? f + 8 * (v_out + (long)il * up) : nullptr;
-        const bool third_first = rc == RC_THREE_U_SWAP || rc == RC_THREE_V_SWAP;
-        const double no_xs[1] = {0.0};
-        switch (rc) {
-        case RC_ONE: brick_step<RC_ONE, 0>(L.math, lead, cur, kap, no_xs, Jc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane); break;
-        case RC_TWO_U: brick_step<RC_TWO_U, 0>(L.math, lead, cur, kap, no_xs, Jc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane); break;
-        case RC_TWO_V: brick_step<RC_TWO_V, 0>(L.math, lead, cur, kap, no_xs, Jc, false, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane); break;
-        case RC_THREE_U:
-        case RC_THREE_U_SWAP:
-            brick_step<RC_THREE_U, 0>(L.math, lead, cur, kap, no_xs, Jc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane);
-            break;
-        default:
-            brick_step<RC_THREE_V, 0>(L.math, lead, cur, kap, no_xs, Jc, third_first, d0, d1, d2, w, uvb, uin, uout, vin, vout, lane);
-            break;
-        }
-        if (ndir == 1) { // nobody to add up with
-            if (own_lane) {
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-                    if (cv0 + r <= n)
-                        __builtin_nontemporal_store(accumulate ? Jprev[r] + Jc[r] : Jc[r], (gdouble *)(jplane + (cv0 + r) * row_bytes + off0));
-            }
-            continue;
-        }
-        double *buf = contrib + (size_t)(i & 1) * ((blockDim.x >> 6) * R * 64);
-#pragma unroll
-        for (int r = 0; r < R; ++r) buf[(d * R + r) * 64 + lane] = Jc[r];
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const int r = d + k * ndir;
-            if (r >= R) break;
-            double sum = buf[r * 64 + lane]; // direction 0
-            if (accumulate) sum = Jprev[k] + sum;
-            for (int q = 1; q < ndir; ++q) sum += buf[(q * R + r) * 64 + lane];
-            if (own_lane && cv0 + r <= n) __builtin_nontemporal_store(sum, (gdouble *)(jplane + (cv0 + r) * row_bytes + off0));
-        }
-    }
-
-    if (has_i_out) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) ((gdouble *)f)[i_out + (long)r * up] = cur[r];
-    }
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (threadIdx.x == 0) atomicOr(mask, 1u << (xcc & 15u));
 }
 
-int launch_brick_team(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stream)
+int launch_xcc_census(unsigned *mask_dev, hipStream_t stream)
 {
-    if (L.ntasks <= 0) return 0;
-    if (max_dirs < 1 || max_dirs > kBrickMaxDirs) return -1;
-    const dim3 grid((unsigned)L.ntasks * (unsigned)L.nnu);
-    const dim3 block(64u * (unsigned)max_dirs);
-    const size_t lds = max_dirs > 1 ? (size_t)2 * max_dirs * kBrickRows * 64 * sizeof(double) : 0;
-    switch (waves) {
-    case 2: hipLaunchKernelGGL((brick_team_kernel<2>), grid, block, lds, stream, L); break;
-    case 3: hipLaunchKernelGGL((brick_team_kernel<3>), grid, block, lds, stream, L); break;
-    case 4: hipLaunchKernelGGL((brick_team_kernel<4>), grid, block, lds, stream, L); break;
-    default: return -1;
-    }
+    hipLaunchKernelGGL(xcc_census_kernel, dim3(4096), dim3(64), 0, stream, mask_dev);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -749,32 +662,38 @@ int launch_brick_pair(const BrickLaunch &L, int max_dirs, int waves, hipStream_t
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-int launch_brick(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stream, bool masked)
+int launch_brick(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stream, bool masked, int persistent)
 {
     if (L.ntasks <= 0) return 0;
     if (max_dirs < 1 || max_dirs > kBrickMaxDirs) return -1;
+    if (L.tiled && (L.emit || masked)) return -1; // brick-ordered storage: the emission rows and the cut bricks are addressed in frame order only
     const dim3 grid((unsigned)L.ntasks * (unsigned)L.nnu);
     const size_t lds = (size_t)(max_dirs - 1) * kBrickRows * 64 * sizeof(double) + (size_t)lds_pad(); // pad: diagnostic knob "ldspad"
     const bool flow = L.ticket != nullptr;
+    if (L.queue) { // persistent form: `persistent` workgroups, what the GPU holds at once (more are harmless: they find the queues empty)
+        if (masked || L.emit || !flow || persistent < 1) return -1;
+        hipLaunchKernelGGL((brick_kernel<4, 0, 2>), dim3((unsigned)persistent), dim3(64), lds, stream, L);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     if (masked && !flow && L.emit) { // (the emission forms hold 162 registers with the lane range, as without it: three waves per SIMD)
-        if (L.emit == 1) hipLaunchKernelGGL((brick_kernel<2, 1, false, true>), grid, dim3(64), lds, stream, L);
-        else hipLaunchKernelGGL((brick_kernel<2, 2, false, true>), grid, dim3(64), lds, stream, L);
+        if (L.emit == 1) hipLaunchKernelGGL((brick_kernel<2, 1, 0, true>), grid, dim3(64), lds, stream, L);
+        else hipLaunchKernelGGL((brick_kernel<2, 2, 0, true>), grid, dim3(64), lds, stream, L);
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
     if (masked) {
         if (flow) return -1; // the hybrid sweep issues a launch per stage
-        hipLaunchKernelGGL((brick_kernel<3, 0, false, true>), grid, dim3(64), lds, stream, L); // (126 registers since the trimming: four waves per SIMD in fact)
+        hipLaunchKernelGGL((brick_kernel<3, 0, 0, true>), grid, dim3(64), lds, stream, L); // (126 registers since the trimming: four waves per SIMD in fact)
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
     // emission: the log-mean's own division and polynomials need more registers than three waves per SIMD leave
-    if (L.emit == 1 && !flow) hipLaunchKernelGGL((brick_kernel<3, 1, false>), grid, dim3(64), lds, stream, L);
-    else if (L.emit == 2 && !flow) hipLaunchKernelGGL((brick_kernel<3, 2, false>), grid, dim3(64), lds, stream, L);
+    if (L.emit == 1 && !flow) hipLaunchKernelGGL((brick_kernel<3, 1, 0>), grid, dim3(64), lds, stream, L);
+    else if (L.emit == 2 && !flow) hipLaunchKernelGGL((brick_kernel<3, 2, 0>), grid, dim3(64), lds, stream, L);
     else if (L.emit) return -1; // the dataflow form is built without emission
-    else if (flow) hipLaunchKernelGGL((brick_kernel<4, 0, true>), grid, dim3(64), lds, stream, L);
+    else if (flow) hipLaunchKernelGGL((brick_kernel<4, 0, 1>), grid, dim3(64), lds, stream, L);
     else switch (waves) {
-    case 2: hipLaunchKernelGGL((brick_kernel<2, 0, false>), grid, dim3(64), lds, stream, L); break;
-    case 3: hipLaunchKernelGGL((brick_kernel<3, 0, false>), grid, dim3(64), lds, stream, L); break;
-    case 4: hipLaunchKernelGGL((brick_kernel<4, 0, false>), grid, dim3(64), lds, stream, L); break;
+    case 2: hipLaunchKernelGGL((brick_kernel<2, 0, 0>), grid, dim3(64), lds, stream, L); break;
+    case 3: hipLaunchKernelGGL((brick_kernel<3, 0, 0>), grid, dim3(64), lds, stream, L); break;
+    case 4: hipLaunchKernelGGL((brick_kernel<4, 0, 0>), grid, dim3(64), lds, stream, L); break;
     default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;

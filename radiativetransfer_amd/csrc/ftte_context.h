@@ -81,6 +81,12 @@ struct BrickPlan {
     std::vector<BrickTask> tasks;      // stage after stage
     bool dataflow = false;             // one launch, bricks wait for each other through flags (needs whole bricks: n % 64 == 0)
     std::vector<int32_t> deps;         // [tasks][kBrickDeps]
+    // persistent form (option "dataflow" = 3): one queue of (task, frequency slot) pairs per XCD, whole dependency chains each
+    bool persistent = false;
+    int qnnu = 0, nq = 0, qmix = 0;    // frequency groups and XCDs the queues were cut for, option "queue_mix"
+    std::vector<uint32_t> queue;       // work ids task * nnu + slot, queue after queue
+    uint32_t qoff[kBrickQueues] = {}, qlen[kBrickQueues] = {};
+    int64_t qload[kBrickQueues] = {};  // cell.direction.frequency updates per queue (balance: instrumentation)
     int ut = kBrickRows, uw = 0;       // u-face ring: doubles per brick and layer, per layer
     int64_t uqface_off = 0;            // BrickLaunch::uqface_off
     int nslot = 2;                     // face slots along the march (BrickLaunch::nslot)
@@ -147,13 +153,20 @@ struct ftte_ctx {
     bool stage_used[2] = {false, false};    // the pinned staging block has a transfer recorded on stage_ev
     std::vector<hipEvent_t> lane_done;
     hipEvent_t ev_fork = nullptr;
-    // option: 0 = a launch per stage (default); 1, 2 = the bricks of a sweep in ONE launch where the grid allows it, waiting for each
-    // other through flags (measured: no faster -- the stage boundaries are not what limits the sweep, DESIGN.md -- so not the default)
+    // option: 0 = a launch per stage; 1, 2 = the bricks of a sweep in ONE launch where the grid allows it, a workgroup per brick,
+    // waiting for each other through flags (cross-XCD hand-overs: L2 write-back per brick, or write-through stores); 3 = one launch of
+    // persistent workgroups that draw bricks from a queue per XCD (hand-overs stay behind one L2: plain stores)
     int dataflow = 0;
+    int ablate = 0;                   // diagnostic option "ablate": parts of the brick kernel's memory traffic left out (wrong J; timing only)
+    int queue_mix = 0;                // persistent form: 0 = a frequency group per queue where they divide, else by load; 1 = by load; 2 = (group + accumulator) mod queues
     int32_t *d_bdeps = nullptr; size_t d_bdeps_cap = 0;
     uint32_t *d_bdone = nullptr; size_t d_bdone_cap = 0;
-    uint32_t *d_bsync = nullptr;      // [0] ticket, [1] error
-    uint32_t *h_berror = nullptr;     // pinned: the error flag of the last dataflow sweep, copied back behind it
+    uint32_t *d_bsync = nullptr;      // [32 q] ticket of queue q (one counter, [0], without queues), [32 kBrickQueues] error
+    uint32_t *h_berror = nullptr;     // pinned: [0] the error flag of the last dataflow sweep, [1 + q] its tickets, copied back behind it
+    uint32_t bqlen[kBrickQueues] = {}; // what those tickets must have reached (0: no persistent sweep pending)
+    uint32_t *d_bqueue = nullptr; size_t d_bqueue_cap = 0; bool bqueue_uploaded = false;
+    int xcc_count = -1;               // XCC ids this device reports (census, ftte_brick.hip); -1: not taken yet
+    int8_t xcc_queue[16] = {};        // XCC id -> 0 .. xcc_count - 1, or -1
     uint32_t bepoch = 0;
     BrickPlan bplan;
     bool bplan_uploaded = false;
@@ -274,15 +287,14 @@ struct ftte_ctx {
     }
 };
 
-// Which form of the brick kernel sweeps: 0 one wavefront per brick, 1 a wavefront per direction, 2 a pair of wavefronts per brick.
+// Which form of the brick kernel sweeps: 0 one wavefront per brick, 2 a pair of wavefronts per brick.
 // Option "team" = -1 (the default) leaves it to the parallelism: with four frequency groups or fewer on this GPU (a rank of a
 // frequency-sharded run) the stages are narrow, and the pair form's twice as many wavefronts fill them better (5 / 7 / 9 %
 // at 4 / 2 / 1 groups); at eight the single wavefront is 1.5 % ahead.  The dataflow launch is built for form 0 only.
 inline int brick_form(const ftte_ctx *c, int nnu)
 {
     // (with emission the pair form is ahead at eight groups as well, 64.8 against 65.5 ms: 103 instead of 162 VGPRs)
-    const int form = c->team >= 0 ? c->team : (((nnu <= 4 || c->emit_mode) && !c->dataflow) ? 2 : 0);
-    return (c->emit_mode && form == 1) ? 0 : form; // (the team form is built without emission)
+    return c->team >= 0 ? c->team : (((nnu <= 4 || c->emit_mode) && !c->dataflow) ? 2 : 0);
 }
 
 
@@ -316,6 +328,7 @@ int build_plan(ftte_ctx *c, int rows, int stack, int ndir, const double *phi, co
 int plan_brick_groups(ftte_ctx *c, BrickPlan &P, int ndir, const double *phi, const double *theta, const double *w, int chunk, int gmax,
                       int want_dataflow, bool whole_faces);
 int build_brick_plan(ftte_ctx *c, int ndir, const double *phi, const double *theta, const double *w);
+int xcc_census(ftte_ctx *c); // fills ftte_ctx::xcc_count, xcc_queue (once per context)
 
 // ---- ftte_sweeps.cpp
 int ensure_kappa(ftte_ctx *c, int nnu);

@@ -182,7 +182,8 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
     // short bricks: the box is widened by one brick on every side, and what lies inside it costs several times a brick's bytes
     const int chunk = std::min(c->chunk > 0 ? c->chunk : 4, n);
     const int gmax = c->group > 0 ? c->group : (nnu >= 2 ? 3 : 2);
-    std::vector<double> key = {c->box, (double)chunk, (double)gmax, (double)c->share, (double)c->halves, (double)c->hybrid_lanes, (double)c->hybrid_slots};
+    std::vector<double> key = {c->box, (double)chunk, (double)gmax, (double)c->share, (double)c->halves, (double)c->hybrid_lanes, (double)c->hybrid_slots,
+                               (double)c->forest_batch};
     key.insert(key.end(), phi, phi + ndir);
     key.insert(key.end(), theta, theta + ndir);
     key.insert(key.end(), w, w + ndir);
@@ -221,6 +222,10 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
     // which needs accumulators that are not shared between groups (the proof that two groups of one accumulator never meet in a
     // launch rests on launch = stage + offset).  36 accumulators of a 128^3 base grid are 5 GB and 1 ms of merge.
     H.slots = (H.npass > 1 && c->hybrid_slots) || c->hybrid_slots == 2;
+    // Forest batches smaller than the direction list (option "forest_batch") put all pipelines' forests into one run on one stream,
+    // which has ONE place in the launch sequence: only the phase form gives every pipeline the same place for a pass.  (Where it is
+    // the device memory that makes the batch small, hybrid_sweep finds out later and leaves such a sweep to the forest path.)
+    if (c->forest_batch > 0 && c->forest_batch < ndir) H.slots = false;
     if (H.slots) {
         int per_layout[3] = {0, 0, 0};
         for (const auto &G : P.groups) ++per_layout[G.layout];
@@ -566,6 +571,8 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
 {
     *done = false;
     int rc;
+    // (decided before any device state is touched: the forest path then builds its own plan and scratch, not both)
+    if (c->nnu > 96) return FTTE_OK; // the cell-major copy of kappa is what the level kernel reads here: leave it to the forest path
     if ((rc = wait_sweep(c))) return rc;
     FTTE_HIP(c, hipStreamSynchronize(stream));
     if (stream != c->stream) FTTE_HIP(c, hipStreamSynchronize(c->stream));
@@ -654,7 +661,11 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
         FTTE_HIP(c, hipMalloc((void **)&c->amr_mean, sizeof(double) * per_dir * (size_t)batch));
         c->amr_scratch_cap = per_dir * (size_t)batch;
     } else batch = (int)std::min<size_t>((size_t)most, c->amr_scratch_cap / per_dir);
-    if (nnu > 96) return FTTE_OK; // the cell-major copy of kappa is what the level kernel reads here: leave it to the forest path
+    // Several passes keep every direction's scratch from pass to pass, and pipelines whose launch lists go by slot have each their
+    // own place for a pass (pass_at[pipeline][pass]): with fewer directions resident than the sweep has, all pipelines' forests
+    // would have to go in one run at ONE place, in front of bricks of the other pipelines that feed them or behind bricks that
+    // read what they export.  Both are left to the forest path for the whole tree.
+    if (batch < ndir && (H.npass > 1 || (H.slots && H.nhalves > 1))) return FTTE_OK;
     if ((rc = ensure(c, &c->amr_kappa, &c->amr_kappa_cap, (size_t)nnu * (size_t)std::max<int64_t>(H.ncells, 1)))) return rc;
     if (!c->kappa_ready[3] || c->amr_kappa_form != 1) {
         if (launch_cell_major(c->kappa[0], c->amr_kappa, ncell, nnu, stream, H.cells, (long)H.ncells)) return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
@@ -703,7 +714,6 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
     // ---- per half: bricks not behind the boxes, the forests of the boxes (all directions of the half per depth launch), the
     // bricks behind them.  The halves run side by side on two streams and meet only in J: the second half's means are added
     // after the first half's (an event), the bricks' accumulators after both.
-    if (H.npass > 1 && batch < ndir) return FTTE_OK; // several passes keep every direction's scratch: leave it to the forest path
     const int nh = (H.nhalves > 1 && batch >= ndir) ? H.nhalves : 1; // scratch for every direction at once, or one pipeline
     hipStream_t qs[ftte_ctx::kMaxPipes] = {stream, stream, stream, stream};
     if (nh > 1) {

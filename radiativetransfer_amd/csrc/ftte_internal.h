@@ -82,6 +82,7 @@ struct LaunchRec {
 // neighbours (u-1, v-1, chunk-1) to be done: bricks with equal tu + tv + ti form a stage, one launch per stage.
 constexpr int kBrickRows = 8;
 constexpr int kBrickDeps = 6;    // the bricks a brick waits for: u-1, v-1, chunk-1, the previous writer of its J tile, the readers of the two ring slots it reuses
+constexpr int kBrickQueues = 8;  // task queues of the persistent form: one per XCD of an MI355X
 constexpr int kBrickMaxDirs = 8; // directions of one group (their ray state waits in LDS: 4 KB per direction and wave)
 
 struct BrickDir {
@@ -143,6 +144,14 @@ struct BrickLaunch {
     // group's org, sv, bu, bv are then those of this order (tiled_index, ftte_kernels.hip); si is the same in both.  tiled == 2: the
     // `chunk` layers of a brick follow each other as well (the whole brick in one piece of chunk x 4 KB; n a multiple of the chunk).
     int32_t tiled, pad2_;
+    // Persistent form (queue != nullptr, ftte_brick.hip): as many workgroups as the GPU holds at once, each bound to the XCD it runs
+    // on (read from HW_REG_XCC_ID); a workgroup draws (task, frequency group) pairs from ITS XCD's queue only, in queue order, until
+    // the queue is empty.  A queue holds whole chains of dependent bricks (everything a brick waits for lies earlier in the same
+    // queue), so every ray face and accumulator row a brick reads was written by a CU behind the same L2: plain stores, a drained
+    // store counter and a flag suffice, no write-through and no L2 write-back.  Tickets 32 words apart: ticket[32 q].
+    const uint32_t *queue;                        // work ids (task index * nnu + frequency slot), queue after queue, each in stage order
+    uint32_t qoff[kBrickQueues], qlen[kBrickQueues];
+    int8_t xcc_queue[16];                         // XCC id -> queue, from the census of the device's XCC ids (-1: an id the census did not see)
     ftte_consts math;
 };
 

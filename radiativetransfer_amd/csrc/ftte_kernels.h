@@ -12,9 +12,9 @@ void set_lds_pad(int bytes); // diagnostic: dynamic LDS per workgroup, to cap re
 int lds_pad();
 int launch_sweep(const LaunchRec &L, int rows, int waves, int stack, int nnu, hipStream_t stream);
 // one stage of the cell-fixed brick sweep; max_dirs: directions of the launch's largest group (sizes the LDS); waves 2..4
-int launch_brick(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stream, bool masked = false);
-// the same stage by teams: one wavefront per direction of a group in one workgroup
-int launch_brick_team(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stream);
+// persistent > 0 (BrickLaunch::queue set): the whole sweep in one launch of that many workgroups, a task queue per XCD
+int launch_brick(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stream, bool masked = false, int persistent = 0);
+int launch_xcc_census(unsigned *mask_dev, hipStream_t stream); // bit x of *mask_dev set: some workgroup ran on the XCD whose HW_REG_XCC_ID is x
 int launch_brick_pair(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stream); // two wavefronts per brick, four rows each
 // cell-array order -> layout 1 ([jc][ic][kc]) or 2 ([kc][ic][jc]); nnu groups, group_stride apart
 int launch_to_layout(int layout, const double *src, double *dst, int n, int nnu, long group_stride, hipStream_t stream, bool tiled = false, int tchunk = 0); // tiled: brick order (BrickLaunch::tiled), layout 0 too; tchunk: layers per piece

@@ -85,6 +85,8 @@ typedef struct {
     double lg[7];   /* (atanh(s)/s - 1)/s^2 ~ lg0 + lg1 z + ... + lg6 z^6, z = s^2, tools/fit_log_poly.py */
     double s_max;   /* (sqrt(2)-1)/(sqrt(2)+1): below it the log-mean of two intensities needs no logarithm */
     double mn[7];   /* (s/atanh(s) - 1)/s^2 ~ mn0 + mn1 z + ... + mn6 z^6, tools/fit_mean_poly.py */
+    double thin_max; /* the largest tau with rint(fl(-tau * log2e)) == 0, i.e. n = 0 in the range reduction: ln2/2 rounded down to
+                      * 0x1.62e42fefa39efp-2 (found by bisection, checked ulp by ulp on both sides: tests/test_device_math.py) */
 } ftte_consts;
 
 #define FTTE_CONSTS_INIT                                                                                              \
@@ -104,7 +106,8 @@ typedef struct {
         {                                                                                                             \
             -0x1.5555555555556p-2, -0x1.6c16c16c1511dp-4, -0x1.7d6d2c2f3c50dp-5, -0x1.eeb2c916bdc4dp-6,               \
                 -0x1.6522b1e23e2e9p-6, -0x1.123931a9bb85bp-6, -0x1.e26cad68d7a18p-7                                   \
-        }                                                                                                             \
+        },                                                                                                            \
+            0x1.62e42fefa39efp-2                                                                                      \
     }
 
 /* e = exp(-tau), g = (1-exp(-tau))/tau  (g(0) = 1).  tau >= 0 expected; a
@@ -120,63 +123,96 @@ FTTE_HD void ftte_attenuation(const ftte_consts *K, double tau, double *e_out, d
  * operand: c9 * r + c8 with both coefficients in scalar registers needs one of them copied first).
  *
  * Returns whether any lane of the wavefront (on the host: this evaluation) left the thin range tau < ln2/2, where n = 0,
- * exp(-tau) = exp(r) needs no scaling and g is the polynomial itself.  Everything the other lanes need -- the scaling by 2^n,
- * the floor at exp(-1000) = 0, the division -- is done behind that one test, so a wavefront of thin segments (five in six of
- * the benchmark's) executes the range reduction, twelve fused multiply-adds and the test, and nothing else.  The values are
+ * exp(-tau) = exp(r) needs no scaling and g is the polynomial itself.  Everything the other lanes need -- the range reduction,
+ * the scaling by 2^n, the floor at exp(-1000) = 0, the division -- is done behind that one test, so a wavefront of thin segments
+ * (five in six of the benchmark's) executes the test, eleven fused multiply-adds, and nothing else.  The values are
  * those of the straightforward form x = max(-tau, x_floor), e = ldexp(exp(r), n), g = n ? (1 - e)/tau : expm1(r)/r. */
+/* The range reduction.  n = rint(-tau log2e) is 0 exactly for |tau| <= thin_max (the product is monotonic in tau, the bound is the
+ * last tau whose rounded product rounds to 0): a wavefront of such segments needs no reduction at all, and the test of the
+ * wavefront is one comparison of tau itself.  The polynomial's argument is carried with the opposite sign, t = -r = tau + n ln2,
+ * so that for n = 0 it is tau as it stands (negating an operand of a fused multiply-add is free, a negated copy is not); the two
+ * reduction steps round to the same magnitudes either way. */
+FTTE_HD int ftte_all_thin(const ftte_consts *K, double tau) { return !FTTE_ANY(!(__builtin_fabs(tau) <= K->thin_max)); }
+
+FTTE_HD double ftte_reduce(const ftte_consts *K, double tau)
+{
+    const double nf = FTTE_RINT(-tau * K->log2e);
+    double t = FTTE_FMA(nf, K->ln2_hi, tau);
+    t = FTTE_FMA(nf, K->ln2_lo, t);
+    FTTE_KEEP(t); /* a branch of the wavefront: nothing of this is hoisted in front of the test */
+    return t;
+}
+
+/* g = expm1(r)/r and e = exp(r) for r = -t, |t| <= ln2/2 */
+FTTE_HD void ftte_exp_reduced(const ftte_consts *K, double lead, double t, double *e_out, double *g_out)
+{
+    double q = lead;
+    q = FTTE_FMA(q, -t, K->c[8]);
+    q = FTTE_FMA(q, -t, K->c[7]);
+    q = FTTE_FMA(q, -t, K->c[6]);
+    q = FTTE_FMA(q, -t, K->c[5]);
+    q = FTTE_FMA(q, -t, K->c[4]);
+    q = FTTE_FMA(q, -t, K->c[3]);
+    q = FTTE_FMA(q, -t, K->c[2]);
+    q = FTTE_FMA(q, -t, K->c[1]);
+    q = FTTE_FMA(q, -t, K->c[0]);
+    const double g = FTTE_FMA(-t, q, 1.0);
+    *g_out = g;
+    *e_out = FTTE_FMA(-t, g, 1.0);
+}
+
+/* What the lanes outside the thin range need on top (every lane of a wavefront with such a lane passes through here; the thin ones
+ * keep their values): the scaling by 2^n, the floor at exp(-1000) = 0, g by division. */
+FTTE_HD void ftte_thick_part(const ftte_consts *K, double tau, double *e_io, double *g_io)
+{
+    /* below x_floor exp(x) is 0 in binary64 (and t, q of such a lane are whatever the reduction of a huge x gives: not used);
+     * n is kept inside the range of an int for it */
+    const double nf = FTTE_RINT(-tau * K->log2e);
+    const int n = (int)FTTE_FMAX(nf, -2048.0);
+    const double scaled = FTTE_LDEXP(*e_io, n); /* n == 0: e itself */
+    const double e = (-tau >= K->x_floor) ? scaled : 0.0;
+    double gd = FTTE_DIV(1.0 - e, tau); /* n != 0: tau >= ln2/2, 1-e >= 0.29, no cancellation */
+    FTTE_KEEP(gd);
+    *g_io = (nf == 0.0) ? *g_io : gd;
+    *e_io = e;
+}
+
 FTTE_HD int ftte_attenuation_lead(const ftte_consts *K, double lead, double tau, double *e_out, double *g_out)
 {
-    const double x = -tau;
-    const double nf = FTTE_RINT(x * K->log2e);
-    double r = FTTE_FMA(nf, -K->ln2_hi, x);
-    r = FTTE_FMA(nf, -K->ln2_lo, r);
-
-    double q = lead;
-    q = FTTE_FMA(q, r, K->c[8]);
-    q = FTTE_FMA(q, r, K->c[7]);
-    q = FTTE_FMA(q, r, K->c[6]);
-    q = FTTE_FMA(q, r, K->c[5]);
-    q = FTTE_FMA(q, r, K->c[4]);
-    q = FTTE_FMA(q, r, K->c[3]);
-    q = FTTE_FMA(q, r, K->c[2]);
-    q = FTTE_FMA(q, r, K->c[1]);
-    q = FTTE_FMA(q, r, K->c[0]);
-
-    double g = FTTE_FMA(r, q, 1.0); /* expm1(r)/r */
-    double e = FTTE_FMA(r, g, 1.0); /* exp(r)     */
-    const int thick = FTTE_ANY(nf != 0.0);
-    if (thick) {
-        /* below x_floor exp(x) is 0 in binary64 (and r, q of such a lane are whatever the reduction of a huge x gives: not used);
-         * n is kept inside the range of an int for it */
-        const int n = (int)FTTE_FMAX(nf, -2048.0);
-        const double scaled = FTTE_LDEXP(e, n); /* n == 0: e itself */
-        e = (x >= K->x_floor) ? scaled : 0.0;
-        double gd = FTTE_DIV(1.0 - e, tau); /* n != 0: tau >= ln2/2, 1-e >= 0.29, no cancellation */
-        FTTE_KEEP(gd);
-        g = (nf == 0.0) ? g : gd;
+    if (ftte_all_thin(K, tau)) {
+        ftte_exp_reduced(K, lead, tau, e_out, g_out);
+        return 0;
     }
+    double e, g;
+    ftte_exp_reduced(K, lead, ftte_reduce(K, tau), &e, &g);
+    ftte_thick_part(K, tau, &e, &g);
     *e_out = e;
     *g_out = g;
-    return thick;
+    return 1;
 }
 
 /* One segment: advances the ray intensity and returns the path-mean intensity
  * the cell receives from it.  Iout == 0 (underflow) yields a zero mean, as the
  * reference's (Iin-0)/log(Iin/0) does.  A thin segment (n = 0: exp(-tau) > 0.7) takes a nonzero Iin to a nonzero Iout --
  * the product with the smallest subnormal still rounds to it --, and with Iin = 0 the mean is 0 as it stands: the fix-up is
- * needed only where some lane is thick, and sits behind the same test. */
+ * needed only where some lane is thick.  Two complete paths behind the one test of the wavefront: the thin one is the test,
+ * eleven fused multiply-adds on tau itself and the two products, and nothing else. */
 FTTE_HD double ftte_segment_lead(const ftte_consts *K, double lead, double *I, double tau)
 {
     double e, g;
-    const int thick = ftte_attenuation_lead(K, lead, tau, &e, &g);
     const double Iin = *I;
-    const double Iout = Iin * e;
-    *I = Iout;
-    double mean = Iin * g;
-    if (thick) {
-        mean = (Iout == 0.0) ? 0.0 : mean;
-        FTTE_KEEP(mean); /* a branch, not a pair of selects every lane pays for */
+    if (__builtin_expect(ftte_all_thin(K, tau), 1)) {
+        ftte_exp_reduced(K, lead, tau, &e, &g);
+        *I = Iin * e;
+        return Iin * g;
     }
+    ftte_exp_reduced(K, lead, ftte_reduce(K, tau), &e, &g);
+    ftte_thick_part(K, tau, &e, &g);
+    const double Iout = Iin * e;
+    double mean = Iin * g;
+    mean = (Iout == 0.0) ? 0.0 : mean;
+    FTTE_KEEP(mean); /* (a branch, not a pair of selects every lane pays for) */
+    *I = Iout;
     return mean;
 }
 

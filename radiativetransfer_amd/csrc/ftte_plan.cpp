@@ -313,10 +313,14 @@ int build_brick_plan(ftte_ctx *c, int ndir, const double *phi, const double *the
     const int chunk = std::min(c->chunk > 0 ? c->chunk : (nnu >= 4 ? 16 : nnu >= 2 ? 8 : 4), n);
     const int form = brick_form(c, nnu);
     const int gmax = c->group > 0 ? c->group : (nnu >= 2 || form == 2 ? 3 : 2);
-    const int want_dataflow = (c->dataflow && n % 64 == 0 && n % kBrickRows == 0 && n % chunk == 0 && form == 0 && !c->emit_mode) ? 1 : 0;
+    int want_dataflow = (c->dataflow && n % 64 == 0 && n % kBrickRows == 0 && n % chunk == 0 && form == 0 && !c->emit_mode) ? 1 : 0;
+    if (want_dataflow && c->dataflow == 3) { // persistent workgroups, a queue per XCD: needs to know the XCDs
+        if ((rc = xcc_census(c))) return rc;
+        want_dataflow = (c->xcc_count >= 1 && c->xcc_count <= kBrickQueues) ? 3 : 1;
+    }
     const int want_glanes = want_dataflow ? 1 : (nnu >= c->lanes ? 1 : c->lanes);
     if (P.valid && P.n == n && P.chunk == chunk && P.gmax == gmax && P.share == c->share && P.want_glanes == want_glanes &&
-        P.want_dataflow == want_dataflow && P.box == c->box &&
+        P.want_dataflow == want_dataflow && P.box == c->box && (want_dataflow != 3 || (P.qnnu == nnu && P.nq == c->xcc_count && P.qmix == c->queue_mix)) &&
         (int)P.phi.size() == ndir &&
         (ndir == 0 || (!std::memcmp(P.phi.data(), phi, sizeof(double) * ndir) &&
                        !std::memcmp(P.theta.data(), theta, sizeof(double) * ndir) &&
@@ -435,6 +439,56 @@ int build_brick_plan(ftte_ctx *c, int ndir, const double *phi, const double *the
         for (size_t q = 0; q < nt; ++q)
             for (int k = 0; k < kBrickDeps; ++k)
                 if (P.deps[q * kBrickDeps + k] >= (int32_t)q) return fail(c, FTTE_ERR_STATE, "brick plan: a dependency does not precede its brick");
+    }
+    P.persistent = false;
+    if (P.dataflow && want_dataflow == 3 && !P.tasks.empty()) {
+        // Queues.  What a brick waits for belongs to its own frequency group and to the groups of directions that share its
+        // accumulator, so (frequency group, accumulator) pairs are the units that can be dealt out.  With a multiple of the queue
+        // count in frequency groups, queue = group mod queues (all direction groups of a frequency group read the same opacities:
+        // one L2 for them); else the units go, largest first, to the queue with the least work so far.
+        const int nq = c->xcc_count;
+        P.persistent = true; P.qnnu = nnu; P.nq = nq; P.qmix = c->queue_mix;
+        std::vector<int64_t> acc_dirs(3 * (size_t)kMaxAcc, 0);
+        for (const auto &G : P.groups) acc_dirs[(size_t)G.layout * kMaxAcc + G.acc] += (int64_t)G.dirs.size();
+        std::vector<int> queue_of((size_t)nnu * 3 * kMaxAcc, -1);
+        int64_t load[kBrickQueues] = {};
+        if (nnu % nq == 0 && c->queue_mix == 0) {
+            for (int nu = 0; nu < nnu; ++nu)
+                for (size_t a = 0; a < acc_dirs.size(); ++a)
+                    if (acc_dirs[a]) { queue_of[(size_t)nu * acc_dirs.size() + a] = nu % nq; load[nu % nq] += acc_dirs[a]; }
+        } else if (c->queue_mix == 2) { // every queue a share of every frequency group: accumulator a of group nu to queue (nu + a) mod queues
+            for (int nu = 0; nu < nnu; ++nu) {
+                int k = 0;
+                for (size_t a = 0; a < acc_dirs.size(); ++a)
+                    if (acc_dirs[a]) { const int q = (nu + k++) % nq; queue_of[(size_t)nu * acc_dirs.size() + a] = q; load[q] += acc_dirs[a]; }
+            }
+        } else {
+            std::vector<std::pair<int64_t, size_t>> units;
+            for (int nu = 0; nu < nnu; ++nu)
+                for (size_t a = 0; a < acc_dirs.size(); ++a)
+                    if (acc_dirs[a]) units.push_back({acc_dirs[a], (size_t)nu * acc_dirs.size() + a});
+            std::stable_sort(units.begin(), units.end(), [](const auto &x, const auto &y) { return x.first > y.first; });
+            for (const auto &u : units) {
+                int q = 0;
+                for (int k = 1; k < nq; ++k) if (load[k] < load[q]) q = k;
+                queue_of[u.second] = q;
+                load[q] += u.first;
+            }
+        }
+        std::vector<std::vector<uint32_t>> lists((size_t)nq);
+        for (size_t t = 0; t < P.tasks.size(); ++t) {
+            const BrickPlan::Group &G = P.groups[(size_t)P.tasks[t].group];
+            const size_t a = (size_t)G.layout * kMaxAcc + G.acc;
+            for (int nu = 0; nu < nnu; ++nu)
+                lists[(size_t)queue_of[(size_t)nu * acc_dirs.size() + a]].push_back((uint32_t)(t * (size_t)nnu + (size_t)nu));
+        }
+        P.queue.clear();
+        for (int q = 0; q < kBrickQueues; ++q) {
+            P.qoff[q] = (uint32_t)P.queue.size();
+            P.qlen[q] = q < nq ? (uint32_t)lists[(size_t)q].size() : 0;
+            P.qload[q] = q < nq ? load[q] * (int64_t)n * n * n : 0;
+            if (q < nq) P.queue.insert(P.queue.end(), lists[(size_t)q].begin(), lists[(size_t)q].end());
+        }
     }
     P.valid = true;
     return FTTE_OK;

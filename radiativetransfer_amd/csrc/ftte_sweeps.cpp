@@ -1,5 +1,7 @@
 // ftte_sweeps.cpp -- the launch sequences of the diffuse sweep: per-direction segment forests on refined cell arrays
 // (forest_sweep and its pieces, also used by the hybrid sweep) and cell-fixed bricks on uniform grids (brick_sweep).
+#include <cstdlib>
+
 #include "ftte_context.h"
 
 namespace ftte {
@@ -33,11 +35,47 @@ int wait_sweep(ftte_ctx *c)
     if (c->sweep_pending) {
         FTTE_HIP(c, hipEventSynchronize(c->ev_sweep_done));
         c->sweep_pending = false;
-        if (c->h_berror && *c->h_berror) {
-            *c->h_berror = 0;
-            return fail(c, FTTE_ERR_NO_DEVICE, "the previous sweep gave up: a brick waited too long for the bricks it depends on (its J is not valid)");
+        if (c->h_berror && c->h_berror[32 * kBrickQueues]) {
+            c->h_berror[32 * kBrickQueues] = 0;
+            std::memset(c->bqlen, 0, sizeof c->bqlen);
+            return fail(c, FTTE_ERR_STALLED, "the previous sweep gave up: a brick waited for the bricks it depends on while nothing moved (its J is not valid)");
+        }
+        if (c->h_berror && c->bqlen[0] && std::getenv("FTTE_QUEUE_STATS")) { // instrumentation of the persistent form, per queue
+            unsigned long long began = 0;
+            std::memcpy(&began, c->h_berror + 32 * kBrickQueues + 2, 8);
+            began = ~began;
+            for (int q = 0; q < kBrickQueues; ++q) {
+                unsigned long long fin = 0, waited = 0;
+                std::memcpy(&fin, c->h_berror + 32 * q + 2, 8);
+                std::memcpy(&waited, c->h_berror + 32 * q + 4, 8);
+                std::fprintf(stderr, "[ftte] queue %d: %u tasks, %u workgroups, drained after %.3f ms, %.1f polls per task, load %lld updates\n", q, c->bqlen[q],
+                             c->h_berror[32 * q + 6], (double)(fin - began) * 1e-5, c->bqlen[q] ? (double)waited / c->bqlen[q] : 0.0, (long long)c->bplan.qload[q]);
+            }
+        }
+        for (int q = 0; q < kBrickQueues; ++q) {
+            const uint32_t want = c->bqlen[q];
+            c->bqlen[q] = 0;
+            if (want && c->h_berror && c->h_berror[32 * q] < want)
+                return fail(c, FTTE_ERR_STALLED, "the previous sweep left a task queue undrained: no workgroup ran on that queue's XCD (its J is not valid)");
         }
     }
+    return FTTE_OK;
+}
+
+// The XCC ids this device's workgroups report (HW_REG_XCC_ID), numbered 0 .. count - 1 in ascending order: the persistent form of
+// the brick sweep keeps a task queue per XCD.  Once per context.
+int xcc_census(ftte_ctx *c)
+{
+    if (c->xcc_count >= 0) return FTTE_OK;
+    unsigned *mask_dev = nullptr, mask = 0;
+    FTTE_HIP(c, hipMalloc((void **)&mask_dev, sizeof(unsigned)));
+    FTTE_HIP(c, hipMemset(mask_dev, 0, sizeof(unsigned)));
+    if (launch_xcc_census(mask_dev, c->stream)) { (void)hipFree(mask_dev); return fail(c, FTTE_ERR_NO_DEVICE, "census kernel launch failed"); }
+    FTTE_HIP(c, hipStreamSynchronize(c->stream));
+    FTTE_HIP(c, hipMemcpy(&mask, mask_dev, sizeof(unsigned), hipMemcpyDeviceToHost));
+    FTTE_HIP(c, hipFree(mask_dev));
+    c->xcc_count = 0;
+    for (int x = 0; x < 16; ++x) c->xcc_queue[x] = (mask >> x) & 1u ? (int8_t)c->xcc_count++ : (int8_t)-1;
     return FTTE_OK;
 }
 
@@ -416,7 +454,7 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
     // third more out of the memory system that way (tools/membench.hip); the sweep gets nothing (31.66 against 31.67 ms), so the
     // option is off by default.  For grids made of whole bricks, device-resident opacities, the forms of the kernel that know it;
     // costs one more copy of the opacities per axis order.
-    const bool tiled = c->tiled_opt && !pipe && !c->emit_mode && n % 64 == 0 && n % kBrickRows == 0 && brick_form(c, nnu) != 1 &&
+    const bool tiled = c->tiled_opt && !pipe && !c->emit_mode && n % 64 == 0 && n % kBrickRows == 0 &&
                        (c->tiled_opt == 1 || n % P.chunk == 0);
     const int tchunk = tiled && c->tiled_opt == 2 ? P.chunk : 0; // 2: a whole brick in one piece
     // accumulators and the opacity in the layouts the groups march through
@@ -461,6 +499,7 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
             FTTE_HIP(c, hipMemcpy(c->d_bdeps, P.deps.data(), sizeof(int32_t) * P.deps.size(), hipMemcpyHostToDevice));
         }
         c->bplan_uploaded = true;
+        c->bqueue_uploaded = false;
     }
     // the group records carry pointers that depend on nnu (face blocks) and on the buffers: rebuilt per sweep (a few KB)
     {
@@ -559,12 +598,18 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
                 FTTE_HIP(c, hipMemsetAsync(c->d_bdone, 0, sizeof(uint32_t) * c->d_bdone_cap, stream));
                 c->bepoch = 0;
             }
+            constexpr size_t kSyncWords = 32 * (kBrickQueues + 1);
             if (!c->d_bsync) {
-                FTTE_HIP(c, hipMalloc((void **)&c->d_bsync, sizeof(uint32_t) * 2));
-                FTTE_HIP(c, hipHostMalloc((void **)&c->h_berror, sizeof(uint32_t), hipHostMallocDefault));
-                *c->h_berror = 0;
+                FTTE_HIP(c, hipMalloc((void **)&c->d_bsync, sizeof(uint32_t) * kSyncWords));
+                FTTE_HIP(c, hipHostMalloc((void **)&c->h_berror, sizeof(uint32_t) * kSyncWords, hipHostMallocDefault));
+                std::memset(c->h_berror, 0, sizeof(uint32_t) * kSyncWords);
             }
-            FTTE_HIP(c, hipMemsetAsync(c->d_bsync, 0, sizeof(uint32_t) * 2, stream));
+            FTTE_HIP(c, hipMemsetAsync(c->d_bsync, 0, sizeof(uint32_t) * kSyncWords, stream));
+            if (P.persistent && (c->d_bqueue_cap < P.queue.size() || !c->bqueue_uploaded)) {
+                if ((rc = ensure(c, &c->d_bqueue, &c->d_bqueue_cap, P.queue.size()))) return rc;
+                FTTE_HIP(c, hipMemcpy(c->d_bqueue, P.queue.data(), sizeof(uint32_t) * P.queue.size(), hipMemcpyHostToDevice));
+                c->bqueue_uploaded = true;
+            }
             BrickLaunch L;
             std::memset(&L, 0, sizeof L);
             L.groups = c->d_bgroups;
@@ -576,12 +621,26 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
             L.n = n; L.ntasks = (int)P.tasks.size(); L.nnu = nnu; L.nu0 = 0; L.chunk = P.chunk;
             L.up = P.up; L.vp = P.vp; L.uw = P.uw; L.ut = P.ut; L.nslot = P.nslot;
             L.emit = c->emit_mode;
-            L.ticket = c->d_bsync; L.error = c->d_bsync + 1; L.done = c->d_bdone; L.deps = c->d_bdeps; L.epoch = ++c->bepoch; L.pad_ = c->dataflow == 2 ? 1 : 0;
+            L.ticket = c->d_bsync; L.error = c->d_bsync + 32 * kBrickQueues; L.done = c->d_bdone; L.deps = c->d_bdeps; L.epoch = ++c->bepoch; L.pad_ = c->dataflow == 2 ? 1 : 0;
             L.math = kMath;
             L.tiled = tiled ? 1 : 0;
-            const int lrc = launch_brick(L, P.max_dirs, c->brick_waves, stream);
+            L.pad2_ = c->ablate;
+            int persistent = 0;
+            if (P.persistent) {
+                L.queue = c->d_bqueue;
+                std::memcpy(L.qoff, P.qoff, sizeof L.qoff);
+                std::memcpy(L.qlen, P.qlen, sizeof L.qlen);
+                std::memcpy(L.xcc_queue, c->xcc_queue, sizeof L.xcc_queue);
+                // as many workgroups as the GPU holds (four waves per SIMD; fewer fit when LDS is padded: the rest start late and
+                // find the queues empty)
+                hipDeviceProp_t prop;
+                FTTE_HIP(c, hipGetDeviceProperties(&prop, c->device));
+                persistent = (int)std::min<size_t>((size_t)prop.multiProcessorCount * 16, P.queue.size());
+            }
+            const int lrc = launch_brick(L, P.max_dirs, c->brick_waves, stream, false, persistent);
             if (lrc) return fail(c, lrc == -1 ? FTTE_ERR_ARG : FTTE_ERR_NO_DEVICE, "brick kernel launch failed");
-            FTTE_HIP(c, hipMemcpyAsync(c->h_berror, c->d_bsync + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            FTTE_HIP(c, hipMemcpyAsync(c->h_berror, c->d_bsync, sizeof(uint32_t) * kSyncWords, hipMemcpyDeviceToHost, stream));
+            if (P.persistent) std::memcpy(c->bqlen, P.qlen, sizeof c->bqlen);
         }
         FTTE_HIP(c, hipEventRecord(c->ev_fork, stream));
         for (int lane = 0; lane < nlanes && !P.dataflow; ++lane) {
@@ -623,10 +682,10 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
                 L.emit = c->emit_mode;
                 L.math = kMath;
                 L.tiled = tiled ? 1 : 0;
+                L.pad2_ = c->ablate;
                 const int form = brick_form(c, nnu);
                 c->last_brick_form = form;
-                const int lrc = form == 2 ? launch_brick_pair(L, P.max_dirs, c->pair_waves, q)
-                              : form == 1 ? launch_brick_team(L, P.max_dirs, c->brick_waves, q) : launch_brick(L, P.max_dirs, c->brick_waves, q);
+                const int lrc = form == 2 ? launch_brick_pair(L, P.max_dirs, c->pair_waves, q) : launch_brick(L, P.max_dirs, c->brick_waves, q);
                 if (lrc) return fail(c, lrc == -1 ? FTTE_ERR_ARG : FTTE_ERR_NO_DEVICE, "brick kernel launch failed");
             }
             if (lane_ends) { // this lane's J: merged as soon as its stages are done, and on its way back (pinned arrays) behind that

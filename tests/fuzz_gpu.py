@@ -42,8 +42,8 @@ def main():
         # the organisation of the uniform-grid sweep: bricks with random shapes and sharing, now and then one launch with flags,
         # now and then the ray-following tiles; every form of the brick kernel
         opts = dict(engine=int(rng.choice([0, 0, 0, 1])), chunk=int(rng.choice([0, 1, 3, 4, 16, 32])), group=int(rng.integers(0, 6)),
-                    share=int(rng.integers(0, 3)), lanes=int(rng.integers(1, 5)), dataflow=int(rng.choice([0, 0, 0, 2])),
-                    team=int(rng.choice([-1, -1, 0, 1, 2, 2])))
+                    share=int(rng.integers(0, 3)), lanes=int(rng.integers(1, 5)), dataflow=int(rng.choice([0, 0, 0, 2, 3, 3])),
+                    team=int(rng.choice([-1, -1, 0, 2, 2])))
         for k, v in opts.items():
             eng.set_option(k, v)
         eng.set_grid(n, level, 1.0)

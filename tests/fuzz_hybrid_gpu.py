@@ -41,7 +41,7 @@ def main():
         w = rng.uniform(0.1, 1.0, pick.size) / pick.size
         opts = dict(chunk=int(rng.choice([0, 2, 4, 8])), group=int(rng.choice([0, 1, 2, 4])), share=int(rng.integers(0, 3)),
                     pipelines=int(rng.integers(1, 5)), box_lanes=int(rng.choice([1, 2, 4, 16, 64])),
-                    forest_batch=int(rng.choice([0, 0, 5])), hybrid_slots=int(rng.integers(0, 2)))
+                    forest_batch=int(rng.choice([0, 0, 5])), hybrid_slots=int(rng.integers(0, 3)))
         t0 = time.perf_counter()
         with rt.DiffuseTransfer() as eng:
             eng.set_grid(n, level, 1.0)

@@ -17,12 +17,12 @@ EPS = np.finfo(np.float64).eps
 SUM_RTOL = 64 * EPS
 
 
-@pytest.fixture(params=["team", "solo", "pair"])
+@pytest.fixture(params=["solo", "pair"])
 def bricks(engine, request):
-    """Both forms of the brick kernel: a team of wavefronts, one per direction of a group (the default), and one wavefront
-    that takes the group's directions in turn."""
+    """Both forms of the brick kernel: one wavefront that takes the directions of a group in turn, and a pair of wavefronts
+    with half the brick's rows each."""
     engine.set_option("engine", 2)
-    engine.set_option("team", {"team": 1, "solo": 0, "pair": 2}[request.param])
+    engine.set_option("team", {"solo": 0, "pair": 2}[request.param])
     yield engine
     for key, value in (("engine", 0), ("team", -1), ("chunk", 0), ("group", 0), ("share", 2), ("lanes", 2)):
         engine.set_option(key, value)
@@ -143,7 +143,7 @@ def test_brick_order_and_frame_order_same_bits(engine, n):
                     J = engine.transport(phi, theta, w, uvb)
                     assert np.array_equal(J, O.sweep_uniform(n, kappa, box, phi, theta, w, uvb, arith=O.ARITH_DEVICE)), (tiled, O.fold_direction(p, t)[2])
         phi, theta, w = O.healpix_directions(2)
-        for form, dataflow in ((0, 0), (2, 0), (0, 2)):
+        for form, dataflow in ((0, 0), (2, 0), (0, 2), (0, 3)):
             engine.set_option("team", form)
             engine.set_option("dataflow", dataflow)
             J = {}
@@ -242,7 +242,7 @@ def test_emission_through_an_opaque_source_free_slab_stays_finite(engine):
     engine.set_option("engine", 0)
 
 
-@pytest.mark.parametrize("nnu,ndirs,group", [(2, 3, 3), (1, 2, 2), (3, 3, 4)])
+@pytest.mark.parametrize("nnu,ndirs,group", [(2, 3, 3), (1, 2, 2), (3, 3, 4), (8, 2, 3), (16, 1, 3)])
 def test_one_launch_with_flags_equals_a_launch_per_stage(engine, nnu, ndirs, group):
     """Grids of whole bricks (n a multiple of 64) are swept in ONE launch: a workgroup takes the next brick of the list, waits for
     the flags of the bricks it depends on (upstream neighbours, the previous writer of its J tile, the readers of the ring slots
@@ -257,7 +257,7 @@ def test_one_launch_with_flags_equals_a_launch_per_stage(engine, nnu, ndirs, gro
     engine.set_opacity(kappa)
     engine.set_option("dataflow", 0)
     J_stages = engine.transport(phi, theta, w, uvb)
-    for form in (1, 2):   # 2: write-through stores instead of an L2 write-back before the flag
+    for form in (1, 2, 3):   # 2: write-through stores instead of an L2 write-back before the flag; 3: persistent workgroups, a queue per XCD
         engine.set_option("dataflow", form)
         for _ in range(3):
             J_flags = engine.transport(phi, theta, w, uvb)

@@ -84,3 +84,26 @@ def test_log_mean_with_emission_accuracy():
     # complete extinction without a source: zero out, zero mean (the reference's (Iin-0)/log(Iin/0))
     Iout, mean = O.device_segment_emit(np.array([3e-21]), np.array([2000.0]), 0.0, np.array([0.0]))
     assert Iout[0] == 0.0 and mean[0] == 0.0
+
+
+def test_thin_bound_is_where_the_range_reduction_starts():
+    """ftte_consts.thin_max = the last tau whose rounded product with 1/ln2 rounds to n = 0: the wavefront's test `|tau| <= thin_max`
+    must decide exactly as `rint(-tau * log2e) == 0` did, or a lane next to the bound would get another range reduction.  Checked
+    ulp by ulp on both sides, and the attenuation pair stays continuous across it."""
+    log2e, thin_max = float.fromhex("0x1.71547652b82fep+0"), float.fromhex("0x1.62e42fefa39efp-2")
+    t = np.float64(thin_max)
+    for _ in range(2000):
+        t = np.nextafter(t, 0.0)
+    for k in range(4000):
+        n_is_zero = np.rint(-t * np.float64(log2e)) == 0.0
+        assert n_is_zero == (t <= thin_max), (k, float(t).hex())
+        t = np.nextafter(t, 1.0)
+    around = np.array([np.nextafter(thin_max, 0.0), thin_max, np.nextafter(thin_max, 1.0)])
+    e, g = O.device_attenuation(around)
+    mp.mp.dps = 40
+    for tau, ee, gg in zip(around, e, g):
+        assert abs(mp.mpf(float(ee)) / mp.e ** (-mp.mpf(float(tau))) - 1) < 2 * EPS
+        assert abs(mp.mpf(float(gg)) / (-mp.expm1(-mp.mpf(float(tau))) / mp.mpf(float(tau))) - 1) < 3 * EPS
+    # negative tau (unphysical, still evaluated): the same bound on |tau|
+    e_neg, _ = O.device_attenuation(-around)
+    assert np.all(e_neg > 1.0)

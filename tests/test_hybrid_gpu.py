@@ -246,6 +246,33 @@ def test_hybrid_more_directions_than_a_forest_batch():
     assert np.allclose(J_batched, J_forest, rtol=SUM_RTOL, atol=0)
 
 
+def test_slot_lists_with_batched_forests_and_several_pipelines():
+    """An off-centre patch (box depths differ between izones, so the pipelines' places for the forest pass differ in slot form),
+    option "hybrid_slots" = 2 (slots even with one pass), three pipelines and forest batches smaller than the direction list: the
+    pipelines' forests then share one run on one stream, which has one place in the launch sequence -- the sweep must fall back to
+    the phase form (or the forest path) rather than launch them at pipeline 0's place.  Against the forest path of the whole tree,
+    single directions bit for bit."""
+    n = 128
+    blocks = [(18 + a, 90 + b, 40 + c) for a in range(2) for b in range(3) for c in range(2)]
+    level, kappa, uvb = patch_case(n, blocks, 1, 2, seed=29)
+    dirs = one_per_izone()
+    phi, theta = np.array([d[0] for d in dirs]), np.array([d[1] for d in dirs])
+    w = np.full(len(dirs), 1.0 / len(dirs))
+    with rt.DiffuseTransfer() as e:
+        e.set_grid(n, level, 1.0)
+        e.set_opacity(kappa)
+        e.set_option("hybrid_slots", 2)
+        e.set_option("pipelines", 3)
+        J_slots = e.transport(phi, theta, w, uvb)               # slot lists, every direction resident
+        e.set_option("forest_batch", 5)
+        J_batched = e.transport(phi, theta, w, uvb)
+        assert np.array_equal(J_batched, e.transport(phi, theta, w, uvb))
+        e.set_option("hybrid", 0)
+        J_forest = e.transport(phi, theta, w, uvb)
+    assert np.allclose(J_slots, J_forest, rtol=SUM_RTOL, atol=0)
+    assert np.allclose(J_batched, J_forest, rtol=SUM_RTOL, atol=0)
+
+
 def test_small_trees_stay_on_the_forest_path(golden):
     """Where the box around the refined cells takes up most of the grid (the AMR goldens: 8^3 and 6^3) nothing is left for the bricks:
     the whole tree goes through the forest, bit for bit as before."""

@@ -251,7 +251,7 @@ def test_call_order_and_refusals(engine):
             e.set_option("rows", 5)
         assert err.value.status == "FTTE_ERR_ARG"
         # every option refuses what it cannot mean, and unknown names
-        for key, bad in (("engine", 3), ("chunk", -1), ("group", 9), ("share", 3), ("lanes", 0), ("brick_waves", 5), ("dataflow", 3),
+        for key, bad in (("engine", 3), ("chunk", -1), ("group", 9), ("share", 3), ("lanes", 0), ("brick_waves", 5), ("dataflow", 4),
                          ("team", 3), ("hybrid", 2), ("pipelines", 5), ("box_lanes", 3), ("forest_batch", -1), ("graph", 2),
                          ("hybrid_slots", 3), ("no such option", 1)):
             with pytest.raises(rt.FtteError) as err:
