@@ -27,7 +27,8 @@ reduce-scatter over the direction slices comes first).  --exchange gather assemb
 --weak restores round 1's mode (96 directions per GPU, 96 N in all, all-reduce).
 
 The JSON line also carries
-  roofline    : sweep kernel, algorithmic bytes (24 B per update) / HIP-event time of its launches
+  roofline    : sweep kernel: `achieved` = algorithmic bytes (24 B per update) / HIP-event time of its launches; `frac` = HBM bytes the
+                counters saw (a committed --measure-traffic record of the same configuration) / the same time / peak
   cpu_baseline: the reference's own compiled transport (oracle/_ref) or the C oracle, on the host cores
 """
 from __future__ import annotations
@@ -81,6 +82,9 @@ def parse():
                     help="N > 1 ranks sharing GPU 0 with the collectives on host copies over gloo: exercises this script's multi-rank "
                          "path on a one-GPU box (RCCL refuses two ranks on one device); the timings mean nothing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--measure-traffic", action="store_true",
+                    help="collect this configuration's HBM traffic and SQ counters with rocprofv3 --pmc passes of this script (child "
+                         "processes, a few minutes) and write profiles/pmc_traffic.json, which later runs of the same configuration quote")
     ap.add_argument("--cpu-n", type=int, default=0, help="grid size of the CPU sample (default: --n)")
     return ap.parse_args()
 
@@ -203,6 +207,8 @@ def all_cores_leg(harness, tmp, box, uvb3, phi, theta, w, cores_usable):
 
 def main():
     a = parse()
+    if a.measure_traffic:
+        return measure_traffic(a)
     import torch
     import torch.distributed as dist
     import radiativetransfer_amd as rt
@@ -342,10 +348,14 @@ def main():
         parallelism = f"weak: {a.ndir} directions per rank, RCCL all-reduce of J"
     else:
         parallelism = f"{world} ranks = " + shard.describe("combine" if a.exchange == "gather" else "exchange") + " (RCCL)"
-    kernel = "ftte::brick_kernel (all stage launches of a sweep, two streams)" if len(eng.launch_records()) == 1 else "ftte::sweep_kernel"
-    traffic = pmc_traffic(n, nnu) if (world == 1 and total_dirs == 96 and len(eng.launch_records()) == 1) else None
+    bricks = len(eng.launch_records()) == 1
+    form = eng.counter("brick_form") if bricks else -1
+    kernel = ("ftte::brick_pair_kernel" if form == 2 else "ftte::brick_kernel") + " (all stage launches of a sweep)" if bricks else "ftte::sweep_kernel"
+    pmc = pmc_record(config_key(a, n, nnu, total_dirs, world)) if bricks else None
+    traffic = pmc["hbm_bytes_per_launch"] if pmc else None
     avg_launch_ms = launch_ms / nlaunch if nlaunch else None
-    # what the counters say the kernel really moved per second: the kernel-quality figure beside the contract's algorithmic one
+    # what the counters say the kernel really moved per second: the roofline fraction proper (the 24-byte figure of the contract is
+    # not a lower bound for a kernel whose directions share the opacity load and the J store)
     moved = traffic / (avg_launch_ms * 1e-3) / 1e9 if (traffic and avg_launch_ms) else None
     out = {
         "metric": "cell·dir·ν updates/sec per iteration, 256³ grid; achieved HBM GB/s vs peak",
@@ -359,15 +369,22 @@ def main():
                    "parallelism": parallelism,
                    "compute_ms_per_step": compute_ms / a.steps, "collective_ms_per_step": collective_ms / a.steps},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": moved / HBM_PEAK_GBS if moved else None,
+                     "frac_contract_24B": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic,
+                     "traffic_source": (pmc["source"] + " (committed rocprofv3 --pmc passes of this configuration, not this run)") if pmc else None,
                      "kernel": kernel, "launches": nlaunch,
                      "avg_launch_ms": avg_launch_ms,
                      "bytes_per_update": BYTES_PER_UPDATE,
-                     "moved_GBs": moved, "moved_frac": moved / HBM_PEAK_GBS if moved else None,
-                     "note": "achieved = 24 B x updates of rank 0's sweep launches / their HIP-event time (24 B is the per-update "
-                             "figure of a kernel that reads kappa and read-modify-writes J per direction; the brick kernel shares "
-                             "both between the directions of a group, so frac can pass 1); moved_GBs = PMC traffic of the same "
-                             "launches / the same time: what the memory system actually delivered (DESIGN.md 3, 6)"},
+                     "moved_GBs": moved,
+                     "valu_busy": pmc.get("valu_busy_fraction") if pmc else None,
+                     "valu_instructions_per_update": pmc.get("valu_instructions_per_update") if pmc else None,
+                     "note": "achieved = 24 B x updates of rank 0's sweep launches / their HIP-event time: the contract's algorithmic "
+                             "figure (SURVEY.md 8(d)); 24 B is what a kernel pays that reads kappa and read-modify-writes J per "
+                             "direction, NOT a lower bound for the brick kernel, whose directions share both, so frac_contract_24B "
+                             "can pass 1.  frac = moved_GBs / peak, moved_GBs = HBM bytes of the same launches from the PMC counters "
+                             "(traffic; FETCH_SIZE doubled per the guide, + WRITE_SIZE) / the same HIP-event time: what the memory "
+                             "system delivered.  null where no committed counter pass matches this configuration (options, sharding)."},
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cn = a.cpu_n or n
@@ -382,17 +399,85 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(n, nnu):
-    """HBM bytes per sweep-kernel launch from the committed rocprofv3 --pmc passes (profiles/), if one matches this
-    workload; bench.py cannot collect counters itself."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+SWEEP_OPTIONS = ("rows", "slots", "waves", "engine", "chunk", "group", "brick_waves", "tiled", "pair_waves", "team", "share", "dataflow", "ldspad")
+
+
+def config_key(a, n, nnu, ndir, world):
+    """What decides the sweep kernel's traffic: the workload and every option that shapes the sweep (streams do not: a counter pass
+    runs with --lanes 1 so that dispatches do not overlap)."""
+    opts = {k: getattr(a, k) for k in SWEEP_OPTIONS}
+    opts["opt"] = sorted(a.opt)
+    return {"grid": n, "nnu": nnu, "ndir": ndir, "world": world, "weak": bool(a.weak), "options": opts}
+
+
+def pmc_record(key):
+    """The committed counter record (profiles/pmc_traffic.json, written by --measure-traffic) if it was taken for exactly this
+    configuration; None otherwise: a bench line never quotes traffic measured on another kernel form or option set."""
     try:
-        rec = json.load(open(path))
-        if rec.get("grid") == n and rec.get("nnu") == nnu:
-            return rec.get("hbm_bytes_per_launch")
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if rec.get("key") == key and rec.get("hbm_bytes_per_launch"):
+            return rec
     except Exception:
         pass
     return None
+
+
+def measure_traffic(a):
+    """rocprofv3 --pmc passes over one sweep of this configuration (separate passes, counters only: FETCH_SIZE, WRITE_SIZE, two SQ
+    sets), summed over the sweep kernel's dispatches; FETCH_SIZE doubled (gfx950 tallies 128-byte read requests at 64 B,
+    MI355X_MICROARCH.md).  Children of this process; needs a GPU box with rocprofv3."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    n, nnu, ndir = a.n, a.nnu, a.ndir
+    passes = {"FETCH_SIZE": ["FETCH_SIZE"], "WRITE_SIZE": ["WRITE_SIZE"],
+              "SQ": ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE"],
+              "SQ2": ["SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_INSTS_SMEM"]}
+    fwd = ["--grid", str(n), "--nnu", str(nnu), "--ndir", str(ndir), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--lanes", "1"]
+    for k in SWEEP_OPTIONS:
+        v = getattr(a, k)
+        if v not in (0, -1):
+            fwd += ["--" + k.replace("_", "-"), str(v)]
+    for kv in a.opt:
+        fwd += ["--opt", kv]
+    out = os.path.join(ROOT, "gpurun_out", "pmc_traffic")
+    shutil.rmtree(out, ignore_errors=True)
+    env = dict(os.environ, TMPDIR="/tmp")
+    totals, ndisp = {}, 0
+    for name, counters in passes.items():
+        d = os.path.join(out, name)
+        cmd = ["rocprofv3", "--pmc", *counters, "--kernel-include-regex", "brick_|sweep_kernel", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+               "python3", os.path.abspath(__file__), *fwd]
+        res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=900)
+        if res.returncode:
+            sys.exit(f"[bench] counter pass {name} failed:\n{res.stderr[-2000:]}")
+        tot, disp = collections.defaultdict(float), set()
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                tot[r["Counter_Name"]] += float(r["Counter_Value"])
+                disp.add(r["Dispatch_Id"])
+        totals.update(tot)
+        ndisp = max(ndisp, len(disp))
+    updates = n ** 3 * nnu * ndir
+    rec = {"key": config_key(a, n, nnu, ndir, 1), "source": "profiles/pmc_traffic.json", "command": "bench.py --measure-traffic " + " ".join(fwd),
+           "unit": "one sweep = all sweep-kernel dispatches of an iteration (bench.py's launch record)", "dispatches_per_sweep": ndisp,
+           "updates_per_sweep": updates, "counters": dict(totals)}
+    rec["fetch_bytes_x2"] = 2 * 1024 * totals["FETCH_SIZE"]      # KB; doubled per the guide
+    rec["write_bytes"] = 1024 * totals["WRITE_SIZE"]
+    rec["hbm_bytes_per_launch"] = rec["fetch_bytes_x2"] + rec["write_bytes"]
+    rec["hbm_bytes_per_update"] = rec["hbm_bytes_per_launch"] / updates
+    cycles = totals["GRBM_GUI_ACTIVE"] / 8
+    rec["valu_instructions_per_update"] = totals["SQ_INSTS_VALU"] * 64 / updates
+    rec["salu_instructions_per_update"] = totals["SQ_INSTS_SALU"] * 64 / updates
+    rec["valu_busy_fraction"] = totals["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / cycles
+    rec["mean_waves_per_simd"] = totals["SQ_WAVE_CYCLES"] * 4 / 1024 / cycles
+    rec["wave_time_in_waitcnt"] = totals["SQ_WAIT_ANY"] / totals["SQ_WAVE_CYCLES"]
+    rec["wave_time_waiting_to_issue"] = totals["SQ_WAIT_INST_ANY"] / totals["SQ_WAVE_CYCLES"]
+    rec["wave_time_issuing"] = totals["SQ_ACTIVE_INST_ANY"] / totals["SQ_WAVE_CYCLES"]
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    json.dump(rec, open(path, "w"), indent=1)
+    print(json.dumps({k: v for k, v in rec.items() if k != "counters"}, indent=1))
 
 
 if __name__ == "__main__":

@@ -319,8 +319,11 @@ int ftte_set_option(ftte_ctx *c, const char *key, int value)
         if (value < 1 || value > ftte_ctx::kMaxPipes) return fail(c, FTTE_ERR_ARG, "pipelines (independent bricks-forests-bricks sequences of the hybrid sweep, each on a stream of its own) must be 1..4");
         c->halves = value;
         c->hplan.valid = false;
+    } else if (!std::strcmp(key, "atomic_acc")) {
+        if (value < 0 || value > 1) return fail(c, FTTE_ERR_ARG, "atomic_acc must be 0 or 1");
+        c->atomic_acc = value;
     } else if (!std::strcmp(key, "ablate")) {
-        if (value < 0 || value > 15) return fail(c, FTTE_ERR_ARG, "ablate is a mask of 4 bits");
+        if (value < 0 || value > 63) return fail(c, FTTE_ERR_ARG, "ablate is a mask of 6 bits");
         c->ablate = value;
     } else if (!std::strcmp(key, "queue_mix")) {
         if (value < 0 || value > 2) return fail(c, FTTE_ERR_ARG, "queue_mix must be 0, 1 or 2");

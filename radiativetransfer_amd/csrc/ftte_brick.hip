@@ -260,6 +260,7 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
     const int tv = MASKED ? tv_field & kBrickTvMask : tv_field, box = MASKED ? (tv_field >> kBrickBoxShift) & kBrickBoxMask : 0;
     const int ti = uniform((int)T.ti) & (kBrickAccumulate - 1);
     const bool accumulate = (uniform((int)T.ti) & kBrickAccumulate) != 0 && !(L.pad2_ & 4);
+    const bool atomic_acc = L.atomic_acc != 0 && !through;
     cgroup *G = (cgroup *)(L.groups + (MASKED ? group_field & kBrickGroupMask : group_field));
     const int n = L.n, chunk = L.chunk, up = L.up, vp = L.vp;
     const int ndir = G->ndir;
@@ -286,7 +287,8 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
     const int i1 = (i0 + chunk - 1 < n) ? i0 + chunk - 1 : n;
 
     // (pad2_: diagnostic option "ablate" -- WRONG RESULTS, timing only: bit 0 no rays taken from the left and from below, bit 1 none
-    // handed to the right and above, bit 2 no earlier J read, bit 3 no rays taken from or left for the chunks before and after)
+    // handed to the right and above, bit 2 no earlier J read, bit 3 no rays taken from or left for the chunks before and after,
+    // bit 4 the opacities of a brick's first layer for all its layers, bit 5 no J stored)
     const int ablate = L.pad2_;
     const bool has_u_in = (tu > 0 || lane_lo > 0) && !(ablate & 1), has_u_out = (64 * (tu + 1) < n || lane_hi < 63) && !(ablate & 2);
     const bool has_v_in = tv > 0 && !(ablate & 1), has_v_out = R * (tv + 1) < n && !(ablate & 2);
@@ -388,8 +390,10 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
         for (int r = 0; r < R; ++r) { kap[r] = kap_next[r]; Jacc[r] = 0.0; if (EMIT) { const int row = (cv0 + r < n) ? cv0 + r : n; xs[r] = *(gcdouble *)(xbase + 8l * i * si + row * row_bytes + off0); } }
         gbyte *jplane = jbase + 8l * i * si;
         const long rstep = here(row_bytes); // (per layer: the seven steps of a ragged brick are then not kept, and spilled, for the whole run)
-        if (accumulate) load_rows<R, true>(Jacc, (gcbyte *)jplane + row0, off0, rstep, nrows); // what the groups before this one left in these cells
-        if (i < i1) load_rows<R, false>(kap_next, kbase + 8l * (i + 1) * si + row0, off0, rstep, nrows);
+        // what the groups before this one left in these cells: read now and added to (the wavefront waits for it at its first sum), or
+        // -- BrickLaunch::atomic_acc -- left where it is and added to by the memory system when the layer's sums are stored
+        if (accumulate && !atomic_acc) load_rows<R, true>(Jacc, (gcbyte *)jplane + row0, off0, rstep, nrows);
+        if (i < i1 && !(ablate & 16)) load_rows<R, false>(kap_next, kbase + 8l * (i + 1) * si + row0, off0, rstep, nrows);
         for (int j = 0; j < ndir; ++j) {
             int d = p0 + j;
             d = d >= ndir ? d - ndir : d;
@@ -426,13 +430,14 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
         }
         p0 = p0 ? p0 - 1 : ndir - 1;
         // the group's contribution to J of this layer's cells: stored once, read only by the merge
-        if (own_lane) {
+        if (own_lane && !(ablate & 32)) {
             gbyte *jrow = jplane + row0;
             const unsigned off = here(off0);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 if (r < nrows) {
                     if (through) __hip_atomic_store((double *)(jrow + off0), Jacc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else if (accumulate && atomic_acc) (void)__builtin_amdgcn_global_atomic_fadd_f64((gdouble *)lane_address(jrow, off), Jacc[r]);
                     else __builtin_nontemporal_store(Jacc[r], (gdouble *)lane_address(jrow, off));
                 }
                 jrow += rstep;
@@ -494,6 +499,7 @@ __global__ void __launch_bounds__(128, WAVES) brick_pair_kernel(const BrickLaunc
     const BrickTask T = L.tasks[blockIdx.x / nnu];
     const int tu = uniform((int)T.tu), tv = uniform((int)T.tv), ti = uniform((int)T.ti) & (kBrickAccumulate - 1);
     const bool accumulate = (uniform((int)T.ti) & kBrickAccumulate) != 0;
+    const bool atomic_acc = L.atomic_acc != 0;
     cgroup *G = (cgroup *)(L.groups + uniform((int)T.group));
     const int n = L.n, chunk = L.chunk, up = L.up, vp = L.vp;
     const int ndir = G->ndir;
@@ -565,7 +571,7 @@ __global__ void __launch_bounds__(128, WAVES) brick_pair_kernel(const BrickLaunc
             for (int r = 0; r < H; ++r) { kap[r] = kap_next[r]; Jacc[r] = 0.0; }
             const long rstep = here(row_bytes);
             if (EMIT) load_rows<EMIT ? H : 1, false>(xs, xbase + 8l * i * si + row0, off0, rstep, nrows); // the layer's emissivities or source functions
-            if (accumulate) load_rows<H, true>(Jacc, (gcbyte *)jplane + row0, off0, rstep, nrows);
+            if (accumulate && !atomic_acc) load_rows<H, true>(Jacc, (gcbyte *)jplane + row0, off0, rstep, nrows);
             if (i < i1) load_rows<H, false>(kap_next, kbase + 8l * (i + 1) * si + row0, off0, rstep, nrows);
             double *hand = handover + (size_t)(il & 1) * max_dirs * 64;
             for (int j = 0; j < ndir; ++j) {
@@ -610,7 +616,10 @@ __global__ void __launch_bounds__(128, WAVES) brick_pair_kernel(const BrickLaunc
                 const unsigned off = here(off0);
 #pragma unroll
                 for (int r = 0; r < H; ++r) {
-                    if (r < nrows) __builtin_nontemporal_store(Jacc[r], (gdouble *)lane_address(jrow, off));
+                    if (r < nrows) {
+                        if (accumulate && atomic_acc) (void)__builtin_amdgcn_global_atomic_fadd_f64((gdouble *)lane_address(jrow, off), Jacc[r]);
+                        else __builtin_nontemporal_store(Jacc[r], (gdouble *)lane_address(jrow, off));
+                    }
                     jrow += rstep;
                 }
             }

@@ -157,6 +157,7 @@ struct ftte_ctx {
     // waiting for each other through flags (cross-XCD hand-overs: L2 write-back per brick, or write-through stores); 3 = one launch of
     // persistent workgroups that draw bricks from a queue per XCD (hand-overs stay behind one L2: plain stores)
     int dataflow = 0;
+    int atomic_acc = 0;               // option "atomic_acc": later visitors of an accumulator add with fp64 atomics instead of read-add-store
     int ablate = 0;                   // diagnostic option "ablate": parts of the brick kernel's memory traffic left out (wrong J; timing only)
     int queue_mix = 0;                // persistent form: 0 = a frequency group per queue where they divide, else by load; 1 = by load; 2 = (group + accumulator) mod queues
     int32_t *d_bdeps = nullptr; size_t d_bdeps_cap = 0;

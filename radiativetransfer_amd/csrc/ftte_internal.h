@@ -152,6 +152,10 @@ struct BrickLaunch {
     const uint32_t *queue;                        // work ids (task index * nnu + frequency slot), queue after queue, each in stage order
     uint32_t qoff[kBrickQueues], qlen[kBrickQueues];
     int8_t xcc_queue[16];                         // XCC id -> queue, from the census of the device's XCC ids (-1: an id the census did not see)
+    // A brick that comes second to an accumulator's cells (kBrickAccumulate) adds its sums with fp64 atomic adds instead of reading
+    // the earlier ones first: nothing to wait for.  One brick per cell and launch (or, in one launch, in dependency order), so the
+    // additions still happen in a fixed order: J stays reproducible bit for bit.
+    int32_t atomic_acc, pad3_;
     ftte_consts math;
 };
 

@@ -118,15 +118,6 @@ FTTE_HD void ftte_attenuation(const ftte_consts *K, double tau, double *e_out, d
     (void)ftte_attenuation_lead(K, K->c[9], tau, e_out, g_out);
 }
 
-/* `lead`: the polynomial's leading coefficient, K->c[9], handed in by the caller.  A device kernel that keeps it in a vector
- * register for its whole run saves the move every first Horner step otherwise starts with (an instruction reads one scalar
- * operand: c9 * r + c8 with both coefficients in scalar registers needs one of them copied first).
- *
- * Returns whether any lane of the wavefront (on the host: this evaluation) left the thin range tau < ln2/2, where n = 0,
- * exp(-tau) = exp(r) needs no scaling and g is the polynomial itself.  Everything the other lanes need -- the range reduction,
- * the scaling by 2^n, the floor at exp(-1000) = 0, the division -- is done behind that one test, so a wavefront of thin segments
- * (five in six of the benchmark's) executes the test, eleven fused multiply-adds, and nothing else.  The values are
- * those of the straightforward form x = max(-tau, x_floor), e = ldexp(exp(r), n), g = n ? (1 - e)/tau : expm1(r)/r. */
 /* The range reduction.  n = rint(-tau log2e) is 0 exactly for |tau| <= thin_max (the product is monotonic in tau, the bound is the
  * last tau whose rounded product rounds to 0): a wavefront of such segments needs no reduction at all, and the test of the
  * wavefront is one comparison of tau itself.  The polynomial's argument is carried with the opposite sign, t = -r = tau + n ln2,
@@ -177,6 +168,15 @@ FTTE_HD void ftte_thick_part(const ftte_consts *K, double tau, double *e_io, dou
     *e_io = e;
 }
 
+/* `lead`: the polynomial's leading coefficient, K->c[9], handed in by the caller.  A device kernel that keeps it in a vector
+ * register for its whole run saves the move every first Horner step otherwise starts with (an instruction reads one scalar
+ * operand: c9 * r + c8 with both coefficients in scalar registers needs one of them copied first).
+ *
+ * Returns whether any lane of the wavefront (on the host: this evaluation) left the thin range |tau| <= thin_max, where n = 0,
+ * exp(-tau) = exp(r) needs no scaling and g is the polynomial itself.  Everything the other lanes need -- the range reduction,
+ * the scaling by 2^n, the floor at exp(-1000) = 0, the division -- is done behind that one test, so a wavefront of thin segments
+ * (five in six of the benchmark's) executes the test, eleven fused multiply-adds, and nothing else.  The values are
+ * those of the straightforward form x = max(-tau, x_floor), e = ldexp(exp(r), n), g = n ? (1 - e)/tau : expm1(r)/r. */
 FTTE_HD int ftte_attenuation_lead(const ftte_consts *K, double lead, double tau, double *e_out, double *g_out)
 {
     if (ftte_all_thin(K, tau)) {
@@ -189,6 +189,57 @@ FTTE_HD int ftte_attenuation_lead(const ftte_consts *K, double lead, double tau,
     *e_out = e;
     *g_out = g;
     return 1;
+}
+
+/* The attenuation pairs of the two (three) segments of ONE cell -- one opacity, the path lengths of the ray's pieces -- behind one
+ * test of the wavefront, the polynomials in one block: the chains are independent of each other (and of the intensities), so the
+ * instruction scheduler interleaves them, and a wavefront issues two (three) dependent chains instead of one.  Same values as one
+ * call of ftte_attenuation_lead per segment. */
+FTTE_HD int ftte_attenuation2(const ftte_consts *K, double lead, double tau0, double tau1, double *e, double *g)
+{
+    if (__builtin_expect(!FTTE_ANY(!(__builtin_fabs(tau0) <= K->thin_max) || !(__builtin_fabs(tau1) <= K->thin_max)), 1)) {
+        ftte_exp_reduced(K, lead, tau0, &e[0], &g[0]);
+        ftte_exp_reduced(K, lead, tau1, &e[1], &g[1]);
+        return 0;
+    }
+    ftte_exp_reduced(K, lead, ftte_reduce(K, tau0), &e[0], &g[0]);
+    ftte_thick_part(K, tau0, &e[0], &g[0]);
+    ftte_exp_reduced(K, lead, ftte_reduce(K, tau1), &e[1], &g[1]);
+    ftte_thick_part(K, tau1, &e[1], &g[1]);
+    return 1;
+}
+
+FTTE_HD int ftte_attenuation3(const ftte_consts *K, double lead, double tau0, double tau1, double tau2, double *e, double *g)
+{
+    if (__builtin_expect(!FTTE_ANY(!(__builtin_fabs(tau0) <= K->thin_max) || !(__builtin_fabs(tau1) <= K->thin_max) ||
+                                   !(__builtin_fabs(tau2) <= K->thin_max)), 1)) {
+        ftte_exp_reduced(K, lead, tau0, &e[0], &g[0]);
+        ftte_exp_reduced(K, lead, tau1, &e[1], &g[1]);
+        ftte_exp_reduced(K, lead, tau2, &e[2], &g[2]);
+        return 0;
+    }
+    ftte_exp_reduced(K, lead, ftte_reduce(K, tau0), &e[0], &g[0]);
+    ftte_thick_part(K, tau0, &e[0], &g[0]);
+    ftte_exp_reduced(K, lead, ftte_reduce(K, tau1), &e[1], &g[1]);
+    ftte_thick_part(K, tau1, &e[1], &g[1]);
+    ftte_exp_reduced(K, lead, ftte_reduce(K, tau2), &e[2], &g[2]);
+    ftte_thick_part(K, tau2, &e[2], &g[2]);
+    return 1;
+}
+
+/* The segment itself, given its attenuation pair: what ftte_segment_lead does behind the pair.  `thick`: some lane of the
+ * wavefront (or some segment of the cell) left the thin range; only then can a nonzero Iin end as Iout = 0. */
+FTTE_HD double ftte_segment_apply(double *I, double e, double g, int thick)
+{
+    const double Iin = *I;
+    const double Iout = Iin * e;
+    double mean = Iin * g;
+    if (thick) {
+        mean = (Iout == 0.0) ? 0.0 : mean;
+        FTTE_KEEP(mean);
+    }
+    *I = Iout;
+    return mean;
 }
 
 /* One segment: advances the ray intensity and returns the path-mean intensity

@@ -625,6 +625,7 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
             L.math = kMath;
             L.tiled = tiled ? 1 : 0;
             L.pad2_ = c->ablate;
+            L.atomic_acc = c->atomic_acc;
             int persistent = 0;
             if (P.persistent) {
                 L.queue = c->d_bqueue;
@@ -683,6 +684,7 @@ int brick_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, c
                 L.math = kMath;
                 L.tiled = tiled ? 1 : 0;
                 L.pad2_ = c->ablate;
+                L.atomic_acc = c->atomic_acc;
                 const int form = brick_form(c, nnu);
                 c->last_brick_form = form;
                 const int lrc = form == 2 ? launch_brick_pair(L, P.max_dirs, c->pair_waves, q) : launch_brick(L, P.max_dirs, c->brick_waves, q);

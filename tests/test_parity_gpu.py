@@ -490,3 +490,76 @@ def test_baseline_size_slab_against_oracle(engine, big):
         Jh = J[[0, 7]].cpu().numpy()
         ref = O.sweep_uniform(n, big["kappa"][[0, 7]], big["box"], phi, theta, w, big["uvb"][[0, 7]], arith=O.ARITH_DEVICE)
         assert np.array_equal(Jh, ref)
+
+
+# ---- BASELINE configs[2] (192 directions) and the shapes an 8-rank run executes, at full size -------------------------------------
+
+def _all_192(big):
+    import radiativetransfer_amd as rt
+    ang = np.array([rt.pix2ang_nest(4, i) for i in range(192)])
+    return dict(big, phi=ang[:, 0].copy(), theta=ang[:, 1].copy(), w=np.full(192, 1 / 192))
+
+
+def test_config3_192_directions_at_full_size(engine, big, organisation):
+    """BASELINE configs[2]'s workload on one GPU: 256^3 x 8 groups x all 192 directions of nside 4 (equiSources.f90:1385-1391) --
+    reproducible bit for bit, exactly linear in the inflow, bounded by it; and the first 96 directions of the same list, swept
+    alone with the weights of the 192-set, plus the other 96 swept alone, add up to the whole (J = sum over directions,
+    transportRoutinesModule.f90:953-955) to the rounding of the sum."""
+    import torch
+    if organisation == "tiles":
+        pytest.skip("the full 192-direction sweep is run once, with the default organisation")
+    b = _all_192(big)
+    J1 = _sweep_dev(engine, b, b["uvb"], ndir=192)
+    assert torch.equal(J1, _sweep_dev(engine, b, b["uvb"], ndir=192))
+    assert torch.equal(_sweep_dev(engine, b, 2.0 * b["uvb"], ndir=192), 2.0 * J1)
+    cap = torch.from_numpy(b["uvb"]).to(J1.device)[:, None] * (1 + 1e-12)
+    assert bool(torch.all(J1 > 0)) and bool(torch.all(J1 <= cap))
+    # a direction-split pair of ranks (2 x 96): their sum is the unsharded J
+    Ja = _sweep_dev(engine, b, b["uvb"], ndir=96)
+    second = dict(b, phi=b["phi"][96:], theta=b["theta"][96:], w=b["w"][96:])
+    Jb = _sweep_dev(engine, second, b["uvb"], ndir=96)
+    assert torch.allclose(Ja + Jb, J1, rtol=SUM_RTOL, atol=0)
+
+
+def test_every_rank_share_of_an_eight_rank_run_at_full_size(engine, big, organisation):
+    """What rank r of an N = 8 run of configs[2] executes (radiativetransfer_amd/distributed.py: Shard2D with 8 groups on 8 ranks):
+    ONE frequency group, all 192 directions -- nnu_local = 1, so the planner takes short bricks, the pair form and direction
+    groups dealt to streams.  Each of the eight shares equals the matching group of the unsharded sweep to the rounding of the sum
+    over directions -- NOT bit for bit: frequency groups never meet inside the sweep and the direction groups are the same, but the
+    order in which the (up to six) groups of a shared accumulator visit a cell follows the brick length, which the planner shortens
+    for a single frequency group (measured: the first share already differs in last bits)."""
+    import torch
+    if organisation == "tiles":
+        pytest.skip("the rank shapes are those of the default organisation")
+    b = _all_192(big)
+    J_all = _sweep_dev(engine, b, b["uvb"], ndir=192)
+    for nu in range(b["nnu"]):
+        engine.set_opacity_device(1, b["k_dev"][nu:nu + 1].contiguous().data_ptr())
+        J = torch.empty((1, b["n"] ** 3), dtype=torch.float64, device="cuda:0")
+        engine.transport_device(b["phi"], b["theta"], b["w"], b["uvb"][nu:nu + 1], J.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert engine.counter("brick_form") == 2            # the pair form: this is the narrow-stage shape
+        assert torch.allclose(J[0], J_all[nu], rtol=SUM_RTOL, atol=0), nu
+    engine.set_opacity_device(b["nnu"], b["k_dev"].data_ptr())   # back to the module's eight groups
+    torch.cuda.synchronize()
+
+
+def test_baseline_size_several_directions_against_oracle(engine, big):
+    """Four directions at 256^3 on two frequency groups against the oracle (device arithmetic): three of one izone -- one pass of a
+    direction group, sharing opacity loads, J stores and an accumulator with the fourth's group where the planner pairs them --
+    and one of another izone.  To the rounding of the sum over directions (the planner adds in plan order)."""
+    import torch
+    n = big["n"]
+    zone = np.array([O.fold_direction(p, t)[2] for p, t in zip(big["phi"], big["theta"])])
+    zs, counts = np.unique(zone, return_counts=True)
+    z0 = zs[np.argmax(counts >= 3)]
+    first = np.flatnonzero(zone == z0)[:3]
+    other = np.flatnonzero(zone != z0)[:1]
+    pick = np.concatenate([first, other])
+    phi, theta, w = big["phi"][pick], big["theta"][pick], big["w"][pick]
+    J = torch.empty((big["nnu"], n ** 3), dtype=torch.float64, device="cuda:0")
+    engine.transport_device(phi, theta, w, big["uvb"], J.data_ptr(), 0)
+    torch.cuda.synchronize()
+    Jh = J[[0, 7]].cpu().numpy()
+    ref = O.sweep_uniform(n, big["kappa"][[0, 7]], big["box"], phi, theta, w, big["uvb"][[0, 7]], arith=O.ARITH_DEVICE)
+    assert np.allclose(Jh, ref, rtol=SUM_RTOL, atol=0)
