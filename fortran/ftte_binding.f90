@@ -30,6 +30,11 @@ module ftte_binding
        type(c_ptr), value :: ctx
      end function ftte_last_error
 
+     type(c_ptr) function ftte_multi_info(ctx) bind(C, name='ftte_multi_info')
+       import :: c_ptr
+       type(c_ptr), value :: ctx
+     end function ftte_multi_info
+
      integer(c_int) function ftte_set_grid(ctx, nx, ny, nz, ncell, level, box_cm) bind(C, name='ftte_set_grid')
        import :: c_ptr, c_int, c_int64_t, c_int32_t, c_double
        type(c_ptr), value :: ctx

@@ -17,6 +17,9 @@ module ftte_uvb_transfer
   implicit none
 
   type(c_ptr), save, private :: ctx = c_null_ptr
+  ! Several GPUs under the one serial host: allocate and fill before the first call, e.g. ftteDevices = (/ (i, i = 0, 7) /);
+  ! the library then splits the frequency groups and the directions over them and sums J itself (include/ftte.h: ftte_create).
+  integer(c_int), allocatable, target, save, public :: ftteDevices(:)
   integer(c_int64_t), private :: cursor
   ! The flattened cell array is kept from call to call (the reference's tree is static over a run) and pinned, so that
   ! kappa and J cross PCIe by DMA straight from / into these arrays; the library for its part keeps the tree, the sweep
@@ -34,7 +37,13 @@ contains
     integer :: i, j, k, ndir, nside
     integer(kind=8) :: iray
 
-    if (.not. c_associated(ctx)) call ftteCheck(c_null_ptr, ftte_create(ctx, 1, c_null_ptr), 'ftte_create')
+    if (.not. c_associated(ctx)) then
+       if (allocated(ftteDevices)) then
+          call ftteCheck(c_null_ptr, ftte_create(ctx, size(ftteDevices), c_loc(ftteDevices)), 'ftte_create')
+       else
+          call ftteCheck(c_null_ptr, ftte_create(ctx, 1, c_null_ptr), 'ftte_create')
+       endif
+    endif
 
     ncell = 0
     do i = 1, nx

@@ -56,10 +56,24 @@ typedef enum {
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
 
-/* One context drives one device. ndev must be 1 (dev_ids[0] = HIP device ordinal; dev_ids may
- * be NULL for the current device): multi-GPU runs use one process and one context per GPU and
- * reduce J with RCCL in the host driver. */
+/* ndev = 1: one context drives one device (dev_ids[0] = HIP device ordinal; dev_ids may be NULL for the current device).
+ *
+ * ndev > 1: ONE context, driven by the one host thread the reference is (its direction loop, equiSources.f90:1385-1391, is serial;
+ * the directions' only coupling is the sum transportRoutinesModule.f90:953-955), sweeps on dev_ids[0 .. ndev-1].  Such a context
+ * takes HOST arrays: ftte_set_grid, ftte_set_opacity, ftte_set_emissivity / ftte_set_source_function, ftte_diffuse_sweep,
+ * ftte_diffuse_iteration (plus ftte_set_option, ftte_host_register / _unregister, ftte_counter, ftte_launch_info for the first
+ * device's share, ftte_last_error, ftte_destroy); every other entry point returns FTTE_ERR_UNSUPPORTED on it.  The work is split
+ * frequency groups first, then directions: with r_nu = gcd(ndev, groups) and r_dir = ndev / r_nu, device k sweeps the groups of
+ * frequency slice k mod r_nu for the directions of slice k div r_nu.  A frequency-sharded J_nu is complete where it is computed
+ * (8 groups on 8 devices: nothing is exchanged, every device sends its groups home); where directions are split too, the r_dir
+ * devices that hold the same groups sum their J by a reduce-scatter over RCCL (librccl.so, loaded on first need) and each sends
+ * its piece home.  Where RCCL cannot serve (two entries of dev_ids name the same device -- a test on a one-GPU box --, or no
+ * library) the pieces are summed by a kernel that reads the partners' buffers in place; ftte_multi_info says which.
+ * J equals the single-device J to the rounding of the sum over directions.  The other way to many GPUs -- one process and one
+ * context per GPU, J combined by the host driver (radiativetransfer_amd/distributed.py over torch.distributed) -- stays. */
 int ftte_create(ftte_ctx **ctx, int ndev, const int *dev_ids);
+/* How the last sweep of a multi-device context combined its devices' J, in words ("" for a single-device context). */
+const char *ftte_multi_info(const ftte_ctx *ctx);
 int ftte_destroy(ftte_ctx *ctx);
 /* Message of the last failing call on this context ("" if none); ctx may be NULL for the
  * message of the last failing ftte_create. */
@@ -303,7 +317,9 @@ int ftte_host_unregister(ftte_ctx *ctx, void *ptr);
  * planner), "forest_builds" (per-direction segment forests of a refined cell array); of the hybrid sweep's current plan, "hybrid_boxes"
  * (boxes around clusters of refined cells, of the izone that has most) and "hybrid_passes" (passes their forests are swept in), 0
  * when the last sweep did not take the hybrid path; "brick_form": the form of the brick kernel the last uniform-grid sweep of the
- * brick engine took (option "team": 0 or 2; -1 before the first).  -1 for an unknown name. */
+ * brick engine took (option "team": 0 or 2; -1 before the first); "devices"; of a multi-device context also "frequency_slices",
+ * "direction_slices" and "multi_rccl" (1: the last direction-split sweep was summed over RCCL), the rest from its first device.
+ * -1 for an unknown name. */
 long long ftte_counter(const ftte_ctx *ctx, const char *name);
 
 /* Tuning knobs.  0 means "automatic" where noted.  Results do not depend on any of them except through the order in which the
@@ -333,7 +349,12 @@ long long ftte_counter(const ftte_ctx *ctx, const char *name);
  *                   than issuing them on this runtime)
  *     "forest_batch" most directions per launch of the segment forests (0: what the path and the device memory allow)
  *     "forest"      1: use the segment forests on a uniform grid too, for cross-checks
- *   "ldspad"        diagnostic: extra dynamic LDS per workgroup (bytes), to cap residency */
+ *   "ldspad"        diagnostic: extra dynamic LDS per workgroup (bytes), to cap residency
+ *   "atomic_acc"    bricks: 1 = later visitors of a shared accumulator add with fp64 atomics instead of read-add-store (default 0)
+ *   "queue_mix"     bricks, dataflow = 3: how (frequency group, accumulator) units are dealt to the XCDs' queues: 0 a frequency
+ *                   group per queue where they divide, 1 by load, 2 (group + accumulator) mod queues
+ *   "ablate"        diagnostic, WRONG RESULTS, timing only: mask of parts of the brick kernel's memory traffic to leave out
+ *   multi-device contexts: every option goes to every device; "multi_reduce" 1 = always sum direction slices with the peer kernel */
 int ftte_set_option(ftte_ctx *ctx, const char *key, int value);
 /* Launch records of the last sweep (valid after the sweep's stream has been synchronised).
  * Each sweep-kernel launch is bracketed by HIP events on the stream it runs on. */

@@ -37,6 +37,7 @@ SIGNATURES = {
     "ftte_create": (C.c_int, [C.POINTER(_vp), C.c_int, _ip]),
     "ftte_destroy": (C.c_int, [_vp]),
     "ftte_last_error": (C.c_char_p, [_vp]),
+    "ftte_multi_info": (C.c_char_p, [_vp]),
     "ftte_set_grid": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int32), C.c_double]),
     "ftte_set_opacity": (C.c_int, [_vp, C.c_int, _dp]),
     "ftte_set_opacity_device": (C.c_int, [_vp, C.c_int, _vp]),

@@ -103,11 +103,19 @@ class DiffuseTransfer:
         J = rt.transport(phi, theta, weight, uvb)  # J[nnu][ncell], cell-array order
     """
 
-    def __init__(self, device: Optional[int] = None):
+    def __init__(self, device: Optional[int] = None, devices: Optional[Sequence[int]] = None):
+        """device: one HIP ordinal (default: the current device); devices: several ordinals -> ONE context that splits the sweep
+        over them (frequency groups first, then directions) and takes host arrays only (include/ftte.h: ftte_create)."""
         self._lib = _lib.load()
         self._ctx = C.c_void_p()
-        ids = (C.c_int * 1)(device) if device is not None else None
-        code = self._lib.ftte_create(C.byref(self._ctx), 1, ids)
+        if devices is not None and len(devices) > 1:
+            ids = (C.c_int * len(devices))(*devices)
+            code = self._lib.ftte_create(C.byref(self._ctx), len(devices), ids)
+        else:
+            if devices is not None:
+                device = devices[0]
+            ids = (C.c_int * 1)(device) if device is not None else None
+            code = self._lib.ftte_create(C.byref(self._ctx), 1, ids)
         if code:
             raise FtteError(code, self._lib.ftte_last_error(None).decode())
         self.n = 0
@@ -227,6 +235,10 @@ class DiffuseTransfer:
 
     def host_unregister(self, a: np.ndarray):
         self._ok(self._lib.ftte_host_unregister(self._ctx, C.c_void_p(a.ctypes.data)))
+
+    def multi_info(self) -> str:
+        """How the last sweep of a multi-device context combined its devices' J ("" for one device)."""
+        return self._lib.ftte_multi_info(self._ctx).decode()
 
     def counter(self, name: str) -> int:
         """grid_builds / plan_builds / forest_builds: how often the expensive host-side builds ran."""

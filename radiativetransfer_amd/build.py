@@ -16,7 +16,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libftte.so")
-SOURCES = ["ftte_kernels.hip", "ftte_brick.hip", "ftte_api.cpp", "ftte_plan.cpp", "ftte_sweeps.cpp", "ftte_hybrid.cpp", "ftte_host_arrays.cpp",
+SOURCES = ["ftte_kernels.hip", "ftte_brick.hip", "ftte_api.cpp", "ftte_plan.cpp", "ftte_sweeps.cpp", "ftte_hybrid.cpp", "ftte_multi.cpp", "ftte_host_arrays.cpp",
            "ftte_geometry.cpp", "ftte_amr.cpp", "ftte_point.cpp", "ftte_ingest.cpp"]
 HEADERS = ["ftte.map", "ftte_context.h", "ftte_internal.h", "ftte_kernels.h", "ftte_geometry.h", "ftte_math.h", "ftte_amr.h", "ftte_point.h", os.path.join("..", "..", "include", "ftte.h")]
 # -ffp-contract=off: the sweep arithmetic spells out its fused multiply-adds (ftte_math.h); nothing else may be fused,

@@ -34,10 +34,8 @@ int ftte_create(ftte_ctx **out, int ndev, const int *dev_ids)
 {
     if (!out) return fail(nullptr, FTTE_ERR_ARG, "ftte_create: ctx is NULL");
     *out = nullptr;
-    if (ndev != 1)
-        return fail(nullptr, FTTE_ERR_UNSUPPORTED,
-                    "ftte_create: one context drives one device (ndev must be 1); run one process per GPU and reduce J "
-                    "with RCCL in the host driver");
+    if (ndev > 1) return multi_create(out, ndev, dev_ids); // one single-device context per device behind this one (ftte_multi.cpp)
+    if (ndev != 1) return fail(nullptr, FTTE_ERR_ARG, "ftte_create: ndev must be at least 1");
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)
@@ -64,6 +62,7 @@ int ftte_create(ftte_ctx **out, int ndev, const int *dev_ids)
 int ftte_destroy(ftte_ctx *c)
 {
     if (!c) return FTTE_ERR_ARG;
+    if (c->multi) return multi_destroy(c);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (int l = 0; l < 3; ++l) {
@@ -127,12 +126,15 @@ int ftte_destroy(ftte_ctx *c)
 
 const char *ftte_last_error(const ftte_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
+const char *ftte_multi_info(const ftte_ctx *c) { return (c && c->multi) ? multi_how(c) : ""; }
+
 int ftte_set_grid(ftte_ctx *c, int nx, int ny, int nz, int64_t ncell, const int32_t *level, double box_cm)
 {
     if (!c) return FTTE_ERR_ARG;
     if (nx < 1 || !level || ncell < 1 || !(box_cm > 0.0)) return fail(c, FTTE_ERR_ARG, "ftte_set_grid: bad argument");
     if (nx != ny || nx != nz) return fail(c, FTTE_ERR_NOT_CUBIC, "base grid needs to be of size n^3");
     if (nx > 32000) return fail(c, FTTE_ERR_UNSUPPORTED, "ftte_set_grid: n > 32000");
+    if (c->multi) return multi_set_grid(c, nx, ny, nz, ncell, level, box_cm);
     // The reference's tree is static over a run while its driver would hand the same list over on every outer iteration
     // (the drop-ins do): an unchanged list keeps the tree, the sweep plan, the segment forests and the resident medium.
     // Only the box may differ (the plans are keyed on it themselves).
@@ -189,6 +191,7 @@ int ftte_set_grid(ftte_ctx *c, int nx, int ny, int nz, int64_t ncell, const int3
 
 int ftte_set_opacity(ftte_ctx *c, int nnu, const double *kappa)
 {
+    if (c && c->multi) return multi_set_opacity(c, nnu, kappa);
     int rc = check_ready(c, false);
     if (rc) return rc;
     if (nnu < 1 || !kappa) return fail(c, FTTE_ERR_ARG, "ftte_set_opacity: bad argument");
@@ -250,6 +253,7 @@ int ftte_set_species(ftte_ctx *c, int nnu, const double *HI, const double *HeI, 
 static int set_emission(ftte_ctx *c, int mode, const double *values, bool on_device, const char *who)
 {
     if (!c) return FTTE_ERR_ARG;
+    if (c->multi) return on_device ? fail(c, FTTE_ERR_UNSUPPORTED, std::string(who) + ": a multi-device context takes host arrays") : multi_set_emission(c, mode, values);
     if (!values) { c->emit_mode = 0; return FTTE_OK; }
     int rc = check_ready(c, true);
     if (rc) return rc;
@@ -274,6 +278,7 @@ int ftte_set_source_function_device(ftte_ctx *c, const double *S_dev) { return s
 int ftte_set_option(ftte_ctx *c, const char *key, int value)
 {
     if (!c || !key) return FTTE_ERR_ARG;
+    if (c->multi) return multi_set_option(c, key, value);
     if (!std::strcmp(key, "rows")) {
         if (value != 4 && value != 8 && value != 16) return fail(c, FTTE_ERR_ARG, "rows must be 4, 8 or 16");
         c->rows = value;
@@ -383,6 +388,7 @@ int ftte_diffuse_sweep_device(ftte_ctx *c, int ndir, const double *phi, const do
 int ftte_diffuse_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, const double *w, const double *uvb,
                        double *J)
 {
+    if (c && c->multi) return multi_sweep(c, ndir, phi, theta, w, uvb, J);
     int rc = check_ready(c, true);
     if (rc) return rc;
     if (!J) return fail(c, FTTE_ERR_ARG, "ftte_diffuse_sweep: J is NULL");
@@ -400,6 +406,7 @@ int ftte_diffuse_sweep(ftte_ctx *c, int ndir, const double *phi, const double *t
 int ftte_diffuse_iteration(ftte_ctx *c, int nnu, const double *kappa, int ndir, const double *phi, const double *theta, const double *w,
                            const double *uvb, double *J)
 {
+    if (c && c->multi) return multi_iteration(c, nnu, kappa, ndir, phi, theta, w, uvb, J);
     int rc = check_ready(c, false);
     if (rc) return rc;
     if (nnu < 1 || !kappa || !J || ndir < 0 || (ndir > 0 && (!phi || !theta || !w)) || !uvb)
@@ -434,9 +441,10 @@ int ftte_host_register(ftte_ctx *c, void *ptr, size_t bytes)
 {
     if (!c) return FTTE_ERR_ARG;
     if (!ptr || !bytes) return fail(c, FTTE_ERR_ARG, "ftte_host_register: bad argument");
+    if (c->multi) return multi_host_register(c, ptr, bytes, true);
     if (is_registered(c, ptr, bytes)) return FTTE_OK;
     FTTE_HIP(c, hipSetDevice(c->device));
-    FTTE_HIP(c, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    FTTE_HIP(c, hipHostRegister(ptr, bytes, hipHostRegisterPortable)); // (portable: pinned for every device of the process)
     c->registered.push_back({(const char *)ptr, bytes});
     return FTTE_OK;
 }
@@ -444,6 +452,7 @@ int ftte_host_register(ftte_ctx *c, void *ptr, size_t bytes)
 int ftte_host_unregister(ftte_ctx *c, void *ptr)
 {
     if (!c) return FTTE_ERR_ARG;
+    if (c->multi) return multi_host_register(c, ptr, 0, false);
     for (size_t q = 0; q < c->registered.size(); ++q)
         if (c->registered[q].base == (const char *)ptr) {
             FTTE_HIP(c, hipSetDevice(c->device));
@@ -458,6 +467,8 @@ int ftte_host_unregister(ftte_ctx *c, void *ptr)
 long long ftte_counter(const ftte_ctx *c, const char *name)
 {
     if (!c || !name) return -1;
+    if (c->multi) return multi_counter(c, name);
+    if (!std::strcmp(name, "devices")) return 1;
     if (!std::strcmp(name, "grid_builds")) return c->n_grid_builds;
     if (!std::strcmp(name, "plan_builds")) return c->n_plan_builds;
     if (!std::strcmp(name, "forest_builds")) return c->n_forest_builds;
@@ -467,10 +478,11 @@ long long ftte_counter(const ftte_ctx *c, const char *name)
     return -1;
 }
 
-int ftte_launch_count(const ftte_ctx *c) { return c ? c->timing_used : 0; }
+int ftte_launch_count(const ftte_ctx *c) { return !c ? 0 : c->multi ? multi_first(c)->timing_used : c->timing_used; }
 
 int ftte_launch_info(ftte_ctx *c, int idx, double *ms, int64_t *updates)
 {
+    if (c && c->multi) return ftte_launch_info(multi_first(c), idx, ms, updates); // (the first device's share of the sweep)
     if (!c || idx < 0 || idx >= c->timing_used) return FTTE_ERR_ARG;
     float t = 0.f;
     const LaunchTiming &T = c->timing[idx];
@@ -536,6 +548,7 @@ int ftte_stellar_beta_table(ftte_ctx *c, const double *a_smc, int nwave, const d
                             const double *specific_luminosity, int iSpectrum, double coefSpectrum, int iMetal, double coefMetal,
                             double *total_integral)
 {
+    if (c && c->multi) return check_ready(c, false); // (refuses: a multi-device context routes the diffuse sweep only)
     if (!c) return FTTE_ERR_ARG;
     if (!a_smc || !wavelength_cm || !specific_luminosity || nwave < 2 || nspectrum < 2 || nmetal < 2)
         return fail(c, FTTE_ERR_ARG, "ftte_stellar_beta_table: bad argument");
@@ -549,6 +562,7 @@ int ftte_stellar_beta_table(ftte_ctx *c, const double *a_smc, int nwave, const d
 
 int ftte_set_rate_tables(ftte_ctx *c, const double *tables)
 {
+    if (c && c->multi) return check_ready(c, false); // (refuses: a multi-device context routes the diffuse sweep only)
     if (!c) return FTTE_ERR_ARG;
     if (!tables) return fail(c, FTTE_ERR_ARG, "ftte_set_rate_tables: bad argument");
     FTTE_HIP(c, hipSetDevice(c->device));
@@ -557,6 +571,7 @@ int ftte_set_rate_tables(ftte_ctx *c, const double *tables)
 
 int ftte_get_rate_tables(ftte_ctx *c, double *tables)
 {
+    if (c && c->multi) return check_ready(c, false); // (refuses: a multi-device context routes the diffuse sweep only)
     if (!c) return FTTE_ERR_ARG;
     if (!tables) return fail(c, FTTE_ERR_ARG, "ftte_get_rate_tables: bad argument");
     FTTE_HIP(c, hipSetDevice(c->device));
@@ -565,6 +580,7 @@ int ftte_get_rate_tables(ftte_ctx *c, double *tables)
 
 int ftte_get_rates_hydrogen_helium(ftte_ctx *c, int dust_approximation, int nsample, const double *tau, double *rates)
 {
+    if (c && c->multi) return check_ready(c, false); // (refuses: a multi-device context routes the diffuse sweep only)
     if (!c) return FTTE_ERR_ARG;
     if (nsample < 0 || (nsample && (!tau || !rates)) || dust_approximation < 0 || dust_approximation > 2)
         return fail(c, FTTE_ERR_ARG, "ftte_get_rates_hydrogen_helium: bad argument");
@@ -576,6 +592,7 @@ int ftte_get_rates_hydrogen_helium(ftte_ctx *c, int dust_approximation, int nsam
 static int set_medium(ftte_ctx *c, const double *HI, const double *HeI, const double *HeII, const double *rho, const double *abun2,
                       int dust, bool on_device, const char *who)
 {
+    if (c && c->multi) return check_ready(c, false); // (refuses: a multi-device context routes the diffuse sweep only)
     int rc = check_ready(c, false);
     if (rc) return rc;
     if (!HI || !HeI || !HeII || dust < 0 || dust > 2) return fail(c, FTTE_ERR_ARG, std::string(who) + ": bad argument");
@@ -642,6 +659,7 @@ int ftte_point_sources(ftte_ctx *c, int nsrc, const int64_t *src_cell, const dou
 
 int ftte_point_escape(ftte_ctx *c, int nsrc, double *remaining, double *boundary, double *dust, double *spectrum, double *fraction)
 {
+    if (c && c->multi) return check_ready(c, false); // (refuses: a multi-device context routes the diffuse sweep only)
     if (!c) return FTTE_ERR_ARG;
     const PointState &P = c->point;
     if (nsrc < 0 || (size_t)nsrc * kEscapeRec != P.escape_host.size())
@@ -662,6 +680,7 @@ int ftte_point_escape(ftte_ctx *c, int nsrc, double *remaining, double *boundary
 
 int ftte_set_output_sigma(ftte_ctx *c, const double *sigma)
 {
+    if (c && c->multi) return check_ready(c, false); // (refuses: a multi-device context routes the diffuse sweep only)
     if (!c) return FTTE_ERR_ARG;
     if (!sigma) return fail(c, FTTE_ERR_ARG, "ftte_set_output_sigma: bad argument");
     FTTE_HIP(c, hipSetDevice(c->device));
@@ -708,6 +727,7 @@ int ftte_point_rates_device(ftte_ctx *c, double **rates_dev)
 int ftte_set_rate_coefficients(ftte_ctx *c, int nratec, double logtem0, double logtem9, double dlogtem, const double *k1a,
                                const double *k2a, const double *k3a, const double *k4a, const double *k5a, const double *k6a)
 {
+    if (c && c->multi) return check_ready(c, false); // (refuses: a multi-device context routes the diffuse sweep only)
     if (!c) return FTTE_ERR_ARG;
     if (nratec < 2 || !(dlogtem > 0.0) || !(logtem9 > logtem0) || !k1a || !k2a || !k3a || !k4a || !k5a || !k6a)
         return fail(c, FTTE_ERR_ARG, "ftte_set_rate_coefficients: bad argument");
@@ -753,6 +773,7 @@ int ftte_set_temperature(ftte_ctx *c, const double *tgas)
 static int solve_rates(ftte_ctx *c, int run_uvb, const double *J, bool J_on_device, const double *ksi, const double *uniform,
                        double threshold, int use_point_rates, double *max_change, const char *who)
 {
+    if (c && c->multi) return check_ready(c, false); // (refuses: a multi-device context routes the diffuse sweep only)
     int rc = check_ready(c, false);
     if (rc) return rc;
     PointState &P = c->point;
@@ -875,6 +896,7 @@ int ftte_compute_opacities(ftte_ctx *c, int nnu, const double *beta)
 
 static int assign_uvb(ftte_ctx *c, int nnu, const double *uvb, double threshold, double *J, bool J_on_device, const char *who)
 {
+    if (c && c->multi) return check_ready(c, false); // (refuses: a multi-device context routes the diffuse sweep only)
     int rc = check_ready(c, false);
     if (rc) return rc;
     if (nnu < 1 || !uvb || !J) return fail(c, FTTE_ERR_ARG, std::string(who) + ": bad argument");

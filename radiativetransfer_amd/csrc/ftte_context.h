@@ -113,7 +113,10 @@ struct LaunchTiming {
 using namespace ftte; // this header is the library's own: every unit that includes it lives in ftte or implements the C ABI
 
 
+namespace ftte { struct Multi; }
+
 struct ftte_ctx {
+    ftte::Multi *multi = nullptr;   // ftte_create with ndev > 1: this context only routes to one single-device context per device (ftte_multi.cpp)
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
@@ -262,6 +265,7 @@ struct ftte_ctx {
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
     struct HostRange { const char *base; size_t bytes; };
     std::vector<HostRange> registered;
+    std::vector<HostRange> registered_elsewhere; // pinned by another context of the same process (the devices of one multi-device context)
 
     // instrumentation (ftte_counter): how often the expensive host-side builds ran
     long long n_grid_builds = 0, n_plan_builds = 0, n_forest_builds = 0;
@@ -384,6 +388,21 @@ int tile_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, co
 void free_hybrid(ftte_ctx *c);
 int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, const double *w, const double *uvb, double *J_dev,
                  hipStream_t stream, bool *done);
+
+// ---- ftte_multi.cpp: several devices behind one context
+int multi_create(ftte_ctx **out, int ndev, const int *dev_ids);
+int multi_destroy(ftte_ctx *c);
+int multi_set_grid(ftte_ctx *c, int nx, int ny, int nz, int64_t ncell, const int32_t *level, double box_cm);
+int multi_set_opacity(ftte_ctx *c, int nnu, const double *kappa);
+int multi_set_emission(ftte_ctx *c, int mode, const double *values);
+int multi_set_option(ftte_ctx *c, const char *key, int value);
+int multi_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, const double *w, const double *uvb, double *J);
+int multi_iteration(ftte_ctx *c, int nnu, const double *kappa, int ndir, const double *phi, const double *theta, const double *w,
+                    const double *uvb, double *J);
+long long multi_counter(const ftte_ctx *c, const char *name);
+const char *multi_how(const ftte_ctx *c);
+ftte_ctx *multi_first(const ftte_ctx *c);
+int multi_host_register(ftte_ctx *c, void *ptr, size_t bytes, bool on);
 
 // ---- ftte_host_arrays.cpp
 bool is_registered(const ftte_ctx *c, const void *p, size_t bytes);

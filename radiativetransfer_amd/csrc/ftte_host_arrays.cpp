@@ -11,6 +11,8 @@ bool is_registered(const ftte_ctx *c, const void *p, size_t bytes)
     const char *b = (const char *)p;
     for (const auto &r : c->registered)
         if (b >= r.base && b + bytes <= r.base + r.bytes) return true;
+    for (const auto &r : c->registered_elsewhere)
+        if (b >= r.base && b + bytes <= r.base + r.bytes) return true;
     return false;
 }
 

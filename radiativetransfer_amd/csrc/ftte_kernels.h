@@ -21,6 +21,9 @@ int launch_to_layout(int layout, const double *src, double *dst, int n, int nnu,
 // J (cell-array order) = acc[0] + acc[1] + ... in list order; layout[a] in {0,1,2}
 int launch_merge(const double *const *acc, const int *layout, int count, double *J, int n, int nnu, long group_stride,
                  bool accumulate, hipStream_t stream, const int32_t *leaf_of_base = nullptr, long j_stride = 0, bool tiled = false, int tchunk = 0);
+// out[q] = parts[0][q] + parts[1][q] + ... (in that order), q < count: the pieces of J the devices of one context swept for different
+// directions (ftte_multi.cpp; the partners' buffers are read where they lie)
+int launch_sum_parts(const double *const *parts, int nparts, double *out, long count, hipStream_t stream);
 // hybrid sweep of a refined cell array: leaf-ordered values -> values of the base cells; the rays leaving the forest's region
 int launch_base_cells(const double *leaf_values, const int32_t *leaf_of_base, double *base_values, long nbase, long ncell, int nnu,
                       hipStream_t stream);

@@ -1282,4 +1282,27 @@ int launch_opacity(const double *HI, const double *HeI, const double *HeII, cons
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// ---- the pieces of J that the devices of one multi-device context swept for different directions, summed (ftte_multi.cpp)
+struct SumParts { const double *part[64]; int nparts; };
+
+__global__ void __launch_bounds__(256) sum_parts_kernel(const SumParts P, double *out, long count)
+{
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= count) return;
+    double sum = P.part[0][q];
+    for (int k = 1; k < P.nparts; ++k) sum += P.part[k][q];
+    out[q] = sum;
+}
+
+int launch_sum_parts(const double *const *parts, int nparts, double *out, long count, hipStream_t stream)
+{
+    if (nparts < 1 || nparts > 64 || count < 0) return -1;
+    if (!count) return 0;
+    SumParts P;
+    for (int k = 0; k < nparts; ++k) P.part[k] = parts[k];
+    P.nparts = nparts;
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, P, out, count);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 } // namespace ftte

@@ -23,6 +23,10 @@ int ensure_kappa(ftte_ctx *c, int nnu)
 
 int check_ready(ftte_ctx *c, bool need_kappa)
 {
+    if (c && c->multi)
+        return fail(c, FTTE_ERR_UNSUPPORTED, "a multi-device context (ftte_create with ndev > 1) takes host arrays through ftte_set_grid, ftte_set_opacity, "
+                                             "ftte_set_emissivity / ftte_set_source_function, ftte_diffuse_sweep and ftte_diffuse_iteration; for "
+                                             "everything else create a context per device");
     if (!c) return FTTE_ERR_ARG;
     if (!c->grid_set) return fail(c, FTTE_ERR_STATE, "ftte_set_grid has not been called");
     if (need_kappa && (!c->nnu || !c->kappa[0])) return fail(c, FTTE_ERR_STATE, "no opacities: call ftte_set_opacity / ftte_set_species first");
