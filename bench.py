@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--nnu", type=int, default=8)
     ap.add_argument("--ndir", type=int, default=96, help="directions in all (per GPU with --weak)")
     ap.add_argument("--weak", action="store_true", help="96 directions per GPU instead of 96 in all")
+    ap.add_argument("--tau-median", type=float, default=0.1,
+                    help="median optical depth of a cell in the lowest frequency group (0.1: the headline field; 1.0: most segments of the "
+                         "first groups leave the thin range and pay the division)")
     ap.add_argument("--exchange", choices=["slabs", "gather"], default="slabs",
                     help="N > 1: every rank ends with all groups for 1/N of the cells (all-to-all), or with the whole J (all-gather)")
     ap.add_argument("--rows", type=int, default=0, help="rays per lane (4/8/16); 0 = library default")
@@ -81,6 +84,10 @@ def parse():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks sharing GPU 0 with the collectives on host copies over gloo: exercises this script's multi-rank "
                          "path on a one-GPU box (RCCL refuses two ranks on one device); the timings mean nothing")
+    ap.add_argument("--in-process", type=int, default=0, metavar="N",
+                    help="ONE process, one library context over N devices (ftte_create with ndev = N: what a serial Fortran host gets), "
+                         "host arrays in and out: the PCIe-inclusive rate of ftte_diffuse_iteration, not the contract's `value`")
+    ap.add_argument("--same-device", action="store_true", help="--in-process on a one-GPU box: all N contexts on device 0 (rehearsal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--measure-traffic", action="store_true",
                     help="collect this configuration's HBM traffic and SQ counters with rocprofv3 --pmc passes of this script (child "
@@ -205,10 +212,47 @@ def all_cores_leg(harness, tmp, box, uvb3, phi, theta, w, cores_usable):
     return {}
 
 
+def in_process(a):
+    """One host thread, one context, N devices: the drop-in's call sequence (ftte_set_grid once, then ftte_diffuse_iteration per
+    source iteration) on pinned host arrays.  Prints one JSON line of its own kind."""
+    import radiativetransfer_amd as rt
+    from radiativetransfer_amd import synthetic
+    n, nnu, nd = a.n, a.nnu, a.in_process
+    phi, theta, w = directions(a.ndir)
+    kappa, uvb, box = synthetic.uniform_workload(n, nnu, seed=12345, tau_median=a.tau_median)
+    J = np.empty_like(kappa)
+    eng = rt.DiffuseTransfer(devices=[0] * nd if a.same_device else list(range(nd)))
+    eng.set_uniform_grid(n, box)
+    for kv in a.opt:
+        key, value = kv.split("=")
+        eng.set_option(key, int(value))
+    eng.host_register(kappa)
+    eng.host_register(J)
+    for _ in range(a.warmup):
+        eng.iterate_into(kappa, phi, theta, w, uvb, J)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        eng.iterate_into(kappa, phi, theta, w, uvb, J)
+    elapsed = time.perf_counter() - t0
+    out = {"metric": "cell·dir·ν updates/sec per iteration through the host-array boundary (PCIe-inclusive), one process over N devices",
+           "value": n ** 3 * nnu * a.ndir * a.steps / elapsed, "unit": "updates/s", "n_gpus": nd, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"{n}^3 uniform grid, {nnu} frequency groups, {a.ndir} directions, ftte_diffuse_iteration on pinned host arrays",
+                      "devices": "device 0 given %d times (rehearsal)" % nd if a.same_device else list(range(nd)),
+                      "frequency_slices": eng.counter("frequency_slices"), "direction_slices": eng.counter("direction_slices"),
+                      "combine": eng.multi_info(), "rccl": eng.counter("multi_rccl")}}
+    eng.host_unregister(kappa)
+    eng.host_unregister(J)
+    eng.close()
+    print(json.dumps(out, ensure_ascii=False))
+
+
 def main():
     a = parse()
     if a.measure_traffic:
         return measure_traffic(a)
+    if a.in_process > 1:
+        return in_process(a)
     import torch
     import torch.distributed as dist
     import radiativetransfer_amd as rt
@@ -239,7 +283,7 @@ def main():
     ncell = n ** 3
     total_dirs = a.ndir * world if a.weak else a.ndir
     phi_all, theta_all, w_all = directions(total_dirs)
-    kappa_host, uvb_all, box = synthetic.uniform_workload(n, nnu, seed=12345, tau_median=0.1)
+    kappa_host, uvb_all, box = synthetic.uniform_workload(n, nnu, seed=12345, tau_median=a.tau_median)
     if a.weak:  # round 1's mode: every rank all groups, its own 96 directions, all-reduce
         shard = None
         nu_lo, nu_hi = 0, nnu
@@ -363,7 +407,8 @@ def main():
         "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak" if a.weak else "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{n}^3 uniform grid, {nnu} frequency groups, {total_dirs} directions in all "
-                               "(NESTED pixels of the rotated HEALPix set), diffuse sweep, log-normal opacity, zero "
+                               "(NESTED pixels of the rotated HEALPix set), diffuse sweep, log-normal opacity (median cell optical depth "
+                               f"{a.tau_median:g} in the lowest group, falling as nu^-3), zero "
                                "emissivity (BASELINE.json configs[" + ("2" if total_dirs == 192 else "1") + "])",
                    "grid": n, "nnu": nnu, "ndir_total": total_dirs, "ndir_this_rank": len(phi), "nnu_this_rank": nnu_local,
                    "parallelism": parallelism,
@@ -407,7 +452,7 @@ def config_key(a, n, nnu, ndir, world):
     runs with --lanes 1 so that dispatches do not overlap)."""
     opts = {k: getattr(a, k) for k in SWEEP_OPTIONS}
     opts["opt"] = sorted(a.opt)
-    return {"grid": n, "nnu": nnu, "ndir": ndir, "world": world, "weak": bool(a.weak), "options": opts}
+    return {"grid": n, "nnu": nnu, "ndir": ndir, "world": world, "weak": bool(a.weak), "tau_median": a.tau_median, "options": opts}
 
 
 def pmc_record(key):
@@ -434,7 +479,8 @@ def measure_traffic(a):
     passes = {"FETCH_SIZE": ["FETCH_SIZE"], "WRITE_SIZE": ["WRITE_SIZE"],
               "SQ": ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE"],
               "SQ2": ["SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_INSTS_SMEM"]}
-    fwd = ["--grid", str(n), "--nnu", str(nnu), "--ndir", str(ndir), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--lanes", "1"]
+    fwd = ["--grid", str(n), "--nnu", str(nnu), "--ndir", str(ndir), "--tau-median", str(a.tau_median), "--steps", "1", "--warmup", "0",
+           "--no-cpu-baseline", "--lanes", "1"]
     for k in SWEEP_OPTIONS:
         v = getattr(a, k)
         if v not in (0, -1):
