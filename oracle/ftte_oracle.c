@@ -275,22 +275,38 @@ int fo_layer_patterns(int n, double phi, double theta, fo_pattern *L)
 /* -------------------------------------------------------- segment arithmetic */
 /* transportRoutinesModule.f90:651-678 and 1036-1054.  Advances *I through one
  * segment and returns the term added to the cell's running mean. */
-/* emitting != 0: an emissivity and/or source-function array was given, so the device takes its emission path for
- * every segment (ftte_segment_emit), whatever the local values */
+/* emitting: 1 an emissivity array was given (the reference's eta, :673-678), 2 a source-function array: the device then takes
+ * that path for every segment, whatever the local values.  One or the other (both: FO_ERR_ARG at the entry points). */
 static double fo_segment(double *I, double kappa, double eta, double src, int emitting, double dpath, int arith,
                          double *noise, double *Inoise)
 {
     const double Iin = *I;
     const double tau = kappa * dpath;
     double mean;
+    if (emitting == 2) {
+        /* a source function S (the build's own extension, not in the reference): the formal solution with S constant along the
+         * piece, I(t) = S + (Iin - S) exp(-t), and its exact path mean S + (Iin - S)(1 - exp(-tau))/tau (ftte_math.h:
+         * ftte_segment_source).  "Reference arithmetic" here is the straightforward evaluation with libm's exp. */
+        if (arith == FO_ARITH_DEVICE) mean = ftte_segment_source(&fo_device_consts, fo_device_consts.c[9], I, tau, src);
+        else {
+            const double absorb = exp(-tau);
+            const double g = tau > 0.0 ? (1.0 - absorb) / tau : 1.0;
+            *I = src + (Iin - src) * absorb;
+            mean = src + (Iin - src) * g;
+        }
+        if (noise) { /* 1 - absorb loses eps/2 absolute to cancellation: (eps/2)/tau relative in g */
+            if (tau > 0.0) *noise += fabs(Iin - src) * (0x1p-53 / tau) + 4 * 0x1p-52 * fabs(mean);
+            if (Inoise) *Inoise = *Inoise * exp(-tau) + 4 * 0x1p-52 * fabs(*I);
+        }
+        return mean;
+    }
     if (arith == FO_ARITH_DEVICE) {
-        mean = emitting ? ftte_segment_emit(&fo_device_consts, I, tau, eta, src) : ftte_segment(&fo_device_consts, I, tau);
+        mean = emitting ? ftte_segment_emit(&fo_device_consts, I, tau, eta, 0.0) : ftte_segment(&fo_device_consts, I, tau);
     } else {
         const double absorb = exp(-tau);
         /* (float)1.e-10: the threshold is a default-real literal, :658 */
         const double emit = (tau > (double)1.e-10f) ? (1.0 - absorb) / kappa : dpath;
         double Iout = Iin * absorb + eta * emit / dpath;
-        if (src != 0.0) Iout += src * (1.0 - absorb); /* source function S: the build's extension, not in the reference */
         *I = Iout;
         mean = (Iout < Iin) ? (Iin - Iout) / log(Iin / Iout) : 0.5 * (Iin + Iout);
     }
@@ -344,7 +360,8 @@ int fo_diffuse_sweep_uniform(int n, int nnu, const double *kappa, const double *
                              int ndir, const double *phiL, const double *thetaL, const double *w, const double *uvb,
                              double *J, int arith, int order, double *noise)
 {
-    const int emitting = eta != NULL || src != NULL;
+    const int emitting = src != NULL ? 2 : eta != NULL ? 1 : 0;
+    if (eta != NULL && src != NULL) return -99; /* one form of emission or the other */
     const size_t ncell = (size_t)n * n * n;
     if (noise) memset(noise, 0, (size_t)nnu * ncell * sizeof *noise);
     const size_t plane = (size_t)n * n;
@@ -626,7 +643,7 @@ static void fo_transport(fo_tree *T, int me, double cell_size) /* :560-963 */
         const double kap = T->kappa[(size_t)g * T->ncell + cell];
         const double em = T->eta ? T->eta[(size_t)g * T->ncell + cell] : 0.0;
         const double sf = T->src ? T->src[(size_t)g * T->ncell + cell] : 0.0;
-        const int emitting = T->eta != NULL || T->src != NULL;
+        const int emitting = T->src != NULL ? 2 : T->eta != NULL ? 1 : 0;
         double sum = 0.0, I, nz = 0.0;
         double *nzp = T->noise ? &nz : NULL;
         int nseg = 0;
@@ -654,6 +671,7 @@ int fo_diffuse_sweep_tree(int n, int64_t ncell, const int32_t *level, int nnu, c
 {
     fo_tree T;
     memset(&T, 0, sizeof T);
+    if (eta != NULL && src != NULL) return -99; /* one form of emission or the other */
     T.eta = eta; T.src = src;
     T.noise = noise;
     if (noise) memset(noise, 0, (size_t)nnu * ncell * sizeof *noise);
@@ -730,6 +748,12 @@ void fo_device_attenuation(int64_t count, const double *tau, double *e, double *
 void fo_device_log(int64_t count, const double *x, double *out)
 {
     for (int64_t i = 0; i < count; ++i) out[i] = ftte_log1p(&fo_device_consts, x[i] - 1.0);
+}
+
+/* ftte_segment_source element-wise: I[i] is Iin on entry and Iout on return, mean[i] the exact path mean */
+void fo_device_segment_source(int64_t count, double *I, const double *tau, const double *src, double *mean)
+{
+    for (int64_t i = 0; i < count; ++i) mean[i] = ftte_segment_source(&fo_device_consts, fo_device_consts.c[9], &I[i], tau[i], src[i]);
 }
 
 /* ftte_segment_emit element-wise: I[i] is Iin on entry and Iout on return, mean[i] the cell's share */

@@ -132,6 +132,8 @@ void fo_device_attenuation(int64_t count, const double *tau, double *e, double *
 void fo_device_log(int64_t count, const double *x, double *out);
 void fo_device_cell_mean(int64_t count, const double *acc, int nseg, double w, double *out);
 void fo_device_segment_emit(int64_t count, double *I, const double *tau, const double *eta, const double *src, double *mean);
+/* ftte_segment_source element-wise (a source function: the exact path mean) */
+void fo_device_segment_source(int64_t count, double *I, const double *tau, const double *src, double *mean);
 
 /* ---- ionisation equilibrium (ftte_oracle_chem.c): solveRateEquations, equiSources.f90:3459-3677 ---- */
 long fo_solve_rate_equations(int n, long ncell, const int32_t *level, double box, const double *rho, const double *tgas,

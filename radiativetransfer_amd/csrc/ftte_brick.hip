@@ -93,7 +93,8 @@ template <int EMIT>
 __device__ __forceinline__ double brick_segment(const ftte_consts &K, double lead, double &I, double kap, double x, double dpath)
 {
     if (EMIT == 0) return ftte_segment_lead(&K, lead, &I, kap * dpath);
-    return ftte_segment_emit(&K, &I, kap * dpath, EMIT == 1 ? x : 0.0, EMIT == 2 ? x : 0.0);
+    if (EMIT == 2) return ftte_segment_source(&K, lead, &I, kap * dpath, x); // a source function: the exact path mean
+    return ftte_segment_emit(&K, &I, kap * dpath, x, 0.0);              // the reference's emissivity term and its log-mean
 }
 
 template <int SHAPE, int EMIT, int RW = kBrickRows>
@@ -660,7 +661,7 @@ int launch_brick_pair(const BrickLaunch &L, int max_dirs, int waves, hipStream_t
     const size_t lds = ((size_t)(max_dirs - 1) * kBrickRows * 64 + 2 * max_dirs * 64) * sizeof(double) + (size_t)lds_pad();
     // emission: the log-mean's own division and polynomials (ftte_segment_emit) need the registers of three workgroups per SIMD
     if (L.emit == 1) hipLaunchKernelGGL((brick_pair_kernel<3, 1>), grid, dim3(128), lds, stream, L, max_dirs);
-    else if (L.emit == 2) hipLaunchKernelGGL((brick_pair_kernel<3, 2>), grid, dim3(128), lds, stream, L, max_dirs);
+    else if (L.emit == 2) hipLaunchKernelGGL((brick_pair_kernel<4, 2>), grid, dim3(128), lds, stream, L, max_dirs);
     else if (L.emit) return -1;
     else switch (waves) {
     case 2: hipLaunchKernelGGL((brick_pair_kernel<2, 0>), grid, dim3(128), lds, stream, L, max_dirs); break;
@@ -686,7 +687,7 @@ int launch_brick(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stre
     }
     if (masked && !flow && L.emit) { // (the emission forms hold 162 registers with the lane range, as without it: three waves per SIMD)
         if (L.emit == 1) hipLaunchKernelGGL((brick_kernel<2, 1, 0, true>), grid, dim3(64), lds, stream, L);
-        else hipLaunchKernelGGL((brick_kernel<2, 2, 0, true>), grid, dim3(64), lds, stream, L);
+        else hipLaunchKernelGGL((brick_kernel<3, 2, 0, true>), grid, dim3(64), lds, stream, L);
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
     if (masked) {
@@ -696,7 +697,7 @@ int launch_brick(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stre
     }
     // emission: the log-mean's own division and polynomials need more registers than three waves per SIMD leave
     if (L.emit == 1 && !flow) hipLaunchKernelGGL((brick_kernel<3, 1, 0>), grid, dim3(64), lds, stream, L);
-    else if (L.emit == 2 && !flow) hipLaunchKernelGGL((brick_kernel<3, 2, 0>), grid, dim3(64), lds, stream, L);
+    else if (L.emit == 2 && !flow) hipLaunchKernelGGL((brick_kernel<3, 2, 0>), grid, dim3(64), lds, stream, L); // (the source rows: 145 registers)
     else if (L.emit) return -1; // the dataflow form is built without emission
     else if (flow) hipLaunchKernelGGL((brick_kernel<4, 0, 1>), grid, dim3(64), lds, stream, L);
     else switch (waves) {

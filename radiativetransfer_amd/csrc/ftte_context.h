@@ -298,7 +298,8 @@ struct ftte_ctx {
 // at 4 / 2 / 1 groups); at eight the single wavefront is 1.5 % ahead.  The dataflow launch is built for form 0 only.
 inline int brick_form(const ftte_ctx *c, int nnu)
 {
-    // (with emission the pair form is ahead at eight groups as well, 64.8 against 65.5 ms: 103 instead of 162 VGPRs)
+    // (with the reference's emissivity term -- its log-mean needs a division and two polynomials per piece -- the pair form is ahead at
+    // eight groups as well: 103 instead of 162 VGPRs; a source function costs three instructions per piece and goes as no emission)
     return c->team >= 0 ? c->team : (((nnu <= 4 || c->emit_mode) && !c->dataflow) ? 2 : 0);
 }
 

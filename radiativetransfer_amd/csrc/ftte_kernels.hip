@@ -69,14 +69,15 @@ template <typename T> __device__ __forceinline__ T *uniform(T *p) { return reint
 // One segment of one ray.  EDGE: the cell may lie outside the domain, where the ray is
 // re-initialised with the inflow (transportRoutinesModule.f90:594-597) and adds nothing.
 // EMIT: 0 no emission (the reference as shipped), 1 `x` is the reference's emissivity eta, 2 `x` is a source function S
-// (ftte_math.h: ftte_segment_emit).
+// (ftte_math.h: ftte_segment_emit, ftte_segment_source).
 template <bool EDGE, int EMIT>
 __device__ __forceinline__ double segment(const ftte_consts &K, double &I, double kap, double x, double dpath, bool inside,
                                           double uvb)
 {
     double It = I, m;
     if (EMIT == 0) m = ftte_segment(&K, &It, kap * dpath);
-    else m = ftte_segment_emit(&K, &It, kap * dpath, EMIT == 1 ? x : 0.0, EMIT == 2 ? x : 0.0);
+    else if (EMIT == 2) m = ftte_segment_source(&K, K.c[9], &It, kap * dpath, x);
+    else m = ftte_segment_emit(&K, &It, kap * dpath, x, 0.0);
     if (EDGE) {
         I = inside ? It : uvb;
         return inside ? m : 0.0;
@@ -569,7 +570,7 @@ __global__ void __launch_bounds__(256) amr_level_kernel(const AmrLevelRec A)
     if (A.emit == 0) m = ftte_segment(&A.math, &I, kap * R.dpath);
     else {
         const double x = A.emis[kat];
-        m = ftte_segment_emit(&A.math, &I, kap * R.dpath, A.emit == 1 ? x : 0.0, A.emit == 2 ? x : 0.0);
+        m = A.emit == 2 ? ftte_segment_source(&A.math, A.math.c[9], &I, kap * R.dpath, x) : ftte_segment_emit(&A.math, &I, kap * R.dpath, x, 0.0);
     }
     D.Iout[at] = I;                              // read again by the segments downstream
     __builtin_nontemporal_store(m, &D.mean[at]); // read once, by the combine kernel

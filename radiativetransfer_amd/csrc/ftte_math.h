@@ -272,6 +272,32 @@ FTTE_HD double ftte_segment(const ftte_consts *K, double *I, double tau)
     return ftte_segment_lead(K, K->c[9], I, tau);
 }
 
+/* One segment through a cell with a SOURCE FUNCTION S (the build's own extension for source iterations: the reference has no
+ * enabled emission and no scattering loop).  With S constant along the piece the formal solution is I(t) = S + (Iin - S) exp(-t):
+ *     Iout = S + (Iin - S) exp(-tau),        mean = (1/tau) int_0^tau I dt = S + (Iin - S) g(tau),   g = (1 - exp(-tau))/tau,
+ * the exact path mean -- what the reference's log-mean (Iin - Iout)/log(Iin/Iout) is for S = 0 (there log(Iin/Iout) = tau), and what
+ * it only approximates once a source term makes the profile something else than one exponential.  For S = 0 the two fused
+ * multiply-adds return Iin e and Iin g as they stand: the same bits as ftte_segment_lead.  In radiative equilibrium (Iin = S) nothing
+ * changes, exactly.  Three instructions on top of the attenuation pair; the same wavefront test as there. */
+FTTE_HD double ftte_segment_source(const ftte_consts *K, double lead, double *I, double tau, double S)
+{
+    double e, g;
+    const double dI = *I - S;
+    if (__builtin_expect(ftte_all_thin(K, tau), 1)) {
+        ftte_exp_reduced(K, lead, tau, &e, &g);
+        *I = FTTE_FMA(dI, e, S);
+        return FTTE_FMA(dI, g, S);
+    }
+    ftte_exp_reduced(K, lead, ftte_reduce(K, tau), &e, &g);
+    ftte_thick_part(K, tau, &e, &g);
+    const double Iout = FTTE_FMA(dI, e, S);
+    double mean = FTTE_FMA(dI, g, S);
+    mean = (Iout == 0.0) ? 0.0 : mean; /* (S = 0 and complete extinction: as ftte_segment_lead) */
+    FTTE_KEEP(mean);
+    *I = Iout;
+    return mean;
+}
+
 /* log(1 + t) for t >= 0, accurate also for tiny t (where forming 1 + t first would lose t's low bits):
  * 1 + t = 2^k m, m in [sqrt(1/2), sqrt(2)); for t < sqrt(2) - 1, k = 0 and f = m - 1 = t exactly.
  * log m = 2 atanh(s), s = f/(2+f), |s| <= 0.1716, degree-6 polynomial in s^2 (approximation error 4.7e-18).
@@ -298,11 +324,11 @@ FTTE_HD double ftte_log1p(const ftte_consts *K, double t)
     return FTTE_FMA(kf, K->ln2_hi, FTTE_FMA(kf, K->ln2_lo, logm));
 }
 
-/* One segment with emission.  The reference's (never enabled) emission term, transportRoutinesModule.f90:673-678:
+/* One segment with the reference's emissivity.  The reference's (never enabled) emission term, transportRoutinesModule.f90:673-678:
  *     Iout = Iin*exp(-tau) + eta * ((tau > 1e-10) ? (1-exp(-tau))/kappa : dpath) / dpath  =  Iin*e + eta*g(tau)
- * (note the reference's extra 1/dpath: its eta is not an emissivity per unit length).  `src` adds the physical form
- * S*(1-exp(-tau)) = (src*tau)*g for a source function S per cell -- the build's own extension for source iterations
- * (DESIGN.md).  With emission log(Iin/Iout) != tau, so the path mean is the reference's log-mean itself
+ * (note the reference's extra 1/dpath: its eta is not an emissivity per unit length).  `src` adds S*(1-exp(-tau)) = (src*tau)*g to
+ * Iout in the same form (kept for the oracle's cross-checks; the kernels' source-function mode is ftte_segment_source above, with
+ * the exact path mean).  With emission log(Iin/Iout) != tau, so the cell's share is the reference's log-mean itself
  * (transportRoutinesModule.f90:1044-1048), evaluated from the difference Iin-Iout (below): the same number, without
  * the reference's loss of the difference when the quotient Iin/Iout is rounded (fatal near Iout = Iin, i.e. wherever
  * the radiation field is close to the source function). */

@@ -161,6 +161,18 @@ def device_attenuation(tau):
     return e, g
 
 
+def device_segment_source(Iin, tau, src):
+    """ftte_segment_source element-wise (a source function S, the exact path mean): returns (Iout, mean)."""
+    I = np.array(Iin, dtype=np.float64, copy=True)
+    tau, src = (_f64(np.broadcast_to(a, I.shape)) for a in (tau, src))
+    mean = np.empty_like(I)
+    dp = C.POINTER(C.c_double)
+    lib().fo_device_segment_source.argtypes = [C.c_int64, dp, dp, dp, dp]
+    lib().fo_device_segment_source.restype = None
+    lib().fo_device_segment_source(I.size, _dp(I), _dp(tau), _dp(src), _dp(mean))
+    return I, mean
+
+
 def device_segment_emit(Iin, tau, eta, src):
     """ftte_segment_emit element-wise: returns (Iout, mean)."""
     I = np.array(Iin, dtype=np.float64, copy=True)

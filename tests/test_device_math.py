@@ -68,7 +68,7 @@ def test_log_mean_with_emission_accuracy():
     S[:1500] = Iin[:1500] * (1 + rng.uniform(-1, 1, 1500) * 10 ** rng.uniform(-14, -2, 1500))
     tau[1500:2500] = -np.log(1 / np.sqrt(2)) * (1 + rng.uniform(-1e-3, 1e-3, 1000))
     S[1500:2500] = 0.0
-    Iout, mean = O.device_segment_emit(Iin, tau, 0.0, S)
+    Iout, mean = O.device_segment_emit(Iin, tau, S * tau, 0.0)   # the reference's emissivity term with eta = S tau: Iout = Iin e + S tau g
     mp.mp.dps = 50
     worst = 0.0
     for a, b, m in zip(Iin, Iout, mean):
@@ -79,11 +79,44 @@ def test_log_mean_with_emission_accuracy():
         worst = max(worst, float(abs(mp.mpf(float(m)) / true - 1)))
     assert worst < 3 * EPS, worst
     # in equilibrium nothing changes, and the mean is the intensity itself
-    Iout, mean = O.device_segment_emit(np.array([3e-21]), np.array([0.7]), 0.0, np.array([3e-21]))
-    assert abs(Iout[0] / 3e-21 - 1) < 2 * EPS and abs(mean[0] / 3e-21 - 1) < 2 * EPS
+    Iout, mean = O.device_segment_emit(np.array([3e-21]), np.array([0.7]), np.array([0.7 * 3e-21]), 0.0)
+    assert abs(Iout[0] / 3e-21 - 1) < 4 * EPS and abs(mean[0] / 3e-21 - 1) < 4 * EPS
     # complete extinction without a source: zero out, zero mean (the reference's (Iin-0)/log(Iin/0))
     Iout, mean = O.device_segment_emit(np.array([3e-21]), np.array([2000.0]), 0.0, np.array([0.0]))
     assert Iout[0] == 0.0 and mean[0] == 0.0
+
+
+def test_source_function_segment_is_the_exact_path_mean():
+    """ftte_segment_source: with a source function S constant along the piece, I(t) = S + (Iin - S) exp(-t); Iout is its end and the
+    cell's share its exact mean S + (Iin - S)(1 - exp(-tau))/tau -- for S = 0 bit for bit what ftte_segment gives (the reference's
+    log-mean IS that mean then), in equilibrium exactly S."""
+    rng = np.random.default_rng(11)
+    n = 6000
+    Iin = 10 ** rng.uniform(-24, -18, n)
+    S = Iin * 10 ** rng.uniform(-6, 2, n)
+    tau = 10 ** rng.uniform(-9, 2.5, n)
+    S[:1000] = Iin[:1000] * (1 + rng.uniform(-1, 1, 1000) * 10 ** rng.uniform(-14, -2, 1000))   # near equilibrium
+    Iout, mean = O.device_segment_source(Iin, tau, S)
+    mp.mp.dps = 50
+    worst_out = worst_mean = 0.0
+    for a, s, t, b, m in zip(Iin, S, tau, Iout, mean):
+        a, s, t = mp.mpf(float(a)), mp.mpf(float(s)), mp.mpf(float(t))
+        e = mp.e ** (-t)
+        true_out, true_mean = s + (a - s) * e, s - (a - s) * mp.expm1(-t) / t
+        # (the error is relative to the larger of the two terms: S + (Iin - S) x cancels when Iin << S and x -> 1)
+        scale = max(abs(s), abs(a))
+        worst_out = max(worst_out, float(abs(mp.mpf(float(b)) - true_out) / scale))
+        worst_mean = max(worst_mean, float(abs(mp.mpf(float(m)) - true_mean) / scale))
+    assert worst_out < 4 * EPS and worst_mean < 4 * EPS, (worst_out, worst_mean)
+    # S = 0: the same bits as the segment without emission
+    I0 = Iin.copy()
+    out0, mean0 = O.device_segment_source(I0, tau, 0.0)
+    out1, mean1 = O.device_segment_emit(I0, tau, 0.0, 0.0)  # (reference form with nothing to emit: Iin e, and the log-mean evaluated from the intensities)
+    e, g = O.device_attenuation(tau)
+    assert np.array_equal(out0, Iin * e) and np.array_equal(mean0[out0 > 0], (Iin * g)[out0 > 0]) and np.all(mean0[out0 == 0] == 0)
+    # equilibrium: nothing changes, exactly
+    out, mean = O.device_segment_source(np.array([3e-21]), np.array([0.7]), np.array([3e-21]))
+    assert out[0] == 3e-21 and mean[0] == 3e-21
 
 
 def test_thin_bound_is_where_the_range_reduction_starts():
