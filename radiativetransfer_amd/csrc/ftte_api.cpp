@@ -214,10 +214,16 @@ int ftte_set_opacity_device(ftte_ctx *c, int nnu, const double *kappa_dev)
     FTTE_HIP(c, hipSetDevice(c->device));
     if ((rc = wait_sweep(c))) return rc;
     if ((rc = ensure_kappa(c, nnu))) return rc;
-    FTTE_HIP(c, hipMemcpyAsync(c->kappa[0], kappa_dev, sizeof(double) * nnu * c->ncell, hipMemcpyDeviceToDevice, c->stream));
-    FTTE_HIP(c, hipStreamSynchronize(c->stream)); // the sweep may run on another stream: the copy must have landed
+    // A uniform grid whose last sweep used all three layouts (the copies are there): the copy and the two transposes in one pass
+    // over the caller's array.  Else the copy alone; the sweep makes what it needs.
+    const bool all_three = !c->use_forest && c->kappa[1] && c->kappa[2] && c->kappa_ready[1] && c->kappa_ready[2] && c->nnu == nnu && !c->tiled_opt;
+    if (all_three) {
+        if (launch_set_layouts(kappa_dev, c->kappa[0], c->kappa[1], c->kappa[2], c->n, nnu, (long)c->ncell, c->stream))
+            return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
+    } else FTTE_HIP(c, hipMemcpyAsync(c->kappa[0], kappa_dev, sizeof(double) * nnu * c->ncell, hipMemcpyDeviceToDevice, c->stream));
+    FTTE_HIP(c, hipStreamSynchronize(c->stream)); // the sweep may run on another stream: the copies must have landed
     c->nnu = nnu;
-    c->kappa_ready[0] = true; c->kappa_ready[1] = c->kappa_ready[2] = c->kappa_ready[3] = false;
+    c->kappa_ready[0] = true; c->kappa_ready[1] = c->kappa_ready[2] = all_three; c->kappa_ready[3] = false;
     ++c->n_kappa_sets;
     return FTTE_OK;
 }

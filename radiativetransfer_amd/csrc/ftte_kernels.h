@@ -18,6 +18,8 @@ int launch_xcc_census(unsigned *mask_dev, hipStream_t stream); // bit x of *mask
 int launch_brick_pair(const BrickLaunch &L, int max_dirs, int waves, hipStream_t stream); // two wavefronts per brick, four rows each
 // cell-array order -> layout 1 ([jc][ic][kc]) or 2 ([kc][ic][jc]); nnu groups, group_stride apart
 int launch_to_layout(int layout, const double *src, double *dst, int n, int nnu, long group_stride, hipStream_t stream, bool tiled = false, int tchunk = 0); // tiled: brick order (BrickLaunch::tiled), layout 0 too; tchunk: layers per piece
+// cell-array order -> the three layouts in one pass (dst0: a copy)
+int launch_set_layouts(const double *src, double *dst0, double *dst1, double *dst2, int n, int nnu, long group_stride, hipStream_t stream);
 // J (cell-array order) = acc[0] + acc[1] + ... in list order; layout[a] in {0,1,2}
 int launch_merge(const double *const *acc, const int *layout, int count, double *J, int n, int nnu, long group_stride,
                  bool accumulate, hipStream_t stream, const int32_t *leaf_of_base = nullptr, long j_stride = 0, bool tiled = false, int tchunk = 0);

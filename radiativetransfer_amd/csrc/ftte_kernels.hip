@@ -439,6 +439,37 @@ __global__ void __launch_bounds__(256) to_layout2_kernel(const double *__restric
         if (k0 + r < n && j0 + tx < n) d[tiled ? tiled_index(n, k0 + r, ic, j0 + tx, tchunk) : ((long)(k0 + r) * n + ic) * n + j0 + tx] = tile[tx][r];
 }
 
+// The caller's opacities (cell-array order) into the library's three copies in ONE pass: dst0 as they come, dst1[jc][ic][kc] the
+// same rows elsewhere, dst2[kc][ic][jc] each ic plane transposed through LDS.  Read once, written three times (a copy and two
+// transposes read them three times).
+__global__ void __launch_bounds__(256) set_layouts_kernel(const double *__restrict__ src, double *__restrict__ dst0, double *__restrict__ dst1,
+                                                          double *__restrict__ dst2, int n, long group_stride)
+{
+    __shared__ double tile[32][33];
+    const long g = blockIdx.z / n;
+    const int ic = blockIdx.z % n;
+    const int j0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
+    const long base = g * group_stride;
+    for (int r = ty; r < 32; r += 8)
+        if (j0 + r < n && k0 + tx < n) {
+            const double v = src[base + ((long)ic * n + j0 + r) * n + k0 + tx];
+            tile[r][tx] = v;
+            dst0[base + ((long)ic * n + j0 + r) * n + k0 + tx] = v;
+            dst1[base + ((long)(j0 + r) * n + ic) * n + k0 + tx] = v;
+        }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (k0 + r < n && j0 + tx < n) dst2[base + ((long)(k0 + r) * n + ic) * n + j0 + tx] = tile[tx][r];
+}
+
+int launch_set_layouts(const double *src, double *dst0, double *dst1, double *dst2, int n, int nnu, long group_stride, hipStream_t stream)
+{
+    const dim3 grid((n + 31) / 32, (n + 31) / 32, n * nnu);
+    hipLaunchKernelGGL(set_layouts_kernel, grid, dim3(256), 0, stream, src, dst0, dst1, dst2, n, group_stride);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 int launch_to_layout(int layout, const double *src, double *dst, int n, int nnu, long group_stride, hipStream_t stream, bool tiled, int tchunk)
 {
     if (tiled && (n % 64 != 0 || n % kBrickRows != 0 || (tchunk > 0 && n % tchunk != 0))) return -1;

@@ -122,3 +122,39 @@ def test_iteration_in_one_call_on_a_refined_cell_array(golden):
         e.iterate_into(g["kappa"], g["phi"], g["theta"], g["w"], g["uvb"], J)
         e.set_opacity(g["kappa"])
         assert np.array_equal(J, e.transport(g["phi"], g["theta"], g["w"], g["uvb"]))
+
+
+@pytest.mark.parametrize("n", [64, 70])
+def test_new_device_opacities_reach_all_three_layouts(n):
+    """ftte_set_opacity_device on a context whose last sweep used all three memory layouts rewrites the three copies in one pass over
+    the caller's array (set_layouts_kernel) instead of a copy and two transposes: the next sweep must see the NEW opacities in every
+    layout -- bit for bit what a fresh context gets for them, also on a grid that is no multiple of the 32 x 32 tiles, also when the
+    number of groups changes (the one-pass form is not taken then)."""
+    import torch
+    phi, theta, w = O.healpix_directions(2)          # 48 directions: izones of all three march axes
+    k1, uvb, box = synthetic.uniform_workload(n, 3, seed=n, tau_median=0.2)
+    k2 = np.ascontiguousarray(k1[::-1] * 1.7)
+    dev = torch.device("cuda", 0)
+
+    def sweep(e, k, u):
+        kd = torch.from_numpy(k).to(dev)
+        e.set_opacity_device(k.shape[0], kd.data_ptr())
+        J = torch.empty(k.shape, dtype=torch.float64, device=dev)
+        e.transport_device(phi, theta, w, u, J.data_ptr(), 0)
+        torch.cuda.synchronize()
+        return J.cpu().numpy()
+
+    with rt.DiffuseTransfer() as e:
+        e.set_uniform_grid(n, box)
+        sweep(e, k1, uvb)
+        J2 = sweep(e, k2, uvb)                         # the one-pass form
+        J2_two_groups = sweep(e, k2[:2], uvb[:2])      # another number of groups: copy, then the sweep's own transposes
+        J1_again = sweep(e, k1, uvb)
+    with rt.DiffuseTransfer() as fresh:
+        fresh.set_uniform_grid(n, box)
+        assert np.array_equal(J2, sweep(fresh, k2, uvb))
+    with rt.DiffuseTransfer() as fresh:
+        fresh.set_uniform_grid(n, box)
+        assert np.array_equal(J1_again, sweep(fresh, k1, uvb))
+    assert np.array_equal(J2_two_groups, J2[:2])
+    assert np.allclose(J2, O.sweep_uniform(n, k2, box, phi, theta, w, uvb, arith=O.ARITH_DEVICE), rtol=64 * np.finfo(float).eps, atol=0)
