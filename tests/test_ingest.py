@@ -97,5 +97,10 @@ def test_ingested_cell_array_drives_the_library(golden, name):
         J = st.transport(phi, theta, w, uvb)
     kappa = O.compute_opacities(g["out_HI"], g["out_HeI"], g["out_HeII"], beta)
     ref = O.sweep_tree(int(g["out_n"]), g["out_level"], kappa, float(g["out_box"]), phi, theta, w, uvb, arith=O.ARITH_DEVICE)
+    # the ingested fields are the reference's own, bit for bit (test_ingest_equals_the_reference_tree checks all nine): so are
+    # the opacities, and J agrees to the rounding of the sum over directions
+    for mine, theirs in (("HI", "out_HI"), ("HeI", "out_HeI"), ("HeII", "out_HeII")):
+        assert np.array_equal(np.asarray(a[mine], dtype=np.float64), np.asarray(g[theirs], dtype=np.float64)), mine
+    assert np.array_equal(a["level"], g["out_level"])
     assert J.shape == ref.shape
-    assert np.allclose(J, ref, rtol=1e-6, atol=0)   # opacities from species that may differ in the last bit of a float (powf)
+    assert np.allclose(J, ref, rtol=64 * np.finfo(np.float64).eps, atol=0)

@@ -253,8 +253,7 @@ def test_stromgren_sphere(stellar, golden):
     in homogeneous hydrogen, photo-ionisation equilibrium iterated on the host with the device tracer supplying the
     absorbed photons.  Recombinations balance the star, so the ionised volume sum(x^2 V) is the Stromgren volume and the
     front sits at R_S = (3 Ndot / 4 pi alpha_B n_H^2)^(1/3) (about 10 base cells here)."""
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
-    import stromgren
+    import stromgren  # tests/stromgren.py: the host loop around the device tracer
     out = stromgren.run(stellar, 32, golden("point16_homogeneous")["tables"], iterations=60)
     assert abs(out["absorbed_fraction"] - 1) < 1e-9          # nothing leaves the box, nothing is lost
     assert abs(out["volume_ratio"] - 1) < 0.03               # the front cells of the discrete problem flicker by ~1 %
