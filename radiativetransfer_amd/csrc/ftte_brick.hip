@@ -251,7 +251,12 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
     const bool through = FLOW == 1 && L.pad_ != 0;
     const int nu = L.nu0 + (int)(work % (unsigned)nnu);
     const unsigned task_index = work / (unsigned)nnu;
-    const BrickTask T = L.tasks[task_index];
+    // (the task list, the inflow and the group records are read-only for the launch and wave-uniform: scalar loads, address space 4)
+    BrickTask T;
+    {
+        const unsigned long raw = ((const __attribute__((address_space(4))) unsigned long *)(unsigned long)L.tasks)[task_index];
+        T.group = (int16_t)(raw & 0xffffu); T.tu = (int16_t)((raw >> 16) & 0xffffu); T.tv = (int16_t)((raw >> 32) & 0xffffu); T.ti = (int16_t)(raw >> 48);
+    }
     const int tu_field = uniform((int)T.tu);
     const int tu = MASKED ? tu_field & kBrickTuMask : tu_field;
     const int group_field = uniform((int)T.group);
@@ -265,7 +270,7 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
     cgroup *G = (cgroup *)(L.groups + (MASKED ? group_field & kBrickGroupMask : group_field));
     const int n = L.n, chunk = L.chunk, up = L.up, vp = L.vp;
     const int ndir = G->ndir;
-    const double uvb = L.uvb[nu];
+    const double uvb = ((const __attribute__((address_space(4))) double *)(unsigned long)L.uvb)[nu];
     double lead = L.math.c[9]; // the exponential's leading coefficient, in a vector register for the whole run (ftte_math.h)
     asm volatile("" : "+v"(lead));
 
@@ -362,6 +367,13 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
     // simpler and costs a quarter of the wavefronts a CU can hold at three directions.)  The order in which a layer's
     // directions are added into a cell's J follows p(i): fixed by the layer, the same for every chunk length.
     int p0 = (ndir - (i0 - 1) % ndir) % ndir;
+    // the opacity of the brick's cells, one layer ahead of the layer being crossed: the first layer's asked for before anything else
+    double kap_next[R];
+    // (row addresses are walked with scalar additions; the rows a ragged last brick lacks repeat its last row's address for loads
+    // and are skipped by stores)
+    const int nrows = n - cv0 + 1 < R ? n - cv0 + 1 : R;
+    const long row0 = tiled ? 8l * ((long)tu * G->bu + (long)tv * G->bv + (long)ti * G->bi) : cv0 * row_bytes;
+    load_rows<R, false>(kap_next, kbase + 8l * i0 * si + row0, off0, row_bytes, nrows);
     double cur[R];
     // rays entering the brick's bottom: the inflow, or what the chunk below left
     {
@@ -373,17 +385,15 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
         int d = p0 + 1 + k;
         d = d >= ndir ? d - ndir : d;
         gcdouble *f = (gcdouble *)(G->dir[d].faces + fnu);
+        // (all eight loads in flight, then the eight LDS stores: left to itself the compiler pairs them, load, load, wait, store,
+        // wait, store -- four round trips to memory per direction where one will do, and a brick is a short thing)
+        double parked[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) state[(k * R + r) * 64 + lane] = !has_i_in ? uvb : FLOW == 2 ? fresh((gcbyte *)&f[i_in + (long)r * up]) : f[i_in + (long)r * up];
+        for (int r = 0; r < R; ++r) parked[r] = !has_i_in ? uvb : FLOW == 2 ? fresh((gcbyte *)&f[i_in + (long)r * up]) : f[i_in + (long)r * up];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < R; ++r) state[(k * R + r) * 64 + lane] = parked[r];
     }
-
-    // the opacity of the brick's cells, one layer ahead of the layer being crossed
-    double kap_next[R];
-    // (row addresses are walked with scalar additions; the rows a ragged last brick lacks repeat its last row's address for loads
-    // and are skipped by stores)
-    const int nrows = n - cv0 + 1 < R ? n - cv0 + 1 : R;
-    const long row0 = tiled ? 8l * ((long)tu * G->bu + (long)tv * G->bv + (long)ti * G->bi) : cv0 * row_bytes;
-    load_rows<R, false>(kap_next, kbase + 8l * i0 * si + row0, off0, row_bytes, nrows);
     for (int i = i0; i <= i1; ++i) {
         const int il = i - i0;
         double kap[R], xs[EMIT ? R : 1], Jacc[R];
@@ -497,14 +507,18 @@ __global__ void __launch_bounds__(128, WAVES) brick_pair_kernel(const BrickLaunc
     double *handover = pair_lds + (size_t)2 * (max_dirs - 1) * H * 64; // [step parity][lane]
     const int nnu = L.nnu;
     const int nu = L.nu0 + blockIdx.x % nnu;
-    const BrickTask T = L.tasks[blockIdx.x / nnu];
+    BrickTask T;
+    {
+        const unsigned long raw = ((const __attribute__((address_space(4))) unsigned long *)(unsigned long)L.tasks)[blockIdx.x / nnu];
+        T.group = (int16_t)(raw & 0xffffu); T.tu = (int16_t)((raw >> 16) & 0xffffu); T.tv = (int16_t)((raw >> 32) & 0xffffu); T.ti = (int16_t)(raw >> 48);
+    }
     const int tu = uniform((int)T.tu), tv = uniform((int)T.tv), ti = uniform((int)T.ti) & (kBrickAccumulate - 1);
     const bool accumulate = (uniform((int)T.ti) & kBrickAccumulate) != 0;
     const bool atomic_acc = L.atomic_acc != 0;
     cgroup *G = (cgroup *)(L.groups + uniform((int)T.group));
     const int n = L.n, chunk = L.chunk, up = L.up, vp = L.vp;
     const int ndir = G->ndir;
-    const double uvb = L.uvb[nu];
+    const double uvb = ((const __attribute__((address_space(4))) double *)(unsigned long)L.uvb)[nu];
     double lead = L.math.c[9]; // the exponential's leading coefficient, in a vector register for the whole run (ftte_math.h)
     asm volatile("" : "+v"(lead));
 
@@ -539,6 +553,14 @@ __global__ void __launch_bounds__(128, WAVES) brick_pair_kernel(const BrickLaunc
     const long i_out = L.iface_off + ((long)((ti + 1) % ns) * vp + R * tv + H * wv) * up + 64 * tu + lane;
 
     int p0 = (ndir - (i0 - 1) % ndir) % ndir;
+    double kap_next[H], kap[H], Jacc[H];
+    double xs[EMIT ? H : 1] = {};
+    // rows of this wave inside the grid (the upper wave of a ragged last brick may have none: it then reads row n throughout)
+    const int nrows = n - cv0 + 1 < H ? (n - cv0 + 1 > 0 ? n - cv0 + 1 : 0) : H;
+    const long row0 = tiled ? 8l * ((long)tu * G->bu + (long)tv * G->bv + (long)ti * G->bi) + (long)(H * wv) * row_bytes : (cv0 < n ? cv0 : n) * row_bytes;
+#pragma unroll
+    for (int r = 0; r < H; ++r) { kap[r] = 0.0; Jacc[r] = 0.0; }
+    load_rows<H, false>(kap_next, kbase + 8l * i0 * si + row0, off0, row_bytes, nrows); // (the first layer's opacities: asked for before anything else)
     double cur[H];
     {
         gcdouble *f = (gcdouble *)(G->dir[p0].faces + fnu);
@@ -549,18 +571,13 @@ __global__ void __launch_bounds__(128, WAVES) brick_pair_kernel(const BrickLaunc
         int d = p0 + 1 + k;
         d = d >= ndir ? d - ndir : d;
         gcdouble *f = (gcdouble *)(G->dir[d].faces + fnu);
+        double parked[H]; // (the loads together, then the LDS stores: brick_kernel)
 #pragma unroll
-        for (int r = 0; r < H; ++r) state[(k * H + r) * 64 + lane] = has_i_in ? f[i_in + (long)r * up] : uvb;
+        for (int r = 0; r < H; ++r) parked[r] = has_i_in ? f[i_in + (long)r * up] : uvb;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < H; ++r) state[(k * H + r) * 64 + lane] = parked[r];
     }
-
-    double kap_next[H], kap[H], Jacc[H];
-    double xs[EMIT ? H : 1] = {};
-    // rows of this wave inside the grid (the upper wave of a ragged last brick may have none: it then reads row n throughout)
-    const int nrows = n - cv0 + 1 < H ? (n - cv0 + 1 > 0 ? n - cv0 + 1 : 0) : H;
-    const long row0 = tiled ? 8l * ((long)tu * G->bu + (long)tv * G->bv + (long)ti * G->bi) + (long)(H * wv) * row_bytes : (cv0 < n ? cv0 : n) * row_bytes;
-#pragma unroll
-    for (int r = 0; r < H; ++r) { kap[r] = 0.0; Jacc[r] = 0.0; }
-    load_rows<H, false>(kap_next, kbase + 8l * i0 * si + row0, off0, row_bytes, nrows);
     // wave 0 crosses layer i0 + it, wave 1 the layer before: what moves up out of row 3 waits a layer in LDS
     const int nlayers = i1 - i0 + 1;
     for (int it = 0; it <= nlayers; ++it) {
