@@ -481,6 +481,11 @@ long long ftte_counter(const ftte_ctx *c, const char *name)
     if (!std::strcmp(name, "hybrid_boxes")) return (c->hplan.valid && c->hplan.worthwhile) ? c->hplan.most_boxes : 0;
     if (!std::strcmp(name, "hybrid_passes")) return (c->hplan.valid && c->hplan.worthwhile) ? c->hplan.npass : 0;
     if (!std::strcmp(name, "brick_form")) return c->last_brick_form;
+    if (!std::strcmp(name, "brick_groups")) return c->bplan.valid ? (long long)c->bplan.groups.size() : 0;
+    if (!std::strcmp(name, "brick_accumulators")) return c->bplan.valid ? c->bplan.nacc[0] + c->bplan.nacc[1] + c->bplan.nacc[2] : 0;
+    if (!std::strcmp(name, "brick_accumulators_0")) return c->bplan.valid ? c->bplan.nacc[0] : 0;
+    if (!std::strcmp(name, "brick_accumulators_1")) return c->bplan.valid ? c->bplan.nacc[1] : 0;
+    if (!std::strcmp(name, "brick_accumulators_2")) return c->bplan.valid ? c->bplan.nacc[2] : 0;
     return -1;
 }
 

@@ -327,7 +327,7 @@ FTTE_HD double ftte_log1p(const ftte_consts *K, double t)
 /* One segment with the reference's emissivity.  The reference's (never enabled) emission term, transportRoutinesModule.f90:673-678:
  *     Iout = Iin*exp(-tau) + eta * ((tau > 1e-10) ? (1-exp(-tau))/kappa : dpath) / dpath  =  Iin*e + eta*g(tau)
  * (note the reference's extra 1/dpath: its eta is not an emissivity per unit length).  `src` adds S*(1-exp(-tau)) = (src*tau)*g to
- * Iout in the same form (kept for the oracle's cross-checks; the kernels' source-function mode is ftte_segment_source above, with
+ * Iout in the same form (kept for cross-checks on the host; the kernels' source-function mode is ftte_segment_source above, with
  * the exact path mean).  With emission log(Iin/Iout) != tau, so the cell's share is the reference's log-mean itself
  * (transportRoutinesModule.f90:1044-1048), evaluated from the difference Iin-Iout (below): the same number, without
  * the reference's loss of the difference when the quotient Iin/Iout is rounded (fatal near Iout = Iin, i.e. wherever
