@@ -164,16 +164,29 @@ class Shard2D:
             src[:, :ncell] = J_local
         # cells = [direction slice b][frequency slice a][length]: slab index b * r_nu + a = rank of (a, b)
         if self.r_dir > 1:
-            blocks = src.view(nloc, self.r_dir, self.r_nu * length).permute(1, 0, 2).contiguous()
+            # a group's row is [direction slice b][frequency slice a][length] as it lies: one reduce-scatter per row, no staging copy
             mine = torch.empty((nloc, self.r_nu * length), dtype=src.dtype, device=src.device)
-            dist.reduce_scatter_tensor(mine.view(-1), blocks.view(-1), op=dist.ReduceOp.SUM, group=self._dir_group)
+            for g in range(nloc):
+                dist.reduce_scatter_tensor(mine[g], src[g], op=dist.ReduceOp.SUM, group=self._dir_group)
         else:
             mine = src
         if self.r_nu > 1:
-            send = mine.view(nloc, self.r_nu, length).permute(1, 0, 2).contiguous()
-            recv = torch.empty_like(send)
-            dist.all_to_all_single(recv.view(-1), send.view(-1), group=self._nu_group)
-            out = recv.view(self.nnu, length)       # frequency slices are contiguous ranges in slice order
+            # all-to-all between the frequency slices, straight out of J's own [group][cell] layout and straight into the rows of
+            # the result: row (slice a, group g) of `out` is rank a's row g, cells of MY slab -- one contiguous run on both sides, so
+            # every (partner, group) pair is one point-to-point transfer and nothing is permuted or staged on the device
+            out = torch.empty((self.nnu, length), dtype=mine.dtype, device=mine.device)
+            rows = mine.view(nloc, self.r_nu, length)
+            ops = []
+            for a in range(self.r_nu):
+                peer = a + self.r_nu * self.i_dir           # global rank of frequency slice a in my direction slice
+                for g in range(nloc):
+                    if a == self.i_nu:
+                        out[a * nloc + g].copy_(rows[g, a])
+                    else:
+                        ops.append(dist.P2POp(dist.isend, rows[g, a], peer))
+                        ops.append(dist.P2POp(dist.irecv, out[a * nloc + g], peer))
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
         else:
             out = mine.view(self.nnu, length)
         lo, hi = self.slab(ncell)
