@@ -53,6 +53,34 @@ std::string AmrTree::build(int n_, int64_t ncell_, const int32_t *lv)
     return err;
 }
 
+// where the top-ending segment of `b` leaves the cell = entry point of the (sub-)layer above
+// (equiSources.f90:1507-1522, transportRoutinesModule.f90:167-182)
+static int advance_entry_point(const ftte_pattern &b, double phi, double theta, double *x0, double *y0)
+{
+    if (b.xy_top == 1) {
+        *x0 = b.xy_x0 + std::cos(phi) / std::tan(theta);
+        *y0 = b.xy_y0 + std::sin(phi) / std::tan(theta);
+    } else if (b.xy_top == 3) {
+        *x0 = b.xz_x0 + b.xz_len * std::cos(theta) * std::cos(phi);
+        *y0 = b.xz_len * std::cos(theta) * std::sin(phi);
+    } else if (b.xy_top == 2) {
+        *x0 = b.yz_len * std::cos(theta) * std::cos(phi);
+        *y0 = b.yz_y0 + b.yz_len * std::cos(theta) * std::sin(phi);
+    } else return 1;
+    return (*x0 > 1.0 || *y0 > 1.0) ? 1 : 0;
+}
+
+int sub_layer_patterns(const ftte_pattern &pp, double phi, double theta, ftte_pattern *lo, ftte_pattern *hi)
+{
+    std::memset(lo, 0, sizeof *lo);
+    std::memset(hi, 0, sizeof *hi);
+    lo->xy_x0 = pp.xy_x0 < 0.5 ? 2.0 * pp.xy_x0 : 2.0 * pp.xy_x0 - 1.0;
+    lo->xy_y0 = pp.xy_y0 < 0.5 ? 2.0 * pp.xy_y0 : 2.0 * pp.xy_y0 - 1.0;
+    int bad = set_pattern(lo, phi, theta) ? 1 : 0;
+    if (advance_entry_point(*lo, phi, theta, &hi->xy_x0, &hi->xy_y0) || set_pattern(hi, phi, theta)) bad = 1;
+    return bad;
+}
+
 namespace {
 
 constexpr int kBrickRowsHost = 8; // kBrickRows of ftte_internal.h
@@ -76,8 +104,30 @@ struct Builder {
     int status = 0;
     std::string err;
     const ForestRegion *reg = nullptr;
+    // fine blocks swept by bricks of their own (ForestRegion::has_fine): which nodes are their leaves and where in the block (fine
+    // sweep coordinates, 1-based); which segments of the forest come after the blocks' bricks
+    std::vector<uint8_t> is_hole, late;
+    std::vector<int16_t> fine_at; // [3 nodes]
 
     Builder(const AmrTree &t, AmrForest &f) : T(t), F(f) {}
+
+    // Where the ray that enters fine cell (fi, fj, fk) [fine sweep frame of the region's block, 1-based; n_f + 1 on an axis: the
+    // position just behind the block] through `face` waits in the direction's face block: what the fine bricks read at the block's
+    // upstream faces and write at its downstream ones (BrickLaunch::sub; the same elements as brick_kernel's u_in/v_in/i_in)
+    int32_t fine_element(int fi, int fj, int fk, int face) const
+    {
+        const ForestRegion::FineFaces &Q = reg->fine;
+        const int u = reg->u_is_k ? fk : fj, v = reg->u_is_k ? fj : fk;
+        const int ti = (fi - 1) / Q.chunk, il = (fi - 1) % Q.chunk, tu = (u - 1) / 64, tv = (v - 1) / kBrickRowsHost;
+        if (face == 0) return (int32_t)(Q.base + Q.iface_off + ((int64_t)(ti % Q.nslot) * Q.vp + (v - 1)) * Q.up + (u - 1));
+        const bool along_u = (face == 2) == reg->u_is_k;
+        if (along_u) {
+            const int64_t ring = tu > 0 ? tu - 1 : Q.ntu;
+            return (int32_t)(Q.base + ((ring * Q.nslot + ti % Q.nslot) * Q.chunk + il) * ((int64_t)Q.ntv * Q.ut) + (int64_t)Q.ut * tv + (v - 1) % kBrickRowsHost);
+        }
+        const int64_t ring = tv > 0 ? tv - 1 : Q.ntv;
+        return (int32_t)(Q.base + Q.vface_off + ((ring * Q.nslot + ti % Q.nslot) * Q.chunk + il) * Q.up + (u - 1));
+    }
 
     // Where the ray that enters base cell (i, j, k) [sweep frame] through `face` (0: from layer i-1, 1: from j-1, 2: from k-1)
     // waits in the direction's face block when the cell on the other side belongs to a brick: the element the brick kernel
@@ -109,17 +159,8 @@ struct Builder {
     {
         if (pats[parent].sub[0] < 0) {
             PatNode lo, hi;
-            std::memset(&lo, 0, sizeof lo);
-            std::memset(&hi, 0, sizeof hi);
             lo.sub[0] = lo.sub[1] = hi.sub[0] = hi.sub[1] = -1;
-            const ftte_pattern &pp = pats[parent].p;
-            lo.p.xy_x0 = pp.xy_x0 < 0.5 ? 2.0 * pp.xy_x0 : 2.0 * pp.xy_x0 - 1.0;
-            lo.p.xy_y0 = pp.xy_y0 < 0.5 ? 2.0 * pp.xy_y0 : 2.0 * pp.xy_y0 - 1.0;
-            if (set_pattern(&lo.p, phi, theta)) { status = FTTE_ERR_PATTERN; err = "ray pattern left the unit cell"; }
-            if (advance_entry(lo.p, &hi.p.xy_x0, &hi.p.xy_y0) || set_pattern(&hi.p, phi, theta)) {
-                status = FTTE_ERR_PATTERN;
-                err = "ray pattern left the unit cell";
-            }
+            if (sub_layer_patterns(pats[parent].p, phi, theta, &lo.p, &hi.p)) { status = FTTE_ERR_PATTERN; err = "ray pattern left the unit cell"; }
             const int32_t a = (int32_t)pats.size();
             pats.push_back(lo);
             pats.push_back(hi);
@@ -127,23 +168,6 @@ struct Builder {
             pats[parent].sub[1] = a + 1;
         }
         return pats[parent].sub[which];
-    }
-
-    // where the top-ending segment of `b` leaves the cell = entry point of the (sub-)layer above
-    // (equiSources.f90:1507-1522, transportRoutinesModule.f90:167-182)
-    int advance_entry(const ftte_pattern &b, double *x0, double *y0) const
-    {
-        if (b.xy_top == 1) {
-            *x0 = b.xy_x0 + std::cos(phi) / std::tan(theta);
-            *y0 = b.xy_y0 + std::sin(phi) / std::tan(theta);
-        } else if (b.xy_top == 3) {
-            *x0 = b.xz_x0 + b.xz_len * std::cos(theta) * std::cos(phi);
-            *y0 = b.xz_len * std::cos(theta) * std::sin(phi);
-        } else if (b.xy_top == 2) {
-            *x0 = b.yz_len * std::cos(theta) * std::cos(phi);
-            *y0 = b.yz_y0 + b.yz_len * std::cos(theta) * std::sin(phi);
-        } else return 1;
-        return (*x0 > 1.0 || *y0 > 1.0) ? 1 : 0;
     }
 
     // get??Neighbour, transportRoutinesModule.f90:455-558: go down into `c`, at every level into the child that
@@ -189,10 +213,40 @@ struct Builder {
         return -1;
     }
 
+    // what leaf U hands over through the face it shares with a cell behind it at level `lvl`: its piece that ends there, or -- a coarser
+    // leaf without one -- the mean of two of its pieces (:612-634)
+    bool handed_over(int32_t U, int face, int lvl, int32_t *up, int32_t *up2)
+    {
+        const ftte_pattern &Q = pats[node_pat[U]].p;
+        const int top = face == 0 ? Q.xy_top : (face == 1 ? Q.xz_top : Q.yz_top);
+        const int32_t ub = 3 * T.leaf[U];
+        *up2 = -1;
+        if (top != 0) { *up = ub + slot_of(top); return true; }
+        // the upstream leaf has no segment ending on the shared face: legal only behind a coarser leaf,
+        // which then hands over the mean of its xy and xz (else yz) segments (:612-634)
+        if (lvl <= T.level[U]) {
+            status = FTTE_ERR_PATTERN;
+            err = "upstream cell of the same or a finer level has no segment ending on the shared face "
+                  "(the reference stops here: 'error in xzTop')";
+            return false;
+        }
+        if (Q.xz_active) { *up = ub + 1; *up2 = ub; }
+        else if (Q.yz_active) { *up = ub + 2; *up2 = ub; }
+        else *up = ub;
+        return true;
+    }
+
     void leaf_segments(int32_t node, int lvl, double cell)
     {
         const ftte_pattern &P = pats[node_pat[node]].p;
         const int64_t base = 3 * (int64_t)T.leaf[node];
+        // a leaf of a fine block that bricks of its own sweep: not part of the forest; what enters it from the forest is listed
+        const bool hole = reg && lvl == 1 && reg->in_fine(seq[0][0], seq[0][1], seq[0][2]);
+        int fc[3] = {0, 0, 0};
+        if (hole) {
+            is_hole[(size_t)node] = 1;
+            for (int a = 0; a < 3; ++a) { fc[a] = 2 * (seq[0][a] - reg->flo[a]) + seq[1][a]; fine_at[3 * (size_t)node + (size_t)a] = (int16_t)fc[a]; }
+        }
         for (int face = 0; face < 3; ++face) {
             const int64_t seg = base + face;
             const bool active = face == 0 || (face == 1 ? P.xz_active : P.yz_active) != 0;
@@ -203,9 +257,27 @@ struct Builder {
             else { a = P.yz_y0; b = P.yz_z0; len = P.yz_len; }
             F.dpath[seg] = cell * len;
             const int32_t U = upstream_leaf(lvl, face, a, b);
+            if (hole) {
+                F.up[seg] = AmrForest::kInflow; // (active; never listed)
+                if (U >= 0 && is_hole[(size_t)U]) continue; // inside the block: the bricks hand the ray over themselves
+                AmrForest::FineImport X{fine_element(fc[0], fc[1], fc[2], face), -1, -1};
+                if (U >= 0) {
+                    if (node_pat[U] < 0) { status = FTTE_ERR_STATE; err = "hybrid sweep: a fine block touches the region's surface"; return; }
+                    if (!handed_over(U, face, lvl, &X.up, &X.up2)) return;
+                }
+                F.fine_imports.push_back(X);
+                continue;
+            }
             int32_t d = 0;
             if (U < 0) {
                 F.up[seg] = AmrForest::kInflow;
+            } else if (reg && !is_hole.empty() && is_hole[(size_t)U]) {
+                // behind a fine cell that bricks sweep: the ray waits where the brick of that cell leaves what crosses this face
+                int uc[3] = {fine_at[3 * (size_t)U], fine_at[3 * (size_t)U + 1], fine_at[3 * (size_t)U + 2]};
+                ++uc[face];
+                F.up[seg] = AmrForest::kImport;
+                F.import_at[seg] = fine_element(uc[0], uc[1], uc[2], face);
+                late[(size_t)seg] = 1;
             } else if (reg && node_pat[U] < 0) {
                 // the upstream leaf was not visited: it lies outside the region, in a brick.  The rim of the region is made of
                 // unrefined base cells, so this is a base cell behind a base cell and the ray waits in the brick's face buffer.
@@ -213,26 +285,18 @@ struct Builder {
                 F.up[seg] = AmrForest::kImport;
                 F.import_at[seg] = face_element(seq[0][0], seq[0][1], seq[0][2], face);
             } else {
-                const ftte_pattern &Q = pats[node_pat[U]].p;
-                const int top = face == 0 ? Q.xy_top : (face == 1 ? Q.xz_top : Q.yz_top);
-                const int32_t ub = 3 * T.leaf[U];
-                if (top != 0) {
-                    F.up[seg] = ub + slot_of(top);
+                int32_t up, up2;
+                if (!handed_over(U, face, lvl, &up, &up2)) return;
+                F.up[seg] = up; F.up2[seg] = up2;
+                if (!late.empty() && (late[(size_t)up] || (up2 >= 0 && late[(size_t)up2]))) {
+                    // after the fine blocks' bricks: its depth counts from them (what it takes from before them is long there)
+                    late[(size_t)seg] = 1;
+                    if (late[(size_t)up]) d = 1 + depth[up];
+                    if (up2 >= 0 && late[(size_t)up2]) d = std::max(d, 1 + depth[up2]);
                 } else {
-                    // the upstream leaf has no segment ending on the shared face: legal only behind a coarser leaf,
-                    // which then hands over the mean of its xy and xz (else yz) segments (:612-634)
-                    if (lvl <= T.level[U]) {
-                        status = FTTE_ERR_PATTERN;
-                        err = "upstream cell of the same or a finer level has no segment ending on the shared face "
-                              "(the reference stops here: 'error in xzTop')";
-                        return;
-                    }
-                    if (Q.xz_active) { F.up[seg] = ub + 1; F.up2[seg] = ub; }
-                    else if (Q.yz_active) { F.up[seg] = ub + 2; F.up2[seg] = ub; }
-                    else F.up[seg] = ub;
+                    d = 1 + depth[up];
+                    if (up2 >= 0) d = std::max(d, 1 + depth[up2]);
                 }
-                d = 1 + depth[F.up[seg]];
-                if (F.up2[seg] >= 0) d = std::max(d, 1 + depth[F.up2[seg]]);
             }
             depth[seg] = d;
         }
@@ -241,7 +305,7 @@ struct Builder {
     // every leaf under `node` belongs to a box swept in pass `pass`
     void mark_inside(int32_t node, uint8_t pass, std::vector<uint8_t> &pass_of)
     {
-        if (T.child0[node] < 0) { F.inside[(size_t)T.leaf[node]] = 1; pass_of[(size_t)T.leaf[node]] = pass; return; }
+        if (T.child0[node] < 0) { F.inside[(size_t)T.leaf[node]] = is_hole.empty() || !is_hole[(size_t)node] ? 1 : 0; pass_of[(size_t)T.leaf[node]] = pass; return; }
         for (int c = 0; c < 8; ++c) mark_inside(T.child0[node] + c, pass, pass_of);
     }
 
@@ -303,6 +367,15 @@ int build_forest_regions(const AmrTree &tree, double phi, double theta, int izon
     for (int i = 0; i < n; ++i) { B.pats[i].p = layers[i]; B.pats[i].sub[0] = B.pats[i].sub[1] = -1; }
     B.node_pat.assign(tree.parent.size(), -1);
     B.depth.assign(nseg, 0);
+    F.fine_imports.clear();
+    bool any_fine = false;
+    for (const ForestRegion &R : regions) any_fine = any_fine || R.has_fine;
+    if (any_fine) {
+        B.is_hole.assign(tree.parent.size(), 0);
+        B.fine_at.assign(3 * tree.parent.size(), 0);
+        B.late.assign((size_t)nseg, 0);
+    }
+    const int per_box = any_fine ? 2 : 1; // passes per box: before and after its fine block's bricks
 
     const double cell = box / (double)n; // equiSources.f90:1570
     // pass of every leaf that belongs to a box (0 without boxes); exports carry their box's pass until they are sorted
@@ -313,7 +386,7 @@ int build_forest_regions(const AmrTree &tree, double phi, double theta, int izon
         pass_of.assign((size_t)tree.ncell, 0);
         for (const ForestRegion &R : regions) {
             if (R.pass < 0 || R.pass > 254) { *err = "hybrid sweep: too many passes"; return FTTE_ERR_STATE; }
-            npass = std::max(npass, R.pass + 1);
+            npass = std::max(npass, per_box * (R.pass + 1));
         }
     }
     const size_t nreg = restricted ? regions.size() : 1;
@@ -359,8 +432,9 @@ int build_forest_regions(const AmrTree &tree, double phi, double theta, int izon
                         const int top = face == 0 ? Q.xy_top : (face == 1 ? Q.xz_top : Q.yz_top);
                         if (top == 0) continue; // no piece of this layer's pattern ends on that face: nothing crosses it
                         const int di = i + (face == 0), dj = j + (face == 1), dk = k + (face == 2);
-                        F.exports.push_back({B.face_element(di, dj, dk, face), (int32_t)(3 * tree.leaf[U] + Builder::slot_of(top))});
-                        export_pass.push_back(R->pass);
+                        const int32_t xs = (int32_t)(3 * tree.leaf[U] + Builder::slot_of(top));
+                        F.exports.push_back({B.face_element(di, dj, dk, face), xs});
+                        export_pass.push_back(per_box * R->pass + (any_fine && B.late[(size_t)xs] ? 1 : 0));
                     }
         }
     }
@@ -368,7 +442,7 @@ int build_forest_regions(const AmrTree &tree, double phi, double theta, int izon
 
     // counting sort of the active segments by (pass, depth)
     std::vector<int32_t> maxd((size_t)npass, -1);
-    auto pass_of_seg = [&](int64_t s) { return restricted ? (int)pass_of[(size_t)(s / 3)] : 0; };
+    auto pass_of_seg = [&](int64_t s) { return restricted ? per_box * (int)pass_of[(size_t)(s / 3)] + (any_fine && B.late[(size_t)s] ? 1 : 0) : 0; };
     auto listed = [&](int64_t s) { return F.up[s] != AmrForest::kInactive && (!restricted || F.inside[(size_t)(s / 3)]); };
     for (int64_t s = 0; s < nseg; ++s) if (listed(s)) maxd[(size_t)pass_of_seg(s)] = std::max(maxd[(size_t)pass_of_seg(s)], B.depth[s]);
     F.pass_first.assign((size_t)npass + 1, 0);

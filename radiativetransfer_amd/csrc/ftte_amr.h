@@ -50,6 +50,21 @@ struct ForestRegion {
     int pass = 0;                              // the boxes of a direction are swept in passes (a box behind another one waits
                                                // for the bricks in between): this box's pass
     bool contains(int i, int j, int k) const { return i >= lo[0] && i <= hi[0] && j >= lo[1] && j <= hi[1] && k >= lo[2] && k <= hi[2]; }
+
+    // A fully refined block inside the box -- every base cell of [flo, fhi] (sweep frame, inclusive) refined exactly once -- whose
+    // fine cells are swept by bricks of their own on the fine level (ftte_hybrid.cpp): inside the block the fine cells are a uniform
+    // grid with a pattern per sub-layer (setRaysRefined, transportRoutinesModule.f90:150-187).  Its leaves are left out of the forest:
+    // a forest segment behind a fine cell takes its ray from the fine bricks' face rings (kImport), a fine cell behind a forest leaf
+    // gets it from there (AmrForest::fine_imports), and the forest comes in two passes per box: what does not depend on the block
+    // before its bricks, what does after them.
+    bool has_fine = false;
+    int flo[3] = {1, 1, 1}, fhi[3] = {0, 0, 0};
+    struct FineFaces {                         // the fine bricks' face block (BrickLaunch of a sub-grid: one ring / slot more at the edges)
+        int chunk = 1, ut = 8, nslot = 1, ntu = 1, ntv = 1, up = 64, vp = 8;
+        int64_t vface_off = 0, iface_off = 0;
+        int64_t base = 0;                      // where it starts inside the direction's face block
+    } fine;
+    bool in_fine(int i, int j, int k) const { return has_fine && i >= flo[0] && i <= fhi[0] && j >= flo[1] && j <= fhi[1] && k >= flo[2] && k <= fhi[2]; }
 };
 
 // One direction's segment forest.  Segment id = 3 * leaf + slot, slot 0 xy, 1 xz, 2 yz (the order in which the
@@ -67,6 +82,8 @@ struct AmrForest {
     std::vector<uint8_t> inside;    // [ncell] the leaf belongs to the region (region only; empty = all)
     std::vector<int32_t> order;  // active segments sorted by pass, then depth
     std::vector<int64_t> depth_off; // [ndepth + 1] ranges of `order`; the depths of all passes one after the other
+    struct FineImport { int32_t at, up, up2; }; // face element of a fine block's bricks <- segment up (mean with up2; -1: the inflow)
+    std::vector<FineImport> fine_imports;       // the rays that enter fine blocks from the forest (regions with has_fine)
     std::vector<int32_t> pass_first;   // [npass + 1] where each pass starts in depth_off ({0, ndepth} without regions)
     std::vector<int64_t> export_first; // [npass + 1] where each pass's rays start in `exports` (sorted by pass)
     int izone = 0;
@@ -82,5 +99,8 @@ int build_forest(const AmrTree &tree, double phi_folded, double theta_folded, in
 // between any two): one forest per box, ordered by the boxes' passes.
 int build_forest_regions(const AmrTree &tree, double phi_folded, double theta_folded, int izone, double box, AmrForest *out,
                          std::string *err, const std::vector<ForestRegion> &regions);
+// setRaysRefined, transportRoutinesModule.f90:150-187: the patterns of the lower and the upper sub-layer of a refined cell that
+// carries `parent`.  Returns 0 or 1 (a pattern left the unit cell).
+int sub_layer_patterns(const ftte_pattern &parent, double phi_folded, double theta_folded, ftte_pattern *lower, ftte_pattern *upper);
 
 } // namespace ftte

@@ -88,6 +88,10 @@ int ftte_destroy(ftte_ctx *c)
     if (c->d_leaf_of_base) (void)hipFree(c->d_leaf_of_base);
     for (int l = 0; l < 3; ++l) if (c->base_kappa[l]) (void)hipFree(c->base_kappa[l]);
     for (int l = 0; l < 3; ++l) if (c->base_emis[l]) (void)hipFree(c->base_emis[l]);
+    for (int l = 0; l < 3; ++l) {
+        if (c->fine_kappa[l]) (void)hipFree(c->fine_kappa[l]);
+        for (int a = 0; a < kMaxAcc; ++a) if (c->fine_acc[l][a]) (void)hipFree(c->fine_acc[l][a]);
+    }
     if (c->amr_Iout) (void)hipFree(c->amr_Iout);
     if (c->amr_mean) (void)hipFree(c->amr_mean);
     if (c->d_amr_dirs) (void)hipFree(c->d_amr_dirs);
@@ -330,6 +334,9 @@ int ftte_set_option(ftte_ctx *c, const char *key, int value)
         if (value < 1 || value > ftte_ctx::kMaxPipes) return fail(c, FTTE_ERR_ARG, "pipelines (independent bricks-forests-bricks sequences of the hybrid sweep, each on a stream of its own) must be 1..4");
         c->halves = value;
         c->hplan.valid = false;
+    } else if (!std::strcmp(key, "fine_bricks")) {
+        if (value < 0 || value > 1) return fail(c, FTTE_ERR_ARG, "fine_bricks must be 0 (a fully refined block stays in the segment forest) or 1 (bricks of its own on the fine level where the block allows it)");
+        c->fine_bricks = value;
     } else if (!std::strcmp(key, "atomic_acc")) {
         if (value < 0 || value > 1) return fail(c, FTTE_ERR_ARG, "atomic_acc must be 0 or 1");
         c->atomic_acc = value;
@@ -480,6 +487,7 @@ long long ftte_counter(const ftte_ctx *c, const char *name)
     if (!std::strcmp(name, "forest_builds")) return c->n_forest_builds;
     if (!std::strcmp(name, "hybrid_boxes")) return (c->hplan.valid && c->hplan.worthwhile) ? c->hplan.most_boxes : 0;
     if (!std::strcmp(name, "hybrid_passes")) return (c->hplan.valid && c->hplan.worthwhile) ? c->hplan.npass : 0;
+    if (!std::strcmp(name, "fine_block")) return (c->hplan.valid && c->hplan.worthwhile && c->hplan.fine.active) ? c->hplan.fine.n : 0;
     if (!std::strcmp(name, "brick_form")) return c->last_brick_form;
     if (!std::strcmp(name, "brick_groups")) return c->bplan.valid ? (long long)c->bplan.groups.size() : 0;
     if (!std::strcmp(name, "brick_accumulators")) return c->bplan.valid ? c->bplan.nacc[0] + c->bplan.nacc[1] + c->bplan.nacc[2] : 0;

@@ -296,9 +296,10 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
     // handed to the right and above, bit 2 no earlier J read, bit 3 no rays taken from or left for the chunks before and after,
     // bit 4 the opacities of a brick's first layer for all its layers, bit 5 no J stored)
     const int ablate = L.pad2_;
-    const bool has_u_in = (tu > 0 || lane_lo > 0) && !(ablate & 1), has_u_out = (64 * (tu + 1) < n || lane_hi < 63) && !(ablate & 2);
-    const bool has_v_in = tv > 0 && !(ablate & 1), has_v_out = R * (tv + 1) < n && !(ablate & 2);
-    const bool has_i_in = ti > 0 && !(ablate & 8), has_i_out = i1 < n && !(ablate & 8);
+    const bool sub = !MASKED && L.sub != 0; // a sub-grid with neighbours all round (BrickLaunch::sub): rings at its faces too
+    const bool has_u_in = (tu > 0 || lane_lo > 0 || sub) && !(ablate & 1), has_u_out = (64 * (tu + 1) < n || lane_hi < 63 || sub) && !(ablate & 2);
+    const bool has_v_in = (tv > 0 || sub) && !(ablate & 1), has_v_out = (R * (tv + 1) < n || sub) && !(ablate & 2);
+    const bool has_i_in = (ti > 0 || sub) && !(ablate & 8), has_i_out = (i1 < n || sub) && !(ablate & 8);
     const long fnu = (long)nu * L.face_stride;
     // element offsets inside a direction's face block (ftte_internal.h)
     const int uw = L.uw, ut = L.ut;
@@ -307,9 +308,9 @@ __global__ void __launch_bounds__(64, WAVES) brick_kernel(const BrickLaunch L)
     // uqface_off), lanes that start inside it take theirs from that box's far u-face (ring 2 * box + 1)
     const long u_out = lane_hi < 63 ? L.uqface_off + ((long)((2 * box) * ns + sl) * chunk) * uw + ut * tv : ((long)(tu * ns + sl) * chunk) * uw + ut * tv;
     const long u_in = lane_lo > 0 ? L.uqface_off + ((long)((2 * box + 1) * ns + sl) * chunk) * uw + ut * tv
-                                  : ((long)((tu - 1) * ns + sl) * chunk) * uw + ut * tv;
+                                  : ((long)((tu > 0 ? tu - 1 : up / 64) * ns + sl) * chunk) * uw + ut * tv; // (tu = 0, sub-grid: ring ntu)
     const long v_out = L.vface_off + ((long)(tv * ns + sl) * chunk) * up + 64 * tu;
-    const long v_in = L.vface_off + ((long)((tv - 1) * ns + sl) * chunk) * up + 64 * tu;
+    const long v_in = L.vface_off + ((long)((tv > 0 ? tv - 1 : vp / R) * ns + sl) * chunk) * up + 64 * tu;   // (tv = 0, sub-grid: ring ntv)
     const long i_in = L.iface_off + ((long)sl * vp + R * tv) * up + 64 * tu + lane;
     const long i_out = L.iface_off + ((long)((ti + 1) % ns) * vp + R * tv) * up + 64 * tu + lane;
 

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -244,11 +245,32 @@ struct ftte_ctx {
         std::vector<size_t> stage_off;    // into bricks.tasks: [half][list]
         int64_t brick_updates = 0;        // cell.direction updates the bricks perform (per frequency group)
         struct Dir { SegRec *rec = nullptr; uint8_t *active = nullptr; AmrExport *exports = nullptr; int64_t nexports = 0;
+                     AmrImport *imports = nullptr; int64_t nimports = 0; // into the face rings of a fine block's bricks
                      std::vector<int64_t> depth_off; std::vector<int32_t> pass_first; std::vector<int64_t> export_first; };
         std::vector<Dir> dirs;
         int32_t *cells = nullptr; int64_t ncells = 0; // the leaves inside the box of at least one direction
         bool uploaded = false;
+        // A fully refined block swept by bricks of its own on the fine level (option "fine_bricks"; one cluster that is a cube of
+        // base cells refined exactly once, twice its side a multiple of 64; no emission): inside it the fine cells are a uniform grid
+        // with a pattern per sub-layer, and the forest keeps only what lies around it (ftte_amr.h: ForestRegion::has_fine)
+        struct Fine {
+            bool active = false;
+            int n = 0;                          // fine cells a side
+            int lo[3] = {0, 0, 0};              // the block's first base cell, storage coordinates (1-based)
+            BrickPlan plan;                     // the fine grid's groups (those of `bricks`, an accumulator each) and tasks
+            std::vector<size_t> stage_off;      // into plan.tasks: list l = pipeline * nstages + stage is [stage_off[l], stage_off[l + 1])
+            int nstages = 0;
+            int64_t face_base = 0;              // where the fine face block starts inside a direction's face block (= bricks.face_elems)
+            int64_t updates = 0;                // cell.direction updates the fine bricks perform (per frequency group)
+            int32_t *leaf_of_fine = nullptr;    // device: [n^3], fine cell in storage order -> leaf
+            LayerRec *layers = nullptr; BrickTask *tasks = nullptr; BrickGroup *groups = nullptr; // device
+        } fine;
     } hplan;
+    int fine_bricks = 1;                  // option "fine_bricks"
+    double *fine_kappa[3] = {nullptr, nullptr, nullptr};  // the fine block's opacities, dense, in the three layouts
+    size_t fine_kappa_cap = 0;
+    double *fine_acc[3][kMaxAcc] = {};    // its groups' J accumulators
+    size_t fine_acc_cap = 0;
     int32_t *d_leaf_of_base = nullptr;
     double *base_kappa[3] = {nullptr, nullptr, nullptr};
     size_t base_kappa_cap = 0;
@@ -328,11 +350,19 @@ template <typename T> int ensure(ftte_ctx *c, T **p, size_t *cap, size_t need)
 }
 
 // ---- ftte_plan.cpp
+// A cubic sub-grid planned like a grid of its own (the fine cells of a fully refined block): side, cell size, and where the layers'
+// patterns come from (`patterns` fills n of them for direction d, folded to phi, theta, izone; returns 0 or an ftte_status)
+struct SubGridPlan {
+    int n = 0;
+    double cell = 0;
+    std::function<int(int d, double phi, double theta, int izone, ftte_pattern *out)> patterns;
+};
 int plan_direction(ftte_ctx *c, int d, double phi_d, double theta_d, double w_d, int tile_rows, std::vector<ftte_pattern> &pat,
-                   std::vector<int> &du_cum, std::vector<int> &dv_cum, DirPlan &D, LayerRec *layers, size_t layer_off);
+                   std::vector<int> &du_cum, std::vector<int> &dv_cum, DirPlan &D, LayerRec *layers, size_t layer_off,
+                   const SubGridPlan *sub = nullptr);
 int build_plan(ftte_ctx *c, int rows, int stack, int ndir, const double *phi, const double *theta, const double *w);
 int plan_brick_groups(ftte_ctx *c, BrickPlan &P, int ndir, const double *phi, const double *theta, const double *w, int chunk, int gmax,
-                      int want_dataflow, bool whole_faces);
+                      int want_dataflow, bool whole_faces, const SubGridPlan *sub = nullptr);
 int build_brick_plan(ftte_ctx *c, int ndir, const double *phi, const double *theta, const double *w);
 int xcc_census(ftte_ctx *c); // fills ftte_ctx::xcc_count, xcc_queue (once per context)
 
@@ -350,6 +380,7 @@ struct ForestDirHost {
     const std::vector<int64_t> *depth_off;
     const std::vector<int32_t> *pass_first;    // the passes of depth_off (AmrForest::pass_first), or null: one pass
     const std::vector<int64_t> *export_first;  // the passes of exports, or null: all in the first
+    const AmrImport *imports = nullptr; int64_t nimports = 0;  // hybrid sweep with a fine block swept by bricks
 };
 
 // A forest pass made ready: the per-direction records and the per-depth tables are in device memory (a batch of 96 would not

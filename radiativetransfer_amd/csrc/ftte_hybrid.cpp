@@ -28,6 +28,11 @@ void free_hybrid(ftte_ctx *c)
         if (d.exports) (void)hipFree(d.exports);
     }
     if (c->hplan.cells) (void)hipFree(c->hplan.cells);
+    for (auto &D : c->hplan.dirs) if (D.imports) (void)hipFree(D.imports);
+    if (c->hplan.fine.leaf_of_fine) (void)hipFree(c->hplan.fine.leaf_of_fine);
+    if (c->hplan.fine.layers) (void)hipFree(c->hplan.fine.layers);
+    if (c->hplan.fine.tasks) (void)hipFree(c->hplan.fine.tasks);
+    if (c->hplan.fine.groups) (void)hipFree(c->hplan.fine.groups);
     c->hplan = ftte_ctx::HybridPlan();
 }
 
@@ -183,7 +188,7 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
     const int chunk = std::min(c->chunk > 0 ? c->chunk : 4, n);
     const int gmax = c->group > 0 ? c->group : (nnu >= 2 ? 3 : 2);
     std::vector<double> key = {c->box, (double)chunk, (double)gmax, (double)c->share, (double)c->halves, (double)c->hybrid_lanes, (double)c->hybrid_slots,
-                               (double)c->forest_batch};
+                               (double)c->forest_batch, (double)c->fine_bricks, (double)(c->emit_mode != 0)};
     key.insert(key.end(), phi, phi + ndir);
     key.insert(key.end(), theta, theta + ndir);
     key.insert(key.end(), w, w + ndir);
@@ -262,6 +267,92 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
         std::vector<int> half_of_dir((size_t)ndir, 0);
         for (size_t g = 0; g < P.groups.size(); ++g) for (int d : P.groups[g].dirs) half_of_dir[(size_t)d] = half_of_group[g];
         for (int d = 0; d < ndir; ++d) H.half_dirs[(size_t)half_of_dir[(size_t)d]].push_back(d);
+    }
+
+    // ---- a fully refined block swept by bricks of its own on the fine level.  One cluster, a cube of q base cells a side refined
+    // exactly once, 2 q a multiple of the bricks' 64 lanes; one pass, launch lists by phase, no emission.  Inside the block the fine
+    // cells are a uniform grid of 2 q cells a side whose sub-layers carry the patterns of setRaysRefined
+    // (transportRoutinesModule.f90:150-187): the brick kernel sweeps it like a grid of its own (plan_brick_groups with a SubGridPlan),
+    // rays cross its faces through rings of its own face block, and the forest keeps what lies around it.
+    ftte_ctx::HybridPlan::Fine &FN = H.fine;
+    FN = ftte_ctx::HybridPlan::Fine();
+    if (c->fine_bricks && clusters.size() == 1 && H.npass == 1 && !H.slots && !c->emit_mode) {
+        const Extent &e = clusters[0];
+        const int q = e.hi[0] - e.lo[0] + 1;
+        bool cube = q == e.hi[1] - e.lo[1] + 1 && q == e.hi[2] - e.lo[2] + 1 && (2 * q) % 64 == 0 && (2 * q) % chunk == 0 && 2 * q <= 32000;
+        for (int a = e.lo[0]; a <= e.hi[0] && cube; ++a)
+            for (int b = e.lo[1]; b <= e.hi[1] && cube; ++b)
+                for (int d = e.lo[2]; d <= e.hi[2] && cube; ++d) {
+                    const int32_t node = (int32_t)(((int64_t)(a - 1) * n + (b - 1)) * n + (d - 1));
+                    const int32_t c0 = c->tree.child0[(size_t)node];
+                    if (c0 < 0) { cube = false; break; }
+                    for (int k = 0; k < 8; ++k) if (c->tree.child0[(size_t)(c0 + k)] >= 0) cube = false; // refined once, no deeper
+                }
+        if (cube) {
+            FN.active = true;
+            FN.n = 2 * q;
+            for (int a = 0; a < 3; ++a) FN.lo[a] = e.lo[a];
+        }
+    }
+    if (FN.active) {
+        SubGridPlan sg;
+        sg.n = FN.n;
+        sg.cell = c->box / (double)n / 2.0; // the size of a cell halves per level (transportRoutinesModule.f90:583)
+        const Extent cluster = clusters[0];
+        sg.patterns = [&, cluster](int, double phi_f, double theta_f, int izone, ftte_pattern *out) -> int {
+            // the base layers the block spans along this izone's march axis, each with its two sub-layers
+            ZoneMap zm;
+            zone_map(izone, &zm);
+            int lo0 = 1;
+            for (int a = 0; a < 3; ++a)
+                if (zm.src[a] == 0) lo0 = zm.mirror[a] ? n + 1 - cluster.hi[a] : cluster.lo[a];
+            std::vector<ftte_pattern> base((size_t)n);
+            if (layer_patterns(n, phi_f, theta_f, base.data())) return FTTE_ERR_PATTERN;
+            for (int i = 0; i < FN.n / 2; ++i)
+                if (sub_layer_patterns(base[(size_t)(lo0 - 1 + i)], phi_f, theta_f, &out[2 * i], &out[2 * i + 1])) return FTTE_ERR_PATTERN;
+            return 0;
+        };
+        const int share = c->share;
+        c->share = 0; // an accumulator per group: the fine grid is small and every launch a plain store
+        rc = plan_brick_groups(c, FN.plan, ndir, phi, theta, w, chunk, gmax, 0, true, &sg);
+        c->share = share;
+        if (rc) { free_hybrid(c); return rc; }
+        BrickPlan &Q = FN.plan;
+        if (Q.groups.size() != P.groups.size()) { free_hybrid(c); return fail(c, FTTE_ERR_STATE, "hybrid plan: the fine block's groups differ from the base grid's"); }
+        Q.face_elems = Q.uqface_off; // (no boxes inside the fine grid)
+        FN.face_base = P.face_elems;
+        // stage lists per pipeline: stage = tu + tv + ti, the groups with the most directions first
+        FN.nstages = Q.ntu + Q.ntv + Q.nti - 2;
+        const size_t nst = (size_t)FN.nstages, nl = (size_t)H.nhalves * nst;
+        FN.stage_off.assign(nl + 1, 0); // list l = pipeline * nstages + stage: tasks [stage_off[l], stage_off[l + 1])
+        for (size_t g = 0; g < Q.groups.size(); ++g)
+            for (int ti = 0; ti < Q.nti; ++ti)
+                for (int tv = 0; tv < Q.ntv; ++tv)
+                    for (int tu = 0; tu < Q.ntu; ++tu) ++FN.stage_off[(size_t)half_of_group[g] * nst + (size_t)(tu + tv + ti) + 1];
+        for (size_t l = 0; l < nl; ++l) FN.stage_off[l + 1] += FN.stage_off[l];
+        Q.tasks.resize(FN.stage_off[nl]);
+        std::vector<size_t> at(FN.stage_off.begin(), FN.stage_off.end() - 1);
+        std::vector<size_t> by_size(Q.groups.size());
+        for (size_t g = 0; g < by_size.size(); ++g) by_size[g] = g;
+        std::stable_sort(by_size.begin(), by_size.end(), [&](size_t x, size_t y) { return Q.groups[x].dirs.size() > Q.groups[y].dirs.size(); });
+        for (size_t g : by_size)
+            for (int ti = 0; ti < Q.nti; ++ti)
+                for (int tv = 0; tv < Q.ntv; ++tv)
+                    for (int tu = 0; tu < Q.ntu; ++tu) {
+                        BrickTask T;
+                        T.group = (int16_t)g; T.tu = (int16_t)tu; T.tv = (int16_t)tv; T.ti = (int16_t)ti;
+                        Q.tasks[at[(size_t)half_of_group[g] * nst + (size_t)(tu + tv + ti)]++] = T;
+                    }
+        FN.updates = (int64_t)FN.n * FN.n * FN.n * ndir;
+        // the boxes learn about the block: its extent in their sweep frame (the refined cells' own) and the fine face block
+        for (auto &BX : boxes)
+            for (HybridBox &B : BX) {
+                ForestRegion &R = B.R;
+                R.has_fine = true;
+                for (int a = 0; a < 3; ++a) { R.flo[a] = B.fine.lo[a]; R.fhi[a] = B.fine.hi[a]; }
+                R.fine.chunk = Q.chunk; R.fine.ut = Q.ut; R.fine.nslot = Q.nslot; R.fine.ntu = Q.ntu; R.fine.ntv = Q.ntv; R.fine.up = Q.up; R.fine.vp = Q.vp;
+                R.fine.vface_off = Q.vface_off; R.fine.iface_off = Q.iface_off; R.fine.base = FN.face_base;
+            }
     }
 
     // tasks: the bricks outside the boxes, and what the boxes leave of the bricks they cut through.  Phase 0: what lies behind no
@@ -475,6 +566,7 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
     std::vector<std::vector<SegRec>> rec((size_t)ndir);
     std::vector<std::vector<uint8_t>> active((size_t)ndir);  // per leaf, until the list is known
     std::vector<std::vector<AmrExport>> exports((size_t)ndir);
+    std::vector<std::vector<AmrImport>> imports((size_t)ndir);
     ++c->n_forest_builds;
     for (int d0 = 0; d0 < ndir; d0 += nthreads) {
         const int nbt = std::min(nthreads, ndir - d0);
@@ -516,6 +608,9 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
             static_assert(sizeof(AmrForest::Export) == sizeof(AmrExport), "export records: host and device forms must agree");
             exports[(size_t)(d0 + t)].resize(F[t].exports.size());
             if (!F[t].exports.empty()) std::memcpy(exports[(size_t)(d0 + t)].data(), F[t].exports.data(), sizeof(AmrExport) * F[t].exports.size());
+            static_assert(sizeof(AmrForest::FineImport) == sizeof(AmrImport), "import records: host and device forms must agree");
+            imports[(size_t)(d0 + t)].resize(F[t].fine_imports.size());
+            if (!F[t].fine_imports.empty()) std::memcpy(imports[(size_t)(d0 + t)].data(), F[t].fine_imports.data(), sizeof(AmrImport) * F[t].fine_imports.size());
             for (int64_t q = 0; q < ncell; ++q) in_any[(size_t)q] |= F[t].inside[(size_t)q];
         }
     }
@@ -541,6 +636,10 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
                         if (place[(size_t)(X.seg / 3)] < 0) { bad[(size_t)d] = 1; break; }
                         X.seg = renumber(X.seg);
                     }
+                    for (AmrImport &X : imports[(size_t)d]) {
+                        if ((X.up >= 0 && place[(size_t)(X.up / 3)] < 0) || (X.up2 >= 0 && place[(size_t)(X.up2 / 3)] < 0)) { bad[(size_t)d] = 1; break; }
+                        X.up = renumber(X.up); X.up2 = renumber(X.up2);
+                    }
                     for (size_t q = 0; q < cells.size(); ++q) compact[q] = active[(size_t)d][(size_t)cells[q]];
                     active[(size_t)d].assign(compact.begin(), compact.end());
                 }
@@ -558,8 +657,33 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
         if (!active[(size_t)d].empty()) FTTE_HIP(c, hipMemcpy(D.active, active[(size_t)d].data(), active[(size_t)d].size(), hipMemcpyHostToDevice));
         if (!exports[(size_t)d].empty())
             FTTE_HIP(c, hipMemcpy(D.exports, exports[(size_t)d].data(), sizeof(AmrExport) * exports[(size_t)d].size(), hipMemcpyHostToDevice));
+        D.nimports = (int64_t)imports[(size_t)d].size();
+        if (D.nimports) {
+            FTTE_HIP(c, hipMalloc((void **)&D.imports, sizeof(AmrImport) * imports[(size_t)d].size()));
+            FTTE_HIP(c, hipMemcpy(D.imports, imports[(size_t)d].data(), sizeof(AmrImport) * imports[(size_t)d].size(), hipMemcpyHostToDevice));
+        }
         std::vector<SegRec>().swap(rec[(size_t)d]);
         std::vector<uint8_t>().swap(active[(size_t)d]);
+    }
+    if (FN.active) {
+        // fine cell (storage order inside the block) -> leaf: the children of a refined base cell follow each other in the cell array
+        // in storage order 4 (a - 1) + 2 (b - 1) + (c - 1) (equiSources.f90:4044-4079)
+        const int nf = FN.n;
+        std::vector<int32_t> map((size_t)nf * nf * nf);
+        for (int a = 0; a < nf; ++a)
+            for (int b = 0; b < nf; ++b)
+                for (int d = 0; d < nf; ++d) {
+                    const int32_t node = (int32_t)(((int64_t)(FN.lo[0] - 1 + a / 2) * n + (FN.lo[1] - 1 + b / 2)) * n + (FN.lo[2] - 1 + d / 2));
+                    map[((size_t)a * nf + b) * nf + d] = c->tree.leaf[(size_t)(c->tree.child0[(size_t)node] + 4 * (a % 2) + 2 * (b % 2) + (d % 2))];
+                }
+        const BrickPlan &Q = FN.plan;
+        FTTE_HIP(c, hipMalloc((void **)&FN.leaf_of_fine, sizeof(int32_t) * map.size()));
+        FTTE_HIP(c, hipMemcpy(FN.leaf_of_fine, map.data(), sizeof(int32_t) * map.size(), hipMemcpyHostToDevice));
+        FTTE_HIP(c, hipMalloc((void **)&FN.layers, sizeof(LayerRec) * Q.layers.size()));
+        FTTE_HIP(c, hipMemcpy(FN.layers, Q.layers.data(), sizeof(LayerRec) * Q.layers.size(), hipMemcpyHostToDevice));
+        FTTE_HIP(c, hipMalloc((void **)&FN.tasks, sizeof(BrickTask) * Q.tasks.size()));
+        FTTE_HIP(c, hipMemcpy(FN.tasks, Q.tasks.data(), sizeof(BrickTask) * Q.tasks.size(), hipMemcpyHostToDevice));
+        FTTE_HIP(c, hipMalloc((void **)&FN.groups, sizeof(BrickGroup) * Q.groups.size()));
     }
     c->kappa_ready[3] = false; // the forests' copy of the opacities follows the list
     H.uploaded = false;
@@ -611,7 +735,10 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
     for (int l = 0; l < 3; ++l)
         for (int s = 0; s < P.nacc[l]; ++s)
             if (!c->acc[l][s]) FTTE_HIP(c, hipMalloc((void **)&c->acc[l][s], sizeof(double) * c->acc_cap));
-    const size_t face_need = (size_t)ndir * nnu * (size_t)P.face_elems;
+    ftte_ctx::HybridPlan::Fine &FN = H.fine;
+    // a direction's face block: the base bricks' rings, then (a fine block swept by bricks) the fine bricks' own
+    const int64_t face_elems = P.face_elems + (FN.active ? FN.plan.face_elems : 0);
+    const size_t face_need = (size_t)ndir * nnu * (size_t)face_elems;
     if ((rc = ensure(c, &c->d_faces, &c->d_faces_cap, face_need))) return rc;
     if (!H.uploaded) {
         if ((rc = ensure(c, &c->d_blayers, &c->d_blayers_cap, P.layers.size()))) return rc;
@@ -636,11 +763,46 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
             for (size_t q = 0; q < Hg.dirs.size(); ++q) {
                 const int d = Hg.dirs[q];
                 G[g].dir[q].layers = c->d_blayers + P.dirs[d].layer_off;
-                G[g].dir[q].faces = c->d_faces + (size_t)d * nnu * (size_t)P.face_elems;
+                G[g].dir[q].faces = c->d_faces + (size_t)d * nnu * (size_t)face_elems;
                 G[g].dir[q].w = P.dirs[d].w;
             }
         }
         FTTE_HIP(c, hipMemcpy(c->d_bgroups, G.data(), sizeof(BrickGroup) * G.size(), hipMemcpyHostToDevice)); c->bgroups_sent.clear();
+    }
+    if (FN.active) {
+        // the fine block's own arrays -- opacities in the three layouts, an accumulator per group -- and its group records
+        const BrickPlan &Q = FN.plan;
+        const size_t per_fine = (size_t)nnu * (size_t)FN.n * FN.n * FN.n;
+        if (c->fine_kappa_cap < per_fine) {
+            for (int l = 0; l < 3; ++l) if (c->fine_kappa[l]) { FTTE_HIP(c, hipFree(c->fine_kappa[l])); c->fine_kappa[l] = nullptr; }
+            for (int l = 0; l < 3; ++l) FTTE_HIP(c, hipMalloc((void **)&c->fine_kappa[l], sizeof(double) * per_fine));
+            c->fine_kappa_cap = per_fine;
+        }
+        if (c->fine_acc_cap < per_fine) {
+            for (int l = 0; l < 3; ++l)
+                for (int a = 0; a < kMaxAcc; ++a) if (c->fine_acc[l][a]) { FTTE_HIP(c, hipFree(c->fine_acc[l][a])); c->fine_acc[l][a] = nullptr; }
+            c->fine_acc_cap = per_fine;
+        }
+        for (int l = 0; l < 3; ++l)
+            for (int a = 0; a < Q.nacc[l]; ++a)
+                if (!c->fine_acc[l][a]) FTTE_HIP(c, hipMalloc((void **)&c->fine_acc[l][a], sizeof(double) * c->fine_acc_cap));
+        std::vector<BrickGroup> G(Q.groups.size());
+        std::memset(G.data(), 0, sizeof(BrickGroup) * G.size());
+        for (size_t g = 0; g < Q.groups.size(); ++g) {
+            const BrickPlan::Group &Hg = Q.groups[g];
+            const DirPlan &D0 = Q.dirs[Hg.dirs[0]];
+            G[g].kappa = c->fine_kappa[Hg.layout];
+            G[g].J = c->fine_acc[Hg.layout][Hg.acc];
+            G[g].org = D0.org; G[g].si = D0.si; G[g].sv = D0.sv; G[g].su = D0.su;
+            G[g].ndir = (int)Hg.dirs.size();
+            for (size_t q = 0; q < Hg.dirs.size(); ++q) {
+                const int d = Hg.dirs[q];
+                G[g].dir[q].layers = FN.layers + Q.dirs[d].layer_off;
+                G[g].dir[q].faces = c->d_faces + (size_t)d * nnu * (size_t)face_elems + (size_t)FN.face_base; // behind the base bricks' rings
+                G[g].dir[q].w = Q.dirs[d].w;
+            }
+        }
+        FTTE_HIP(c, hipMemcpy(FN.groups, G.data(), sizeof(BrickGroup) * G.size(), hipMemcpyHostToDevice));
     }
     if ((rc = ensure(c, &c->d_uvb, &c->d_uvb_cap, (size_t)nnu))) return rc;
     FTTE_HIP(c, hipMemcpy(c->d_uvb, uvb, sizeof(double) * nnu, hipMemcpyHostToDevice)); c->uvb_sent.clear();
@@ -665,7 +827,7 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
     // own place for a pass (pass_at[pipeline][pass]): with fewer directions resident than the sweep has, all pipelines' forests
     // would have to go in one run at ONE place, in front of bricks of the other pipelines that feed them or behind bricks that
     // read what they export.  Both are left to the forest path for the whole tree.
-    if (batch < ndir && (H.npass > 1 || (H.slots && H.nhalves > 1))) return FTTE_OK;
+    if (batch < ndir && (H.npass > 1 || (H.slots && H.nhalves > 1) || FN.active)) return FTTE_OK; // (a fine block's forests come in two passes)
     if ((rc = ensure(c, &c->amr_kappa, &c->amr_kappa_cap, (size_t)nnu * (size_t)std::max<int64_t>(H.ncells, 1)))) return rc;
     if (!c->kappa_ready[3] || c->amr_kappa_form != 1) {
         if (launch_cell_major(c->kappa[0], c->amr_kappa, ncell, nnu, stream, H.cells, (long)H.ncells)) return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
@@ -699,7 +861,7 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
             L.tasks = c->d_btasks + off[l];
             L.uvb = c->d_uvb;
             L.group_stride = nbase;
-            L.face_stride = P.face_elems;
+            L.face_stride = face_elems;
             L.vface_off = P.vface_off; L.iface_off = P.iface_off; L.uqface_off = P.uqface_off;
             L.n = n; L.ntasks = (int)(off[l + 1] - off[l]); L.nnu = nnu; L.nu0 = 0; L.chunk = P.chunk;
             L.up = P.up; L.vp = P.vp; L.uw = P.uw; L.ut = P.ut; L.nslot = P.nslot;
@@ -709,6 +871,36 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
             if (lrc) return fail(c, lrc == -1 ? FTTE_ERR_ARG : FTTE_ERR_NO_DEVICE, "brick kernel launch failed");
         }
       return FTTE_OK;
+    };
+
+    // the fine block's own sweep, pipeline `half`: its rays in from the forest, then its bricks stage by stage
+    int64_t most_imports = 0;
+    for (const auto &D : H.dirs) most_imports = std::max(most_imports, D.nimports);
+    auto fine_sweep = [&](int half, hipStream_t q, const ForestRun &R, AmrLevelRec A) -> int {
+        const ForestRun::Batch &B = R.batches[0];
+        A.dir = c->d_amr_dirs + R.dir_at + (size_t)B.d0;
+        A.ndir = B.nb;
+        if (launch_amr_fine_import(A, most_imports, q)) return fail(c, FTTE_ERR_NO_DEVICE, "fine import kernel launch failed");
+        const BrickPlan &Q = FN.plan;
+        for (int st = 0; st < FN.nstages; ++st) {
+            const size_t l = (size_t)half * (size_t)FN.nstages + (size_t)st;
+            if (FN.stage_off[l + 1] == FN.stage_off[l]) continue;
+            BrickLaunch L;
+            std::memset(&L, 0, sizeof L);
+            L.groups = FN.groups;
+            L.tasks = FN.tasks + FN.stage_off[l];
+            L.uvb = c->d_uvb;
+            L.group_stride = (int64_t)FN.n * FN.n * FN.n;
+            L.face_stride = face_elems;
+            L.vface_off = Q.vface_off; L.iface_off = Q.iface_off; L.uqface_off = Q.uqface_off;
+            L.n = FN.n; L.ntasks = (int)(FN.stage_off[l + 1] - FN.stage_off[l]); L.nnu = nnu; L.nu0 = 0; L.chunk = Q.chunk;
+            L.up = Q.up; L.vp = Q.vp; L.uw = Q.uw; L.ut = Q.ut; L.nslot = Q.nslot;
+            L.sub = 1;
+            L.math = kMath;
+            const int lrc = launch_brick(L, Q.max_dirs, c->brick_waves, q, false);
+            if (lrc) return fail(c, lrc == -1 ? FTTE_ERR_ARG : FTTE_ERR_NO_DEVICE, "brick kernel launch failed");
+        }
+        return FTTE_OK;
     };
 
     // ---- per half: bricks not behind the boxes, the forests of the boxes (all directions of the half per depth launch), the
@@ -737,7 +929,7 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
     A.uvb = c->d_uvb;
     A.ncell = ncell; A.nnu = nnu;
     A.cells = H.cells; A.ncells = H.ncells;
-    A.face_stride = P.face_elems;
+    A.face_stride = face_elems;
     A.math = kMath;
     std::vector<ForestRun> runs;
     {
@@ -747,8 +939,8 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
             const int to = nh > 1 ? h : 0;
             for (int d : H.half_dirs[(size_t)h]) {
                 const ftte_ctx::HybridPlan::Dir &D = H.dirs[(size_t)d];
-                sets[(size_t)to].push_back(ForestDirHost{D.rec, D.active, P.dirs[(size_t)d].w, c->d_faces + (size_t)d * nnu * (size_t)P.face_elems,
-                                                         D.exports, D.nexports, &D.depth_off, &D.pass_first, &D.export_first});
+                sets[(size_t)to].push_back(ForestDirHost{D.rec, D.active, P.dirs[(size_t)d].w, c->d_faces + (size_t)d * nnu * (size_t)face_elems,
+                                                         D.exports, D.nexports, &D.depth_off, &D.pass_first, &D.export_first, D.imports, D.nimports});
             }
         }
         for (int r = 1; r < nh; ++r) slot0[(size_t)r] = slot0[(size_t)r - 1] + (int)sets[(size_t)r - 1].size();
@@ -770,6 +962,14 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
                 if (P.nacc[l] && launch_to_layout(l, c->base_emis[0], c->base_emis[l], n, nnu, (long)nbase, stream))
                     return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
         }
+        if (FN.active) { // the fine block's opacities, dense in its own storage order, then in the layouts its groups march through
+            const long nfine = (long)FN.n * FN.n * FN.n;
+            if (launch_base_cells(c->kappa[0], FN.leaf_of_fine, c->fine_kappa[0], nfine, (long)ncell, nnu, stream))
+                return fail(c, FTTE_ERR_NO_DEVICE, "base-cell kernel launch failed");
+            for (int l = 1; l < 3; ++l)
+                if (FN.plan.nacc[l] && launch_to_layout(l, c->fine_kappa[0], c->fine_kappa[l], FN.n, nnu, nfine, stream))
+                    return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
+        }
         for (int l = 0; l < 3; ++l)
             for (int s = 0; s < P.nacc[l]; ++s) FTTE_HIP(c, hipMemsetAsync(c->acc[l][s], 0, sizeof(double) * per_base, stream));
         FTTE_HIP(c, hipMemsetAsync(J_dev, 0, sizeof(double) * (size_t)nnu * ncell, stream));
@@ -786,6 +986,12 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
                 for (int pass = 0; pass < H.npass; ++pass) {
                     if ((size_t)H.pass_at[(size_t)h][(size_t)pass] != l || (nh == 1 && h > 0)) continue;
                     hipEvent_t before = (nh > 1 && r > 0) ? c->ev_combine[r - 1] : nullptr, after = (nh > 1 && r + 1 < nh) ? c->ev_combine[r] : nullptr;
+                    if (FN.active) { // the forest before the fine block's bricks, those, the forest behind them; the means below
+                        if ((rc = launch_forest_pass(c, qs[r], runs[(size_t)r], 0, 0, A))) return rc;
+                        if ((rc = fine_sweep(h, qs[r], runs[(size_t)r], A))) return rc;
+                        if ((rc = launch_forest_pass(c, qs[r], runs[(size_t)r], 0, 1, A))) return rc;
+                        continue;
+                    }
                     if (H.npass == 1) { // one pass: batch by batch, each with its means
                         if ((rc = launch_forests(c, qs[r], runs[(size_t)r], A, J_dev, false, false, before, after))) return rc;
                         continue;
@@ -798,7 +1004,7 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
         }
         // several passes: the means into J when everything is issued, pipeline after pipeline (a pipeline's last pass may come
         // earlier or later than another's, and the events that order the additions must be recorded before they are waited for)
-        if (H.npass > 1)
+        if (H.npass > 1 || FN.active)
             for (int r = 0; r < nh; ++r) {
                 if (nh > 1 && r > 0) FTTE_HIP(c, hipStreamWaitEvent(qs[r], c->ev_combine[r - 1], 0));
                 if ((rc = launch_forest_combine(c, qs[r], runs[(size_t)r], 0, A, J_dev, false))) return rc;
@@ -818,6 +1024,14 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
             if (count && launch_merge(accs, layouts, count, J_dev, n, nnu, (long)nbase, true, stream, c->d_leaf_of_base, (long)ncell))
                 return fail(c, FTTE_ERR_NO_DEVICE, "merge kernel launch failed");
         }
+        if (FN.active) { // ... and J of the fine block's cells += what its bricks stored
+            const double *accs[3 * kMaxAcc];
+            int layouts[3 * kMaxAcc], count = 0;
+            for (int l = 0; l < 3; ++l)
+                for (int s = 0; s < FN.plan.nacc[l]; ++s) { accs[count] = c->fine_acc[l][s]; layouts[count++] = l; }
+            if (count && launch_merge(accs, layouts, count, J_dev, FN.n, nnu, (long)FN.n * FN.n * FN.n, true, stream, FN.leaf_of_fine, (long)ncell))
+                return fail(c, FTTE_ERR_NO_DEVICE, "merge kernel launch failed");
+        }
         return FTTE_OK;
     };
 
@@ -831,6 +1045,7 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
                                   (uintptr_t)c->brick_waves, (uintptr_t)emit, (uintptr_t)c->emis[0], (uintptr_t)c->amr_emis,
                                   (uintptr_t)c->base_emis[0], (uintptr_t)c->base_emis[1], (uintptr_t)c->base_emis[2]};
     for (int l = 0; l < 3; ++l) { sig.push_back((uintptr_t)c->base_kappa[l]); for (int s2 = 0; s2 < P.nacc[l]; ++s2) sig.push_back((uintptr_t)c->acc[l][s2]); }
+    if (FN.active) for (int l = 0; l < 3; ++l) { sig.push_back((uintptr_t)c->fine_kappa[l]); for (int s2 = 0; s2 < FN.plan.nacc[l]; ++s2) sig.push_back((uintptr_t)c->fine_acc[l][s2]); }
     FTTE_HIP(c, hipEventRecord(Tm.start, stream));
     bool replayed = false;
     if (c->use_graph && H.graph_exec && H.graph_sig == sig) {

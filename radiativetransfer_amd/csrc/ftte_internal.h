@@ -155,7 +155,13 @@ struct BrickLaunch {
     // A brick that comes second to an accumulator's cells (kBrickAccumulate) adds its sums with fp64 atomic adds instead of reading
     // the earlier ones first: nothing to wait for.  One brick per cell and launch (or, in one launch, in dependency order), so the
     // additions still happen in a fixed order: J stays reproducible bit for bit.
-    int32_t atomic_acc, pad3_;
+    int32_t atomic_acc;
+    // A sweep of a SUB-GRID that has neighbours on every side (the fine cells of a fully refined block of a refined cell array,
+    // swept by bricks of their own, ftte_hybrid.cpp): the bricks at the sub-grid's upstream faces take their rays from face rings
+    // like everybody else -- ring `ntu` (`ntv`) stands for the missing brick column to the left (row below), chunk slot 0 for the
+    // chunk before the first; somebody has filled them (amr_fine_import_kernel) --, and the bricks at its downstream faces leave
+    // theirs in their own rings and in chunk slot nti (nslot = nti + 1: no wrap), where the forest behind picks them up.
+    int32_t sub;
     ftte_consts math;
 };
 
@@ -171,6 +177,9 @@ struct SegRec {
 };
 
 struct AmrExport { int32_t at, seg; }; // face element <- outgoing intensity of a segment (a ray leaving the forest's region)
+// face element of a fine block's own brick sweep <- what the coarser leaf upstream hands over: the outgoing intensity of segment `up`,
+// the mean with `up2` where the coarse-neighbour rule asks for it (transportRoutinesModule.f90:612-634), the inflow for up = -1
+struct AmrImport { int32_t at, up, up2; };
 
 struct AmrDirRec {
     const SegRec *rec;       // [active segments], depth after depth
@@ -179,6 +188,8 @@ struct AmrDirRec {
     double *faces;           // hybrid sweep: this direction's face block (BrickDir::faces), else nullptr
     const AmrExport *exports;
     int64_t nexports;
+    const AmrImport *imports; // hybrid sweep with fine blocks swept by bricks: the rays entering the blocks from the forest
+    int64_t nimports;
     double *Iout, *mean;     // [3 ncell][nnu] scratch of this direction's slot
     double w;
 };

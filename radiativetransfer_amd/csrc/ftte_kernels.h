@@ -30,6 +30,7 @@ int launch_sum_parts(const double *const *parts, int nparts, double *out, long c
 int launch_base_cells(const double *leaf_values, const int32_t *leaf_of_base, double *base_values, long nbase, long ncell, int nnu,
                       hipStream_t stream);
 int launch_amr_export(const AmrLevelRec &A, int64_t most_exports, hipStream_t stream);
+int launch_amr_fine_import(const AmrLevelRec &A, int64_t most_imports, hipStream_t stream); // forest -> the face rings of a fine block's bricks
 int launch_opacity(const double *HI, const double *HeI, const double *HeII, const double *beta, double *kappa, long ncell,
                    int nnu, hipStream_t stream);
 

@@ -647,6 +647,33 @@ __global__ void __launch_bounds__(256) amr_export_kernel(const AmrLevelRec A)
     D.faces[(size_t)nu * A.face_stride + (size_t)X.at] = D.Iout[(size_t)(unsigned)X.seg * nnu + nu];
 }
 
+// the rays that enter a fine block's own brick sweep from the forest around it (AmrImport)
+__global__ void __launch_bounds__(256) amr_fine_import_kernel(const AmrLevelRec A)
+{
+    const AmrDirRec &D = A.dir[blockIdx.y];
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nnu = A.nnu;
+    const long e = t / nnu;
+    const int nu = (int)(t - e * nnu);
+    if (e >= (long)D.nimports) return;
+    const AmrImport X = D.imports[e];
+    double I;
+    if (X.up < 0) I = A.uvb[nu];
+    else {
+        I = D.Iout[(size_t)(unsigned)X.up * nnu + nu];
+        if (X.up2 >= 0) I = 0.5 * (I + D.Iout[(size_t)(unsigned)X.up2 * nnu + nu]);
+    }
+    D.faces[(size_t)nu * A.face_stride + (size_t)X.at] = I;
+}
+
+int launch_amr_fine_import(const AmrLevelRec &A, int64_t most, hipStream_t stream)
+{
+    if (most <= 0) return 0;
+    const dim3 grid((unsigned)((most * A.nnu + 255) / 256), (unsigned)A.ndir);
+    hipLaunchKernelGGL(amr_fine_import_kernel, grid, dim3(256), 0, stream, A);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 int launch_amr_export(const AmrLevelRec &A, int64_t most, hipStream_t stream)
 {
     if (most <= 0) return 0;

@@ -9,10 +9,13 @@ namespace ftte {
 // One direction: fold it (equiSources.f90:1395-1454), build its per-layer patterns (:1495-1534, setPattern) and turn them
 // into what the kernels read: the memory frame of its izone and one LayerRec per layer.
 int plan_direction(ftte_ctx *c, int d, double phi_d, double theta_d, double w_d, int tile_rows, std::vector<ftte_pattern> &pat,
-                   std::vector<int> &du_cum, std::vector<int> &dv_cum, DirPlan &D, LayerRec *layers_of_d, size_t layer_off)
+                   std::vector<int> &du_cum, std::vector<int> &dv_cum, DirPlan &D, LayerRec *layers_of_d, size_t layer_off,
+                   const SubGridPlan *sub)
 {
-    const int n = c->n;
-    const double cell = c->box / (double)n; // cellSizeAbsoluteUnits, equiSources.f90:1570
+    // sub: the planes of a cubic sub-grid of `sub->n` cells a side and cell size sub->cell, whose layers carry the patterns
+    // sub->patterns(d) instead of a ray's own march from (0.5, 0.5): the fine cells of a fully refined block (ftte_hybrid.cpp)
+    const int n = sub ? sub->n : c->n;
+    const double cell = sub ? sub->cell : c->box / (double)n; // cellSizeAbsoluteUnits, equiSources.f90:1570
     const long nn = (long)n * n;
     D.w = w_d;
 
@@ -24,7 +27,10 @@ int plan_direction(ftte_ctx *c, int d, double phi_d, double theta_d, double w_d,
                                                                        : "tie between dominant axes");
         return fail(c, fold_status(rc), buf);
     }
-    if (layer_patterns(n, D.phi, D.theta, pat.data())) {
+    if (sub) {
+        const int src = sub->patterns(d, D.phi, D.theta, D.izone, pat.data());
+        if (src) return fail(c, src, "direction " + std::to_string(d) + ": ray pattern left the unit cell (sub-layer patterns of a refined block)");
+    } else if (layer_patterns(n, D.phi, D.theta, pat.data())) {
         char buf[128];
         std::snprintf(buf, sizeof buf, "direction %d: ray pattern left the unit cell (setPattern consistency check)", d);
         return fail(c, FTTE_ERR_PATTERN, buf);
@@ -200,9 +206,9 @@ int build_plan(ftte_ctx *c, int rows, int stack, int ndir, const double *phi, co
 // The part of a brick plan that does not depend on which bricks are swept: the directions, the brick geometry and the face
 // block layout, the groups and their accumulators.
 int plan_brick_groups(ftte_ctx *c, BrickPlan &P, int ndir, const double *phi, const double *theta, const double *w, int chunk, int gmax,
-                      int want_dataflow, bool whole_faces)
+                      int want_dataflow, bool whole_faces, const SubGridPlan *sub)
 {
-    const int n = c->n;
+    const int n = sub ? sub->n : c->n;
     ++c->n_plan_builds;
     P = BrickPlan();
     P.n = n; P.chunk = chunk; P.gmax = gmax; P.share = c->share; P.want_dataflow = want_dataflow; P.box = c->box;
@@ -213,7 +219,7 @@ int plan_brick_groups(ftte_ctx *c, BrickPlan &P, int ndir, const double *phi, co
     std::vector<ftte_pattern> pat(n);
     std::vector<int> du_cum(n + 1), dv_cum(n + 1);
     for (int d = 0; d < ndir; ++d) {
-        const int rc = plan_direction(c, d, phi[d], theta[d], w[d], 7, pat, du_cum, dv_cum, P.dirs[d], &P.layers[(size_t)d * n], (size_t)d * n);
+        const int rc = plan_direction(c, d, phi[d], theta[d], w[d], 7, pat, du_cum, dv_cum, P.dirs[d], &P.layers[(size_t)d * n], (size_t)d * n, sub);
         if (rc) return rc;
     }
     P.ntu = (n + 63) / 64; P.ntv = (n + kBrickRows - 1) / kBrickRows; P.nti = (n + chunk - 1) / chunk;
@@ -221,9 +227,12 @@ int plan_brick_groups(ftte_ctx *c, BrickPlan &P, int ndir, const double *phi, co
     P.dataflow = want_dataflow != 0;
     P.ut = P.dataflow ? 16 : kBrickRows; // a 128-byte line of its own per brick and layer when bricks of one launch exchange rays
     P.uw = P.ntv * P.ut;
-    P.nslot = whole_faces ? P.nti : 2; // rings over two chunks, or every chunk's faces kept (hybrid sweep)
-    P.vface_off = (int64_t)P.ntu * P.nslot * chunk * P.uw;
-    P.iface_off = P.vface_off + (int64_t)P.ntv * P.nslot * chunk * P.up;
+    // rings over two chunks, or every chunk's faces kept (hybrid sweep); a sub-grid keeps one slot more (the chunk before its first)
+    // and one ring more along u and v (the brick columns / rows before its first): BrickLaunch::sub
+    P.nslot = sub ? P.nti + 1 : whole_faces ? P.nti : 2;
+    const int edge = sub ? 1 : 0;
+    P.vface_off = (int64_t)(P.ntu + edge) * P.nslot * chunk * P.uw;
+    P.iface_off = P.vface_off + (int64_t)(P.ntv + edge) * P.nslot * chunk * P.up;
     P.uqface_off = P.iface_off + (int64_t)P.nslot * P.vp * P.up;
     // (the faces inside a brick are used by the hybrid sweep only, which keeps every chunk's faces)
     P.face_elems = P.uqface_off + (whole_faces ? 2 * (int64_t)P.nslot * chunk * P.uw : 0);

@@ -130,6 +130,7 @@ int prepare_forests(ftte_ctx *c, hipStream_t stream, const std::vector<std::vect
                 rec.Iout = c->amr_Iout + per_dir * (size_t)(slot0[q] + t);
                 rec.mean = c->amr_mean + per_dir * (size_t)(slot0[q] + t);
                 rec.faces = D.faces; rec.exports = D.exports; rec.nexports = D.nexports;
+                rec.imports = D.imports; rec.nimports = D.nimports;
                 recs.push_back(rec);
                 if (D.pass_first) npass = std::max(npass, D.pass_first->size() - 1);
             }

@@ -283,3 +283,64 @@ def test_small_trees_stay_on_the_forest_path(golden):
         J = e.transport(g["phi"], g["theta"], g["w"], g["uvb"])
     assert np.array_equal(J, O.sweep_tree(int(g["n"]), g["level"], g["kappa"], float(g["box"]), g["phi"], g["theta"], g["w"], g["uvb"],
                                           arith=O.ARITH_DEVICE))
+
+
+def _cube_case(n, q, lo, nnu, seed):
+    blocks = [(lo[0] + a, lo[1] + b, lo[2] + c) for a in range(q) for b in range(q) for c in range(q)]
+    return patch_case(n, blocks, 1, nnu, seed)
+
+
+@pytest.mark.parametrize("lo", [(16, 16, 16), (8, 24, 12)])
+def test_fine_block_swept_by_bricks_of_its_own_every_izone_bitwise(lo):
+    """A fully refined block -- a cube of 32^3 base cells refined exactly once -- is a uniform grid of 64^3 fine cells with a ray
+    pattern per sub-layer (setRaysRefined, transportRoutinesModule.f90:150-187): option "fine_bricks" sweeps it with bricks of its own
+    on the fine level and leaves to the segment forest only what lies around it; rays cross between the two through the fine bricks'
+    face rings, coarse to fine by the reference's rules (the piece that ends on the shared face, or the mean of two, :612-634), fine
+    to coarse from the one fine cell that holds the entry point.  One direction per izone against the oracle's tree sweep, bit for
+    bit, the block in the middle of the grid and off centre."""
+    n = 64
+    level, kappa, uvb = _cube_case(n, 32, lo, 2, seed=41)
+    with rt.DiffuseTransfer() as e:
+        e.set_grid(n, level, 1.0)
+        e.set_opacity(kappa)
+        for p, t in one_per_izone():
+            phi, theta, w = np.array([p]), np.array([t]), np.array([0.37])
+            J = e.transport(phi, theta, w, uvb)
+            assert e.counter("fine_block") == 64
+            ref = O.sweep_tree(n, level, kappa, 1.0, phi, theta, w, uvb, arith=O.ARITH_DEVICE)
+            assert np.array_equal(J, ref), f"izone {O.fold_direction(p, t)[2]}"
+
+
+def test_fine_block_many_directions_pipelines_and_the_forest_for_it():
+    """The same with 48 directions in three pipelines: reproducible, equal to the sweep that keeps the block in the forest
+    (fine_bricks = 0) and to the forest path for the whole tree to the rounding of the sum; a block the bricks cannot take (30^3:
+    twice its side is no multiple of 64) stays in the forest."""
+    n = 64
+    level, kappa, uvb = _cube_case(n, 32, (16, 16, 16), 3, seed=43)
+    phi, theta, w = O.healpix_directions(2)
+    with rt.DiffuseTransfer() as e:
+        e.set_grid(n, level, 1.0)
+        e.set_opacity(kappa)
+        J = e.transport(phi, theta, w, uvb)
+        assert e.counter("fine_block") == 64 and e.counter("hybrid_boxes") == 1
+        assert np.array_equal(J, e.transport(phi, theta, w, uvb))
+        for pipelines in (1, 2):
+            e.set_option("pipelines", pipelines)
+            assert np.allclose(e.transport(phi, theta, w, uvb), J, rtol=SUM_RTOL, atol=0)
+        e.set_option("pipelines", 3)
+        e.set_option("fine_bricks", 0)
+        J_forest_block = e.transport(phi, theta, w, uvb)
+        assert e.counter("fine_block") == 0 and e.counter("hybrid_boxes") == 1
+        e.set_option("hybrid", 0)
+        J_forest = e.transport(phi, theta, w, uvb)
+    assert np.allclose(J, J_forest_block, rtol=SUM_RTOL, atol=0)
+    assert np.allclose(J, J_forest, rtol=SUM_RTOL, atol=0)
+    assert np.all(J > 0) and np.all(J <= uvb[:, None] * (1 + 1e-12))
+    level, kappa, uvb = _cube_case(n, 30, (17, 17, 17), 2, seed=44)
+    with rt.DiffuseTransfer() as e:
+        e.set_grid(n, level, 1.0)
+        e.set_opacity(kappa)
+        J = e.transport(phi, theta, w, uvb)
+        assert e.counter("fine_block") == 0
+        e.set_option("hybrid", 0)
+        assert np.allclose(J, e.transport(phi, theta, w, uvb), rtol=SUM_RTOL, atol=0)
