@@ -316,7 +316,8 @@ int ftte_host_unregister(ftte_ctx *ctx, void *ptr);
  * ftte_set_grid with an unchanged list keeps the tree, the plans and the resident medium), "plan_builds" (tiled-sweep
  * planner), "forest_builds" (per-direction segment forests of a refined cell array); of the hybrid sweep's current plan, "hybrid_boxes"
  * (boxes around clusters of refined cells, of the izone that has most) and "hybrid_passes" (passes their forests are swept in), 0
- * when the last sweep did not take the hybrid path; "brick_form": the form of the brick kernel the last uniform-grid sweep of the
+ * when the last sweep did not take the hybrid path; "fine_block": fine cells a side of the refined block that plan sweeps with bricks of
+ * its own (0: none); "brick_form": the form of the brick kernel the last uniform-grid sweep of the
  * brick engine took (option "team": 0 or 2; -1 before the first); "devices"; of a multi-device context also "frequency_slices",
  * "direction_slices" and "multi_rccl" (1: the last direction-split sweep was summed over RCCL), the rest from its first device.
  * -1 for an unknown name. */
@@ -347,6 +348,9 @@ long long ftte_counter(const ftte_ctx *ctx, const char *name);
  *                   the refined cells)
  *     "graph"       hybrid: 1 = the launches of a sweep are captured once into a hipGraph and replayed (default 0: measured slower
  *                   than issuing them on this runtime)
+ *     "fine_bricks" hybrid: 1 (default) = a fully refined block -- one cluster that is a cube of base cells refined exactly once, twice
+ *                   its side a multiple of 64 -- is swept by bricks of its own on the fine level, the forests keep what lies around it
+ *                   (DESIGN.md 3b); 0 = every leaf of a box through the forests.  "fine_chunk": layers per fine brick (0: as "chunk")
  *     "forest_batch" most directions per launch of the segment forests (0: what the path and the device memory allow)
  *     "forest"      1: use the segment forests on a uniform grid too, for cross-checks
  *   "ldspad"        diagnostic: extra dynamic LDS per workgroup (bytes), to cap residency

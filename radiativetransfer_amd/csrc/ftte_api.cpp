@@ -337,6 +337,9 @@ int ftte_set_option(ftte_ctx *c, const char *key, int value)
     } else if (!std::strcmp(key, "fine_bricks")) {
         if (value < 0 || value > 1) return fail(c, FTTE_ERR_ARG, "fine_bricks must be 0 (a fully refined block stays in the segment forest) or 1 (bricks of its own on the fine level where the block allows it)");
         c->fine_bricks = value;
+    } else if (!std::strcmp(key, "fine_chunk")) {
+        if (value < 0 || value > 4096) return fail(c, FTTE_ERR_ARG, "fine_chunk (layers per brick on the fine level of a refined block) must be 1..4096, or 0 for the base bricks' chunk");
+        c->fine_chunk = value;
     } else if (!std::strcmp(key, "atomic_acc")) {
         if (value < 0 || value > 1) return fail(c, FTTE_ERR_ARG, "atomic_acc must be 0 or 1");
         c->atomic_acc = value;

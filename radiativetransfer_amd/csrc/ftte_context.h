@@ -266,7 +266,7 @@ struct ftte_ctx {
             LayerRec *layers = nullptr; BrickTask *tasks = nullptr; BrickGroup *groups = nullptr; // device
         } fine;
     } hplan;
-    int fine_bricks = 1;                  // option "fine_bricks"
+    int fine_bricks = 1, fine_chunk = 0;  // options "fine_bricks", "fine_chunk" (0: the base bricks' chunk)
     double *fine_kappa[3] = {nullptr, nullptr, nullptr};  // the fine block's opacities, dense, in the three layouts
     size_t fine_kappa_cap = 0;
     double *fine_acc[3][kMaxAcc] = {};    // its groups' J accumulators

@@ -188,7 +188,7 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
     const int chunk = std::min(c->chunk > 0 ? c->chunk : 4, n);
     const int gmax = c->group > 0 ? c->group : (nnu >= 2 ? 3 : 2);
     std::vector<double> key = {c->box, (double)chunk, (double)gmax, (double)c->share, (double)c->halves, (double)c->hybrid_lanes, (double)c->hybrid_slots,
-                               (double)c->forest_batch, (double)c->fine_bricks, (double)(c->emit_mode != 0)};
+                               (double)c->forest_batch, (double)c->fine_bricks, (double)c->fine_chunk, (double)(c->emit_mode != 0)};
     key.insert(key.end(), phi, phi + ndir);
     key.insert(key.end(), theta, theta + ndir);
     key.insert(key.end(), w, w + ndir);
@@ -276,10 +276,11 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
     // rays cross its faces through rings of its own face block, and the forest keeps what lies around it.
     ftte_ctx::HybridPlan::Fine &FN = H.fine;
     FN = ftte_ctx::HybridPlan::Fine();
+    const int fine_chunk = c->fine_chunk > 0 ? c->fine_chunk : chunk; // layers per brick on the fine level (option "fine_chunk")
     if (c->fine_bricks && clusters.size() == 1 && H.npass == 1 && !H.slots && !c->emit_mode) {
         const Extent &e = clusters[0];
         const int q = e.hi[0] - e.lo[0] + 1;
-        bool cube = q == e.hi[1] - e.lo[1] + 1 && q == e.hi[2] - e.lo[2] + 1 && (2 * q) % 64 == 0 && (2 * q) % chunk == 0 && 2 * q <= 32000;
+        bool cube = q == e.hi[1] - e.lo[1] + 1 && q == e.hi[2] - e.lo[2] + 1 && (2 * q) % 64 == 0 && (2 * q) % fine_chunk == 0 && 2 * q <= 32000;
         for (int a = e.lo[0]; a <= e.hi[0] && cube; ++a)
             for (int b = e.lo[1]; b <= e.hi[1] && cube; ++b)
                 for (int d = e.lo[2]; d <= e.hi[2] && cube; ++d) {
@@ -314,7 +315,7 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
         };
         const int share = c->share;
         c->share = 0; // an accumulator per group: the fine grid is small and every launch a plain store
-        rc = plan_brick_groups(c, FN.plan, ndir, phi, theta, w, chunk, gmax, 0, true, &sg);
+        rc = plan_brick_groups(c, FN.plan, ndir, phi, theta, w, fine_chunk, gmax, 0, true, &sg);
         c->share = share;
         if (rc) { free_hybrid(c); return rc; }
         BrickPlan &Q = FN.plan;

@@ -51,7 +51,13 @@ def test_config3_diffuse_full_size(config3):
     J1 = eng.transport(phi, theta, w, c["uvb"])
     J2 = eng.transport(phi, theta, w, c["uvb"])
     assert eng.counter("forest_builds") == 1          # the second sweep reuses the 96 segment forests
+    assert eng.counter("fine_block") == 64            # the refined 32^3 block is swept by bricks of its own on the fine level
     assert np.array_equal(J1, J2)                     # directions are added in list order, no atomics
+    eng.set_option("fine_bricks", 0)                  # ... and with the block left in the segment forest: the same J to the rounding of the sum
+    J3 = eng.transport(phi, theta, w, c["uvb"])
+    eng.set_option("fine_bricks", 1)
+    assert eng.counter("fine_block") == 0
+    assert np.allclose(J1, J3, rtol=64 * np.finfo(float).eps, atol=0)
     assert J1.shape == (c["nnu"], len(c["level"]))
     assert np.all(J1 > 0) and np.all(J1 <= c["uvb"][:, None] * (1 + 1e-12))
     # the refined patch is denser per unit length (kappa doubles with the level): on average darker than the base grid around it
@@ -68,6 +74,7 @@ def test_config3_two_direction_slab_against_the_oracle(config3):
     pick = [3, 70]
     sel = [0, 4, 7]
     J = eng.transport(phi[pick], theta[pick], w[pick], c["uvb"])
+    assert eng.counter("fine_block") == 64            # (the refined block went through the fine bricks)
     ref = O.sweep_tree(c["n"], c["level"], c["kappa"][sel], c["box"], phi[pick], theta[pick], w[pick], c["uvb"][sel], arith=O.ARITH_DEVICE)
     assert np.array_equal(J[sel], ref)
 
