@@ -90,6 +90,7 @@ int ftte_destroy(ftte_ctx *c)
     for (int l = 0; l < 3; ++l) if (c->base_emis[l]) (void)hipFree(c->base_emis[l]);
     for (int l = 0; l < 3; ++l) {
         if (c->fine_kappa[l]) (void)hipFree(c->fine_kappa[l]);
+        if (c->fine_emis[l]) (void)hipFree(c->fine_emis[l]);
         for (int a = 0; a < kMaxAcc; ++a) if (c->fine_acc[l][a]) (void)hipFree(c->fine_acc[l][a]);
     }
     if (c->amr_Iout) (void)hipFree(c->amr_Iout);

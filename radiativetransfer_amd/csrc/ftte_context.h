@@ -251,7 +251,7 @@ struct ftte_ctx {
         int32_t *cells = nullptr; int64_t ncells = 0; // the leaves inside the box of at least one direction
         bool uploaded = false;
         // A fully refined block swept by bricks of its own on the fine level (option "fine_bricks"; one cluster that is a cube of
-        // base cells refined exactly once, twice its side a multiple of 64; no emission): inside it the fine cells are a uniform grid
+        // base cells refined exactly once, twice its side a multiple of 64): inside it the fine cells are a uniform grid
         // with a pattern per sub-layer, and the forest keeps only what lies around it (ftte_amr.h: ForestRegion::has_fine)
         struct Fine {
             bool active = false;
@@ -269,6 +269,8 @@ struct ftte_ctx {
     int fine_bricks = 1, fine_chunk = 0;  // options "fine_bricks", "fine_chunk" (0: the base bricks' chunk)
     double *fine_kappa[3] = {nullptr, nullptr, nullptr};  // the fine block's opacities, dense, in the three layouts
     size_t fine_kappa_cap = 0;
+    double *fine_emis[3] = {nullptr, nullptr, nullptr};   // its emissivity / source function
+    size_t fine_emis_cap = 0;
     double *fine_acc[3][kMaxAcc] = {};    // its groups' J accumulators
     size_t fine_acc_cap = 0;
     int32_t *d_leaf_of_base = nullptr;

@@ -188,7 +188,7 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
     const int chunk = std::min(c->chunk > 0 ? c->chunk : 4, n);
     const int gmax = c->group > 0 ? c->group : (nnu >= 2 ? 3 : 2);
     std::vector<double> key = {c->box, (double)chunk, (double)gmax, (double)c->share, (double)c->halves, (double)c->hybrid_lanes, (double)c->hybrid_slots,
-                               (double)c->forest_batch, (double)c->fine_bricks, (double)c->fine_chunk, (double)(c->emit_mode != 0)};
+                               (double)c->forest_batch, (double)c->fine_bricks, (double)c->fine_chunk};
     key.insert(key.end(), phi, phi + ndir);
     key.insert(key.end(), theta, theta + ndir);
     key.insert(key.end(), w, w + ndir);
@@ -270,14 +270,14 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
     }
 
     // ---- a fully refined block swept by bricks of its own on the fine level.  One cluster, a cube of q base cells a side refined
-    // exactly once, 2 q a multiple of the bricks' 64 lanes; one pass, launch lists by phase, no emission.  Inside the block the fine
+    // exactly once, 2 q a multiple of the bricks' 64 lanes; one pass, launch lists by phase.  Inside the block the fine
     // cells are a uniform grid of 2 q cells a side whose sub-layers carry the patterns of setRaysRefined
     // (transportRoutinesModule.f90:150-187): the brick kernel sweeps it like a grid of its own (plan_brick_groups with a SubGridPlan),
     // rays cross its faces through rings of its own face block, and the forest keeps what lies around it.
     ftte_ctx::HybridPlan::Fine &FN = H.fine;
     FN = ftte_ctx::HybridPlan::Fine();
     const int fine_chunk = c->fine_chunk > 0 ? c->fine_chunk : chunk; // layers per brick on the fine level (option "fine_chunk")
-    if (c->fine_bricks && clusters.size() == 1 && H.npass == 1 && !H.slots && !c->emit_mode) {
+    if (c->fine_bricks && clusters.size() == 1 && H.npass == 1 && !H.slots) {
         const Extent &e = clusters[0];
         const int q = e.hi[0] - e.lo[0] + 1;
         bool cube = q == e.hi[1] - e.lo[1] + 1 && q == e.hi[2] - e.lo[2] + 1 && (2 * q) % 64 == 0 && (2 * q) % fine_chunk == 0 && 2 * q <= 32000;
@@ -787,12 +787,18 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
         for (int l = 0; l < 3; ++l)
             for (int a = 0; a < Q.nacc[l]; ++a)
                 if (!c->fine_acc[l][a]) FTTE_HIP(c, hipMalloc((void **)&c->fine_acc[l][a], sizeof(double) * c->fine_acc_cap));
+        if (emit && c->fine_emis_cap < per_fine) {
+            for (int l = 0; l < 3; ++l) if (c->fine_emis[l]) { FTTE_HIP(c, hipFree(c->fine_emis[l])); c->fine_emis[l] = nullptr; }
+            for (int l = 0; l < 3; ++l) FTTE_HIP(c, hipMalloc((void **)&c->fine_emis[l], sizeof(double) * per_fine));
+            c->fine_emis_cap = per_fine;
+        }
         std::vector<BrickGroup> G(Q.groups.size());
         std::memset(G.data(), 0, sizeof(BrickGroup) * G.size());
         for (size_t g = 0; g < Q.groups.size(); ++g) {
             const BrickPlan::Group &Hg = Q.groups[g];
             const DirPlan &D0 = Q.dirs[Hg.dirs[0]];
             G[g].kappa = c->fine_kappa[Hg.layout];
+            G[g].emis = emit ? c->fine_emis[Hg.layout] : nullptr;
             G[g].J = c->fine_acc[Hg.layout][Hg.acc];
             G[g].org = D0.org; G[g].si = D0.si; G[g].sv = D0.sv; G[g].su = D0.su;
             G[g].ndir = (int)Hg.dirs.size();
@@ -897,6 +903,7 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
             L.n = FN.n; L.ntasks = (int)(FN.stage_off[l + 1] - FN.stage_off[l]); L.nnu = nnu; L.nu0 = 0; L.chunk = Q.chunk;
             L.up = Q.up; L.vp = Q.vp; L.uw = Q.uw; L.ut = Q.ut; L.nslot = Q.nslot;
             L.sub = 1;
+            L.emit = emit;
             L.math = kMath;
             const int lrc = launch_brick(L, Q.max_dirs, c->brick_waves, q, false);
             if (lrc) return fail(c, lrc == -1 ? FTTE_ERR_ARG : FTTE_ERR_NO_DEVICE, "brick kernel launch failed");
@@ -970,6 +977,13 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
             for (int l = 1; l < 3; ++l)
                 if (FN.plan.nacc[l] && launch_to_layout(l, c->fine_kappa[0], c->fine_kappa[l], FN.n, nnu, nfine, stream))
                     return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
+            if (emit) { // and its emissivity / source function
+                if (launch_base_cells(c->emis[0], FN.leaf_of_fine, c->fine_emis[0], nfine, (long)ncell, nnu, stream))
+                    return fail(c, FTTE_ERR_NO_DEVICE, "base-cell kernel launch failed");
+                for (int l = 1; l < 3; ++l)
+                    if (FN.plan.nacc[l] && launch_to_layout(l, c->fine_emis[0], c->fine_emis[l], FN.n, nnu, nfine, stream))
+                        return fail(c, FTTE_ERR_NO_DEVICE, "layout kernel launch failed");
+            }
         }
         for (int l = 0; l < 3; ++l)
             for (int s = 0; s < P.nacc[l]; ++s) FTTE_HIP(c, hipMemsetAsync(c->acc[l][s], 0, sizeof(double) * per_base, stream));
@@ -1046,7 +1060,7 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
                                   (uintptr_t)c->brick_waves, (uintptr_t)emit, (uintptr_t)c->emis[0], (uintptr_t)c->amr_emis,
                                   (uintptr_t)c->base_emis[0], (uintptr_t)c->base_emis[1], (uintptr_t)c->base_emis[2]};
     for (int l = 0; l < 3; ++l) { sig.push_back((uintptr_t)c->base_kappa[l]); for (int s2 = 0; s2 < P.nacc[l]; ++s2) sig.push_back((uintptr_t)c->acc[l][s2]); }
-    if (FN.active) for (int l = 0; l < 3; ++l) { sig.push_back((uintptr_t)c->fine_kappa[l]); for (int s2 = 0; s2 < FN.plan.nacc[l]; ++s2) sig.push_back((uintptr_t)c->fine_acc[l][s2]); }
+    if (FN.active) for (int l = 0; l < 3; ++l) { sig.push_back((uintptr_t)c->fine_kappa[l]); sig.push_back((uintptr_t)c->fine_emis[l]); for (int s2 = 0; s2 < FN.plan.nacc[l]; ++s2) sig.push_back((uintptr_t)c->fine_acc[l][s2]); }
     FTTE_HIP(c, hipEventRecord(Tm.start, stream));
     bool replayed = false;
     if (c->use_graph && H.graph_exec && H.graph_sig == sig) {

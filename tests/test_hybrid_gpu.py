@@ -344,3 +344,29 @@ def test_fine_block_many_directions_pipelines_and_the_forest_for_it():
         assert e.counter("fine_block") == 0
         e.set_option("hybrid", 0)
         assert np.allclose(J, e.transport(phi, theta, w, uvb), rtol=SUM_RTOL, atol=0)
+
+
+@pytest.mark.parametrize("which", ["source", "eta"])
+def test_fine_block_with_emission(which):
+    """A source function or the reference's emissivity term through the fine block's own bricks (their rows gathered and transposed
+    like the opacities): every third izone bit for bit against the oracle's tree sweep with the same term; in radiative equilibrium
+    (S = inflow) J = inflow to the rounding of the sum, fine cells and coarse cells alike."""
+    n = 64
+    level, kappa, uvb = _cube_case(n, 32, (16, 16, 16), 2, seed=47)
+    rng = np.random.default_rng(5)
+    X = rng.random(kappa.shape) * (2e-21 if which == "source" else 2e-21 * kappa.mean())
+    kw = dict(src=X) if which == "source" else dict(eta=X)
+    with rt.DiffuseTransfer() as e:
+        e.set_grid(n, level, 1.0)
+        e.set_opacity(kappa)
+        (e.set_source_function if which == "source" else e.set_emissivity)(X)
+        for p, t in one_per_izone()[::3]:
+            phi, theta, w = np.array([p]), np.array([t]), np.array([0.37])
+            J = e.transport(phi, theta, w, uvb)
+            assert e.counter("fine_block") == 64
+            assert np.array_equal(J, O.sweep_tree(n, level, kappa, 1.0, phi, theta, w, uvb, arith=O.ARITH_DEVICE, **kw)), f"izone {O.fold_direction(p, t)[2]}"
+        if which == "source":
+            phi, theta, w = O.healpix_directions(2)
+            e.set_source_function(np.repeat(uvb[:, None], len(level), 1))
+            Jeq = e.transport(phi, theta, w, uvb)
+            assert np.allclose(Jeq, uvb[:, None] * w.sum(), rtol=64 * EPS, atol=0)
