@@ -191,57 +191,6 @@ FTTE_HD int ftte_attenuation_lead(const ftte_consts *K, double lead, double tau,
     return 1;
 }
 
-/* The attenuation pairs of the two (three) segments of ONE cell -- one opacity, the path lengths of the ray's pieces -- behind one
- * test of the wavefront, the polynomials in one block: the chains are independent of each other (and of the intensities), so the
- * instruction scheduler interleaves them, and a wavefront issues two (three) dependent chains instead of one.  Same values as one
- * call of ftte_attenuation_lead per segment. */
-FTTE_HD int ftte_attenuation2(const ftte_consts *K, double lead, double tau0, double tau1, double *e, double *g)
-{
-    if (__builtin_expect(!FTTE_ANY(!(__builtin_fabs(tau0) <= K->thin_max) || !(__builtin_fabs(tau1) <= K->thin_max)), 1)) {
-        ftte_exp_reduced(K, lead, tau0, &e[0], &g[0]);
-        ftte_exp_reduced(K, lead, tau1, &e[1], &g[1]);
-        return 0;
-    }
-    ftte_exp_reduced(K, lead, ftte_reduce(K, tau0), &e[0], &g[0]);
-    ftte_thick_part(K, tau0, &e[0], &g[0]);
-    ftte_exp_reduced(K, lead, ftte_reduce(K, tau1), &e[1], &g[1]);
-    ftte_thick_part(K, tau1, &e[1], &g[1]);
-    return 1;
-}
-
-FTTE_HD int ftte_attenuation3(const ftte_consts *K, double lead, double tau0, double tau1, double tau2, double *e, double *g)
-{
-    if (__builtin_expect(!FTTE_ANY(!(__builtin_fabs(tau0) <= K->thin_max) || !(__builtin_fabs(tau1) <= K->thin_max) ||
-                                   !(__builtin_fabs(tau2) <= K->thin_max)), 1)) {
-        ftte_exp_reduced(K, lead, tau0, &e[0], &g[0]);
-        ftte_exp_reduced(K, lead, tau1, &e[1], &g[1]);
-        ftte_exp_reduced(K, lead, tau2, &e[2], &g[2]);
-        return 0;
-    }
-    ftte_exp_reduced(K, lead, ftte_reduce(K, tau0), &e[0], &g[0]);
-    ftte_thick_part(K, tau0, &e[0], &g[0]);
-    ftte_exp_reduced(K, lead, ftte_reduce(K, tau1), &e[1], &g[1]);
-    ftte_thick_part(K, tau1, &e[1], &g[1]);
-    ftte_exp_reduced(K, lead, ftte_reduce(K, tau2), &e[2], &g[2]);
-    ftte_thick_part(K, tau2, &e[2], &g[2]);
-    return 1;
-}
-
-/* The segment itself, given its attenuation pair: what ftte_segment_lead does behind the pair.  `thick`: some lane of the
- * wavefront (or some segment of the cell) left the thin range; only then can a nonzero Iin end as Iout = 0. */
-FTTE_HD double ftte_segment_apply(double *I, double e, double g, int thick)
-{
-    const double Iin = *I;
-    const double Iout = Iin * e;
-    double mean = Iin * g;
-    if (thick) {
-        mean = (Iout == 0.0) ? 0.0 : mean;
-        FTTE_KEEP(mean);
-    }
-    *I = Iout;
-    return mean;
-}
-
 /* One segment: advances the ray intensity and returns the path-mean intensity
  * the cell receives from it.  Iout == 0 (underflow) yields a zero mean, as the
  * reference's (Iin-0)/log(Iin/0) does.  A thin segment (n = 0: exp(-tau) > 0.7) takes a nonzero Iin to a nonzero Iout --
