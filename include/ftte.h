@@ -319,7 +319,9 @@ int ftte_host_unregister(ftte_ctx *ctx, void *ptr);
  * when the last sweep did not take the hybrid path; "fine_block": fine cells a side of the refined block that plan sweeps with bricks of
  * its own (0: none); "brick_form": the form of the brick kernel the last uniform-grid sweep of the
  * brick engine took (option "team": 0 or 2; -1 before the first); "devices"; of a multi-device context also "frequency_slices",
- * "direction_slices" and "multi_rccl" (1: the last direction-split sweep was summed over RCCL), the rest from its first device.
+ * "direction_slices" and "multi_rccl" (1: the last direction-split sweep was summed over RCCL), "rccl_loadable", "rccl_selftest" (runs the
+ * direction sum's RCCL calls on a clique of one rank, the first device: 1 = the piece came back unchanged; negative = it could not
+ * run), the rest from its first device.
  * -1 for an unknown name. */
 long long ftte_counter(const ftte_ctx *ctx, const char *name);
 

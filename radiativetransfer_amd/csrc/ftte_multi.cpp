@@ -350,9 +350,47 @@ int multi_iteration(ftte_ctx *c, int nnu, const double *kappa, int ndir, const d
     return multi_sweep(c, ndir, phi, theta, w, uvb, J);
 }
 
+// The calling sequence of the direction sum -- ncclCommInitAll, a grouped ncclReduceScatter of doubles on the sweep's stream,
+// ncclCommDestroy -- on a clique of ONE rank, the first device: what a box with a single GPU can check of the RCCL branch (that the
+// library loads, that the entry points take these arguments, that the result lands where the sweep expects it).
+// 1: the piece came back unchanged; 0: it did not; -(1000 + r): RCCL returned r; -1: librccl is not loadable; -2: a HIP call failed.
+static long long rccl_selftest(const Multi &M)
+{
+    if (!g_rccl.load()) return -1;
+    const int dev = M.dev[0];
+    if (hipSetDevice(dev) != hipSuccess) return -2;
+    const size_t n = 4096;
+    std::vector<double> in(n), out(n, 0.0);
+    for (size_t i = 0; i < n; ++i) in[i] = 1.0 / (double)(i + 3);
+    double *d_in = nullptr, *d_out = nullptr;
+    void *comm = nullptr;
+    long long verdict = -2;
+    hipStream_t stream = M.sub[0]->stream;
+    if (hipMalloc((void **)&d_in, n * sizeof(double)) == hipSuccess && hipMalloc((void **)&d_out, n * sizeof(double)) == hipSuccess &&
+        hipMemcpy(d_in, in.data(), n * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+        hipMemset(d_out, 0, n * sizeof(double)) == hipSuccess) {
+        int rc = g_rccl.CommInitAll(&comm, 1, &dev);
+        if (!rc) {
+            rc = g_rccl.GroupStart();
+            if (!rc) rc = g_rccl.ReduceScatter(d_in, d_out, n, /*ncclDouble*/ 8, /*ncclSum*/ 0, comm, stream);
+            const int erc = g_rccl.GroupEnd();
+            if (!rc) rc = erc;
+        }
+        if (rc) verdict = -(1000 + rc);
+        else if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(out.data(), d_out, n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess)
+            verdict = std::memcmp(in.data(), out.data(), n * sizeof(double)) == 0 ? 1 : 0;
+    }
+    if (comm) (void)g_rccl.CommDestroy(comm);
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    (void)hipGetLastError();
+    return verdict;
+}
+
 long long multi_counter(const ftte_ctx *c, const char *name)
 {
     const Multi &M = *c->multi;
+    if (!std::strcmp(name, "rccl_selftest")) return rccl_selftest(M);
     if (!std::strcmp(name, "devices")) return (long long)M.sub.size();
     if (!std::strcmp(name, "multi_rccl")) return M.rccl ? 1 : 0;
     if (!std::strcmp(name, "rccl_loadable")) return g_rccl.load() ? 1 : 0; // librccl.so is there and has the entry points this file calls

@@ -114,3 +114,17 @@ def test_rccl_is_there_for_distinct_devices():
     (ncclCommInitAll, ncclReduceScatter, ncclGroupStart/End, ncclCommDestroy, ncclGetErrorString)."""
     with rt.DiffuseTransfer(devices=[0, 0]) as e:
         assert e.counter("rccl_loadable") == 1
+
+
+def test_rccl_calling_sequence_on_a_clique_of_one():
+    """ncclCommInitAll, a grouped ncclReduceScatter of doubles on the sweep's stream and ncclCommDestroy, on one rank: the library
+    takes the arguments csrc/ftte_multi.cpp passes and the piece lands in the receive buffer unchanged (sum over one rank)."""
+    with rt.DiffuseTransfer(devices=[0, 0]) as e:
+        assert e.counter("rccl_selftest") == 1
+        n = 16                                                      # and the context still sweeps afterwards
+        kappa, uvb, box = synthetic.uniform_workload(n, 2, seed=3, tau_median=0.2)
+        phi, theta, w = O.healpix_directions(1)
+        e.set_uniform_grid(n, box)
+        e.set_opacity(kappa)
+        J = e.transport(phi, theta, w, uvb)
+    assert np.allclose(J, O.sweep_uniform(n, kappa, box, phi, theta, w, uvb, arith=O.ARITH_DEVICE), rtol=SUM_RTOL, atol=0)
