@@ -97,8 +97,8 @@ struct Builder {
     double phi, theta;
     int cs[2][2][2]; // storage child index of the sweep child (i,j,k)
     std::vector<PatNode> pats;
-    std::vector<int32_t> node_pat;
-    std::vector<int32_t> depth;
+    std::vector<int32_t> &node_pat;
+    std::vector<int32_t> &depth;
     int32_t anc[64];
     int seq[64][3];
     int status = 0;
@@ -106,10 +106,11 @@ struct Builder {
     const ForestRegion *reg = nullptr;
     // fine blocks swept by bricks of their own (ForestRegion::has_fine): which nodes are their leaves and where in the block (fine
     // sweep coordinates, 1-based); which segments of the forest come after the blocks' bricks
-    std::vector<uint8_t> is_hole, late;
-    std::vector<int16_t> fine_at; // [3 nodes]
+    std::vector<uint8_t> &is_hole, &late;
+    std::vector<int16_t> &fine_at; // [3 nodes]
 
-    Builder(const AmrTree &t, AmrForest &f) : T(t), F(f) {}
+    Builder(const AmrTree &t, AmrForest &f)
+        : T(t), F(f), node_pat(f.scratch.node_pat), depth(f.scratch.depth), is_hole(f.scratch.is_hole), late(f.scratch.late), fine_at(f.scratch.fine_at) {}
 
     // Where the ray that enters fine cell (fi, fj, fk) [fine sweep frame of the region's block, 1-based; n_f + 1 on an axis: the
     // position just behind the block] through `face` waits in the direction's face block: what the fine bricks read at the block's
@@ -256,10 +257,16 @@ struct Builder {
             else if (face == 1) { a = P.xz_x0; b = P.xz_z0; len = P.xz_len; }
             else { a = P.yz_y0; b = P.yz_z0; len = P.yz_len; }
             F.dpath[seg] = cell * len;
-            const int32_t U = upstream_leaf(lvl, face, a, b);
             if (hole) {
                 F.up[seg] = AmrForest::kInflow; // (active; never listed)
-                if (U >= 0 && is_hole[(size_t)U]) continue; // inside the block: the bricks hand the ray over themselves
+                // behind a sibling, or behind a child of the base cell before this one where that is the block's too: inside the
+                // block, the bricks hand the ray over themselves (and the block's interior is not walked: no marks to ask)
+                int before[3] = {seq[0][0], seq[0][1], seq[0][2]};
+                --before[face];
+                if (seq[1][face] == 2 || reg->in_fine(before[0], before[1], before[2])) continue;
+            }
+            const int32_t U = upstream_leaf(lvl, face, a, b);
+            if (hole) {
                 AmrForest::FineImport X{fine_element(fc[0], fc[1], fc[2], face), -1, -1};
                 if (U >= 0) {
                     if (node_pat[U] < 0) { status = FTTE_ERR_STATE; err = "hybrid sweep: a fine block touches the region's surface"; return; }
@@ -315,7 +322,8 @@ struct Builder {
         if (status) return;
         node_pat[node] = pat;
         anc[lvl] = node;
-        if (T.child0[node] < 0) { leaf_segments(node, lvl, cell); return; }
+        if (reg) F.scratch.nodes.push_back(node);
+        if (T.child0[node] < 0) { if (reg) F.visited.push_back(T.leaf[node]); leaf_segments(node, lvl, cell); return; }
         for (int i = 0; i < 2; ++i)
             for (int j = 0; j < 2; ++j)
                 for (int k = 0; k < 2; ++k) {
@@ -343,12 +351,40 @@ int build_forest_regions(const AmrTree &tree, double phi, double theta, int izon
     const int64_t nseg = 3 * tree.ncell;
     const bool restricted = !regions.empty();
     F.izone = izone; F.phi = phi; F.theta = theta;
-    F.up.assign(nseg, AmrForest::kInactive);
-    F.up2.assign(nseg, -1);
-    F.dpath.assign(nseg, 0.0);
-
-    F.import_at.clear(); F.exports.clear(); F.inside.clear();
-    if (restricted) { F.import_at.assign(nseg, -1); F.inside.assign((size_t)tree.ncell, 0); }
+    bool any_fine = false;
+    for (const ForestRegion &R : regions) any_fine = any_fine || R.has_fine;
+    AmrForest::Scratch &S = F.scratch;
+    const int64_t nnode = (int64_t)tree.parent.size();
+    // a forest of this tree that a restricted build left: everything but the leaves and nodes that build walked holds the defaults
+    const bool again = restricted && S.ncell == tree.ncell && S.nnode == nnode && S.fine == any_fine && (int64_t)F.up.size() == nseg &&
+                       (int64_t)F.inside.size() == tree.ncell;
+    if (again) {
+        for (int32_t leaf : F.visited) {
+            for (int64_t s = 3 * (int64_t)leaf; s < 3 * (int64_t)leaf + 3; ++s) {
+                F.up[(size_t)s] = AmrForest::kInactive; F.up2[(size_t)s] = -1; F.import_at[(size_t)s] = -1; S.depth[(size_t)s] = 0;
+                if (any_fine) S.late[(size_t)s] = 0;
+            }
+            F.inside[(size_t)leaf] = 0; S.pass_of[(size_t)leaf] = 0;
+        }
+        for (int32_t node : S.nodes) { S.node_pat[(size_t)node] = -1; if (any_fine) S.is_hole[(size_t)node] = 0; }
+    } else {
+        F.up.assign(nseg, AmrForest::kInactive);
+        F.up2.assign(nseg, -1);
+        F.dpath.assign(nseg, 0.0);
+        F.import_at.clear(); F.inside.clear();
+        if (restricted) { F.import_at.assign(nseg, -1); F.inside.assign((size_t)tree.ncell, 0); }
+        S.node_pat.assign((size_t)nnode, -1);
+        S.depth.assign(nseg, 0);
+        S.is_hole.clear(); S.fine_at.clear(); S.late.clear(); S.pass_of.clear();
+        if (any_fine) {
+            S.is_hole.assign((size_t)nnode, 0);
+            S.fine_at.assign(3 * (size_t)nnode, 0);
+            S.late.assign((size_t)nseg, 0);
+        }
+        if (restricted) S.pass_of.assign((size_t)tree.ncell, 0);
+        S.ncell = restricted ? tree.ncell : -1; S.nnode = nnode; S.fine = any_fine;
+    }
+    F.visited.clear(); S.nodes.clear(); F.exports.clear();
     Builder B(tree, F);
     B.izone = izone; B.phi = phi; B.theta = theta; B.reg = nullptr;
     for (int i = 0; i < 2; ++i)
@@ -365,25 +401,15 @@ int build_forest_regions(const AmrTree &tree, double phi, double theta, int izon
     }
     B.pats.resize(n);
     for (int i = 0; i < n; ++i) { B.pats[i].p = layers[i]; B.pats[i].sub[0] = B.pats[i].sub[1] = -1; }
-    B.node_pat.assign(tree.parent.size(), -1);
-    B.depth.assign(nseg, 0);
     F.fine_imports.clear();
-    bool any_fine = false;
-    for (const ForestRegion &R : regions) any_fine = any_fine || R.has_fine;
-    if (any_fine) {
-        B.is_hole.assign(tree.parent.size(), 0);
-        B.fine_at.assign(3 * tree.parent.size(), 0);
-        B.late.assign((size_t)nseg, 0);
-    }
     const int per_box = any_fine ? 2 : 1; // passes per box: before and after its fine block's bricks
 
     const double cell = box / (double)n; // equiSources.f90:1570
     // pass of every leaf that belongs to a box (0 without boxes); exports carry their box's pass until they are sorted
-    std::vector<uint8_t> pass_of;
+    std::vector<uint8_t> &pass_of = S.pass_of;
     std::vector<int> export_pass;
     int npass = 1;
     if (restricted) {
-        pass_of.assign((size_t)tree.ncell, 0);
         for (const ForestRegion &R : regions) {
             if (R.pass < 0 || R.pass > 254) { *err = "hybrid sweep: too many passes"; return FTTE_ERR_STATE; }
             npass = std::max(npass, per_box * (R.pass + 1));
@@ -404,6 +430,9 @@ int build_forest_regions(const AmrTree &tree, double phi, double theta, int izon
                     B.seq[0][0] = i; B.seq[0][1] = j; B.seq[0][2] = k;
                     const int32_t node = (int32_t)(((int64_t)(ic - 1) * n + (jc - 1)) * n + (kc - 1));
                     if (R && B.node_pat[node] >= 0) { *err = "hybrid sweep: two boxes overlap"; return FTTE_ERR_STATE; }
+                    // (a base cell in the interior of a fine block -- itself, what lies before it and what lies behind it all swept
+                    // by the block's bricks -- has nothing to tell the forest: not walked)
+                    if (R && R->in_fine(i, j, k) && R->in_fine(i - 1, j - 1, k - 1) && R->in_fine(i + 1, j + 1, k + 1)) continue;
                     B.visit(node, i - 1, 0, cell);
                 }
         if (B.status) break;
@@ -414,6 +443,7 @@ int build_forest_regions(const AmrTree &tree, double phi, double theta, int izon
             for (int j = lo1; j <= hi1; ++j)
                 for (int k = lo2; k <= hi2; ++k) {
                     int ic, jc, kc;
+                    if (R->in_fine(i, j, k) && R->in_fine(i - 1, j - 1, k - 1) && R->in_fine(i + 1, j + 1, k + 1)) continue; // (not walked: not the forest's)
                     rotate_indices(i, j, k, n, n, n, izone, &ic, &jc, &kc);
                     B.mark_inside((int32_t)(((int64_t)(ic - 1) * n + (jc - 1)) * n + (kc - 1)), (uint8_t)R->pass, pass_of);
                 }
@@ -444,17 +474,22 @@ int build_forest_regions(const AmrTree &tree, double phi, double theta, int izon
     std::vector<int32_t> maxd((size_t)npass, -1);
     auto pass_of_seg = [&](int64_t s) { return restricted ? per_box * (int)pass_of[(size_t)(s / 3)] + (any_fine && B.late[(size_t)s] ? 1 : 0) : 0; };
     auto listed = [&](int64_t s) { return F.up[s] != AmrForest::kInactive && (!restricted || F.inside[(size_t)(s / 3)]); };
-    for (int64_t s = 0; s < nseg; ++s) if (listed(s)) maxd[(size_t)pass_of_seg(s)] = std::max(maxd[(size_t)pass_of_seg(s)], B.depth[s]);
+    // (restricted: only the leaves that were walked can be listed; in ascending order, as a run over all segments would meet them)
+    if (restricted) std::sort(F.visited.begin(), F.visited.end());
+    auto every_segment = [&](auto &&f) {
+        if (restricted) { for (int32_t leaf : F.visited) for (int64_t s = 3 * (int64_t)leaf; s < 3 * (int64_t)leaf + 3; ++s) f(s); }
+        else for (int64_t s = 0; s < nseg; ++s) f(s);
+    };
+    every_segment([&](int64_t s) { if (listed(s)) maxd[(size_t)pass_of_seg(s)] = std::max(maxd[(size_t)pass_of_seg(s)], B.depth[s]); });
     F.pass_first.assign((size_t)npass + 1, 0);
     for (int p = 0; p < npass; ++p) F.pass_first[(size_t)p + 1] = F.pass_first[(size_t)p] + (maxd[(size_t)p] + 1);
     const size_t ndepth = (size_t)F.pass_first[(size_t)npass];
     F.depth_off.assign(ndepth + 1, 0);
-    for (int64_t s = 0; s < nseg; ++s) if (listed(s)) ++F.depth_off[(size_t)F.pass_first[(size_t)pass_of_seg(s)] + (size_t)B.depth[s] + 1];
+    every_segment([&](int64_t s) { if (listed(s)) ++F.depth_off[(size_t)F.pass_first[(size_t)pass_of_seg(s)] + (size_t)B.depth[s] + 1]; });
     for (size_t d = 1; d < F.depth_off.size(); ++d) F.depth_off[d] += F.depth_off[d - 1];
     F.order.resize((size_t)F.depth_off.back());
     std::vector<int64_t> cursor(F.depth_off.begin(), F.depth_off.end() - 1);
-    for (int64_t s = 0; s < nseg; ++s)
-        if (listed(s)) F.order[(size_t)cursor[(size_t)F.pass_first[(size_t)pass_of_seg(s)] + (size_t)B.depth[s]]++] = (int32_t)s;
+    every_segment([&](int64_t s) { if (listed(s)) F.order[(size_t)cursor[(size_t)F.pass_first[(size_t)pass_of_seg(s)] + (size_t)B.depth[s]]++] = (int32_t)s; });
     // the rays that leave the boxes, pass after pass
     F.export_first.assign((size_t)npass + 1, 0);
     if (!F.exports.empty()) {

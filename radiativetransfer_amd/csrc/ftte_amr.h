@@ -88,6 +88,18 @@ struct AmrForest {
     std::vector<int64_t> export_first; // [npass + 1] where each pass's rays start in `exports` (sorted by pass)
     int izone = 0;
     double phi = 0, theta = 0;
+    // Builds restricted to boxes touch a small part of the tree.  `visited` lists the leaves the last build walked (ascending) --
+    // all the others hold the defaults: up = kInactive, up2 = import_at = -1, inside = 0 -- and an AmrForest handed to
+    // build_forest_regions again for the same tree is cleaned leaf by leaf instead of being filled anew: the builder's work then
+    // follows the boxes, not the tree.  (Empty after a build over the whole tree.)
+    std::vector<int32_t> visited;
+    struct Scratch {                         // the builder's own arrays, kept with the forest for the same reason
+        std::vector<int32_t> node_pat, depth, nodes;
+        std::vector<uint8_t> is_hole, late, pass_of;
+        std::vector<int16_t> fine_at;
+        int64_t ncell = -1, nnode = -1;      // the tree they are sized for, and clean for (apart from `visited` / `nodes`)
+        bool fine = false;
+    } scratch;
 };
 
 // Returns 0, or an ftte_status (FTTE_ERR_PATTERN where the reference stops: a pattern leaving the unit cell,

@@ -565,57 +565,62 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
     const int nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     std::vector<uint8_t> in_any((size_t)ncell, 0);
     std::vector<std::vector<SegRec>> rec((size_t)ndir);
-    std::vector<std::vector<uint8_t>> active((size_t)ndir);  // per leaf, until the list is known
+    // per direction: which pieces the leaves it walked have, and whether they are the forest's (every other leaf: not the forest's)
+    std::vector<std::vector<std::pair<int32_t, uint8_t>>> active((size_t)ndir);
     std::vector<std::vector<AmrExport>> exports((size_t)ndir);
     std::vector<std::vector<AmrImport>> imports((size_t)ndir);
     ++c->n_forest_builds;
-    for (int d0 = 0; d0 < ndir; d0 += nthreads) {
-        const int nbt = std::min(nthreads, ndir - d0);
-        std::vector<AmrForest> F(nbt);
-        std::vector<int> st(nbt, 0);
-        std::vector<std::string> msg(nbt);
+    static_assert(sizeof(AmrForest::Export) == sizeof(AmrExport), "export records: host and device forms must agree");
+    static_assert(sizeof(AmrForest::FineImport) == sizeof(AmrImport), "import records: host and device forms must agree");
+    {
+        // a thread keeps its forest from direction to direction: after the first, a build touches only what the boxes hold (ftte_amr.h)
+        const int nt = std::min(nthreads, ndir);
+        std::vector<int> st((size_t)ndir, 0);
+        std::vector<std::string> msg((size_t)ndir);
+        std::vector<std::vector<int32_t>> seen((size_t)nt); // leaves inside a box of at least one of the thread's directions
         std::vector<std::thread> pool;
-        for (int t = 0; t < nbt; ++t)
+        for (int t = 0; t < nt; ++t)
             pool.emplace_back([&, t] {
-                const int d = d0 + t;
-                const DirPlan &D = P.dirs[(size_t)d];
-                std::vector<ForestRegion> regions;
-                for (const HybridBox &B : boxes[(size_t)group_of[(size_t)d]]) regions.push_back(B.R);
-                st[t] = build_forest_regions(c->tree, D.phi, D.theta, D.izone, c->box, &F[t], &msg[t], regions);
-                if (st[t]) return;
-                const AmrForest &f = F[t];
-                const size_t nact = f.order.size();
-                rec[(size_t)d].resize(std::max<size_t>(nact, 1));
-                for (size_t q = 0; q < nact; ++q) {
-                    const int32_t sg = f.order[q];
-                    SegRec &R = rec[(size_t)d][q];
-                    R.seg = sg; R.up = f.up[sg]; R.up2 = f.up2[sg];
-                    R.at = f.up[sg] == AmrForest::kImport ? f.import_at[sg] : 0;
-                    R.dpath = f.dpath[sg];
+                AmrForest f;
+                for (int d = t; d < ndir; d += nt) {
+                    const DirPlan &D = P.dirs[(size_t)d];
+                    std::vector<ForestRegion> regions;
+                    for (const HybridBox &B : boxes[(size_t)group_of[(size_t)d]]) regions.push_back(B.R);
+                    st[(size_t)d] = build_forest_regions(c->tree, D.phi, D.theta, D.izone, c->box, &f, &msg[(size_t)d], regions);
+                    if (st[(size_t)d]) return;
+                    const size_t nact = f.order.size();
+                    rec[(size_t)d].resize(std::max<size_t>(nact, 1));
+                    for (size_t q = 0; q < nact; ++q) {
+                        const int32_t sg = f.order[q];
+                        SegRec &R = rec[(size_t)d][q];
+                        R.seg = sg; R.up = f.up[sg]; R.up2 = f.up2[sg];
+                        R.at = f.up[sg] == AmrForest::kImport ? f.import_at[sg] : 0;
+                        R.dpath = f.dpath[sg];
+                    }
+                    active[(size_t)d].reserve(f.visited.size());
+                    for (int32_t q : f.visited) {
+                        active[(size_t)d].push_back({q, (uint8_t)((f.up[3 * (size_t)q + 1] != AmrForest::kInactive ? 1 : 0) | (f.up[3 * (size_t)q + 2] != AmrForest::kInactive ? 2 : 0) |
+                                                                  (f.inside[(size_t)q] ? 0 : 4))});
+                        if (f.inside[(size_t)q]) seen[(size_t)t].push_back(q);
+                    }
+                    ftte_ctx::HybridPlan::Dir &HD = H.dirs[(size_t)d];
+                    HD.depth_off = f.depth_off;
+                    HD.pass_first = f.pass_first;
+                    HD.export_first = f.export_first;
+                    HD.nexports = (int64_t)f.exports.size();
+                    exports[(size_t)d].resize(f.exports.size());
+                    if (!f.exports.empty()) std::memcpy(exports[(size_t)d].data(), f.exports.data(), sizeof(AmrExport) * f.exports.size());
+                    imports[(size_t)d].resize(f.fine_imports.size());
+                    if (!f.fine_imports.empty()) std::memcpy(imports[(size_t)d].data(), f.fine_imports.data(), sizeof(AmrImport) * f.fine_imports.size());
                 }
-                active[(size_t)d].resize((size_t)ncell);
-                for (int64_t q = 0; q < ncell; ++q)
-                    active[(size_t)d][(size_t)q] = (uint8_t)((f.up[3 * q + 1] != AmrForest::kInactive ? 1 : 0) | (f.up[3 * q + 2] != AmrForest::kInactive ? 2 : 0) |
-                                                             (f.inside[(size_t)q] ? 0 : 4));
             });
         for (auto &th : pool) th.join();
-        for (int t = 0; t < nbt; ++t) {
-            if (st[t]) { const std::string m = msg[t]; const int code = st[t]; free_hybrid(c); return fail(c, code, "direction " + std::to_string(d0 + t) + ": " + m); }
-            ftte_ctx::HybridPlan::Dir &D = H.dirs[(size_t)(d0 + t)];
-            D.depth_off = F[t].depth_off;
-            D.pass_first = F[t].pass_first;
-            D.export_first = F[t].export_first;
-            D.nexports = (int64_t)F[t].exports.size();
-            static_assert(sizeof(AmrForest::Export) == sizeof(AmrExport), "export records: host and device forms must agree");
-            exports[(size_t)(d0 + t)].resize(F[t].exports.size());
-            if (!F[t].exports.empty()) std::memcpy(exports[(size_t)(d0 + t)].data(), F[t].exports.data(), sizeof(AmrExport) * F[t].exports.size());
-            static_assert(sizeof(AmrForest::FineImport) == sizeof(AmrImport), "import records: host and device forms must agree");
-            imports[(size_t)(d0 + t)].resize(F[t].fine_imports.size());
-            if (!F[t].fine_imports.empty()) std::memcpy(imports[(size_t)(d0 + t)].data(), F[t].fine_imports.data(), sizeof(AmrImport) * F[t].fine_imports.size());
-            for (int64_t q = 0; q < ncell; ++q) in_any[(size_t)q] |= F[t].inside[(size_t)q];
-        }
+        for (int d = 0; d < ndir; ++d)
+            if (st[(size_t)d]) { const std::string m = msg[(size_t)d]; const int code = st[(size_t)d]; free_hybrid(c); return fail(c, code, "direction " + std::to_string(d) + ": " + m); }
+        for (const auto &list : seen) for (int32_t q : list) in_any[(size_t)q] = 1;
     }
     std::vector<int32_t> cells, place((size_t)ncell, -1);
+    std::vector<std::vector<uint8_t>> bytes((size_t)ndir); // the activity bytes of the leaves in `cells`, per direction
     for (int64_t q = 0; q < ncell; ++q)
         if (in_any[(size_t)q]) { place[(size_t)q] = (int32_t)cells.size(); cells.push_back((int32_t)q); }
     H.ncells = (int64_t)cells.size();
@@ -641,8 +646,9 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
                         if ((X.up >= 0 && place[(size_t)(X.up / 3)] < 0) || (X.up2 >= 0 && place[(size_t)(X.up2 / 3)] < 0)) { bad[(size_t)d] = 1; break; }
                         X.up = renumber(X.up); X.up2 = renumber(X.up2);
                     }
-                    for (size_t q = 0; q < cells.size(); ++q) compact[q] = active[(size_t)d][(size_t)cells[q]];
-                    active[(size_t)d].assign(compact.begin(), compact.end());
+                    std::fill(compact.begin(), compact.end(), (uint8_t)4);
+                    for (const auto &a : active[(size_t)d]) if (place[(size_t)a.first] >= 0) compact[(size_t)place[(size_t)a.first]] = a.second;
+                    bytes[(size_t)d] = compact;
                 }
             });
         for (auto &th : pool) th.join();
@@ -652,10 +658,10 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
     for (int d = 0; d < ndir; ++d) {
         ftte_ctx::HybridPlan::Dir &D = H.dirs[(size_t)d];
         FTTE_HIP(c, hipMalloc((void **)&D.rec, sizeof(SegRec) * rec[(size_t)d].size()));
-        FTTE_HIP(c, hipMalloc((void **)&D.active, std::max<size_t>(active[(size_t)d].size(), 1)));
+        FTTE_HIP(c, hipMalloc((void **)&D.active, std::max<size_t>(bytes[(size_t)d].size(), 1)));
         FTTE_HIP(c, hipMalloc((void **)&D.exports, sizeof(AmrExport) * std::max<size_t>(exports[(size_t)d].size(), 1)));
         FTTE_HIP(c, hipMemcpy(D.rec, rec[(size_t)d].data(), sizeof(SegRec) * rec[(size_t)d].size(), hipMemcpyHostToDevice));
-        if (!active[(size_t)d].empty()) FTTE_HIP(c, hipMemcpy(D.active, active[(size_t)d].data(), active[(size_t)d].size(), hipMemcpyHostToDevice));
+        if (!bytes[(size_t)d].empty()) FTTE_HIP(c, hipMemcpy(D.active, bytes[(size_t)d].data(), bytes[(size_t)d].size(), hipMemcpyHostToDevice));
         if (!exports[(size_t)d].empty())
             FTTE_HIP(c, hipMemcpy(D.exports, exports[(size_t)d].data(), sizeof(AmrExport) * exports[(size_t)d].size(), hipMemcpyHostToDevice));
         D.nimports = (int64_t)imports[(size_t)d].size();
@@ -664,7 +670,7 @@ int build_hybrid_plan(ftte_ctx *c, int ndir, const double *phi, const double *th
             FTTE_HIP(c, hipMemcpy(D.imports, imports[(size_t)d].data(), sizeof(AmrImport) * imports[(size_t)d].size(), hipMemcpyHostToDevice));
         }
         std::vector<SegRec>().swap(rec[(size_t)d]);
-        std::vector<uint8_t>().swap(active[(size_t)d]);
+        std::vector<uint8_t>().swap(bytes[(size_t)d]);
     }
     if (FN.active) {
         // fine cell (storage order inside the block) -> leaf: the children of a refined base cell follow each other in the cell array

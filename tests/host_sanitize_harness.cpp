@@ -38,6 +38,18 @@ static void random_levels(int n, double p, int max_level, std::vector<int32_t> *
     for (int b = 0; b < n * n * n; ++b) Rec::go(0, p, max_level, levels);
 }
 
+static bool same_forest(const AmrForest &A, const AmrForest &B)
+{
+    bool same = A.up == B.up && A.up2 == B.up2 && A.import_at == B.import_at && A.inside == B.inside && A.order == B.order &&
+                A.depth_off == B.depth_off && A.pass_first == B.pass_first && A.export_first == B.export_first &&
+                A.exports.size() == B.exports.size() && A.fine_imports.size() == B.fine_imports.size() && A.visited == B.visited;
+    for (size_t q = 0; same && q < A.exports.size(); ++q) same = A.exports[q].at == B.exports[q].at && A.exports[q].seg == B.exports[q].seg;
+    for (size_t q = 0; same && q < A.fine_imports.size(); ++q)
+        same = A.fine_imports[q].at == B.fine_imports[q].at && A.fine_imports[q].up == B.fine_imports[q].up && A.fine_imports[q].up2 == B.fine_imports[q].up2;
+    for (size_t q = 0; same && q < A.order.size(); ++q) same = A.dpath[(size_t)A.order[q]] == B.dpath[(size_t)B.order[q]];
+    return same;
+}
+
 static void check_forest(const AmrTree &T, const AmrForest &F, const ForestRegion *R, int64_t face_elems)
 {
     const int64_t nseg = 3 * T.ncell;
@@ -191,6 +203,76 @@ int main()
                 CHECK(F.inside[(size_t)leaf], "pass 0 lists a leaf outside the boxes");
             }
             CHECK(F.export_first[1] > 0 && F.export_first[2] == (int64_t)F.exports.size(), "the first box hands rays on, the second reaches the boundary");
+            // a forest kept from direction to direction (cleaned leaf by leaf, ftte_amr.h) comes out as a fresh one does
+            static AmrForest kept;
+            CHECK(build_forest_regions(T, phi, theta, izone, 1.0, &kept, &err, regions) == 0, "two boxes, kept forest: %s", err.c_str());
+            CHECK(same_forest(kept, F), "a kept forest differs from a fresh one");
+            ++cases;
+        }
+    }
+    // a fully refined block swept by bricks of its own (ForestRegion::has_fine): a forest with a hole, two passes, imports into the
+    // block and out of it; fresh and kept forests agree, every index lies inside the face block
+    {
+        const int n = 36, q = 32, lo = 3, hi = lo + q - 1; // symmetric: every izone sees the block at the same place; 2 q = one brick's lanes
+        std::vector<int32_t> levels;
+        for (int b = 0; b < n * n * n; ++b) {
+            const int c3[3] = {b / (n * n) + 1, (b / n) % n + 1, b % n + 1};
+            bool fine = true;
+            for (int a = 0; a < 3; ++a) fine = fine && c3[a] >= lo && c3[a] <= hi;
+            if (fine) for (int c = 0; c < 8; ++c) levels.push_back(1); else levels.push_back(0);
+        }
+        AmrTree T;
+        const std::string why3 = T.build(n, (int64_t)levels.size(), levels.data());
+        CHECK(why3.empty() && T.max_level == 1, "fine-block tree: %s", why3.c_str());
+        AmrForest kept;
+        for (int pix = 0; pix < 48; pix += 5) {
+            double phi_l, theta_l, phi, theta;
+            int izone;
+            CHECK(pix2ang_nest(2, pix, &phi_l, &theta_l) == 0 && fold_direction(phi_l, theta_l, &phi, &theta, &izone) == 0, "direction");
+            ForestRegion R;
+            R.chunk = 2; R.ut = 8; R.nslot = 2;
+            const int ntu = 1, ntv = 5;
+            R.ntv = ntv; R.up = 64; R.vp = 40;
+            R.vface_off = (int64_t)ntu * R.nslot * R.chunk * ((int64_t)ntv * R.ut);
+            R.iface_off = R.vface_off + (int64_t)ntv * R.nslot * R.chunk * R.up;
+            R.uqface_off = R.iface_off + (int64_t)R.nslot * R.vp * R.up;
+            const int64_t base_elems = R.uqface_off + 2 * (int64_t)R.nslot * R.chunk * ((int64_t)ntv * R.ut);
+            R.u_is_k = (pix & 2) != 0;
+            // (the box: on brick boundaries along the march and along v -- here the whole extent --, one cell of rim along the lanes)
+            const int iu = R.u_is_k ? 2 : 1;
+            for (int a = 0; a < 3; ++a) { R.lo[a] = a == iu ? lo - 1 : 1; R.hi[a] = a == iu ? hi + 1 : n; R.flo[a] = lo; R.fhi[a] = hi; }
+            R.has_fine = true;
+            ForestRegion::FineFaces &Q = R.fine; // a sub-grid of 64 fine cells a side: one brick across, a ring / slot more at the edges
+            Q.chunk = 16; Q.ut = 8; Q.nslot = 2 * q / Q.chunk + 1; Q.ntu = 1; Q.ntv = 8; Q.up = 64; Q.vp = 64;
+            Q.vface_off = (int64_t)(Q.ntu + 1) * Q.nslot * Q.chunk * ((int64_t)Q.ntv * Q.ut);
+            Q.iface_off = Q.vface_off + (int64_t)(Q.ntv + 1) * Q.nslot * Q.chunk * Q.up;
+            Q.base = base_elems;
+            const int64_t face_elems = base_elems + Q.iface_off + (int64_t)Q.nslot * Q.vp * Q.up;
+            AmrForest F;
+            std::string err;
+            CHECK(build_forest_regions(T, phi, theta, izone, 1.0, &F, &err, {R}) == 0, "fine block: %s", err.c_str());
+            CHECK(build_forest_regions(T, phi, theta, izone, 1.0, &kept, &err, {R}) == 0, "fine block, kept forest: %s", err.c_str());
+            CHECK(same_forest(kept, F), "fine block: a kept forest differs from a fresh one");
+            CHECK(F.pass_first.size() == 3, "a box with a fine block is swept in two passes");
+            CHECK(!F.fine_imports.empty(), "rays enter the block from the forest");
+            for (const auto &X : F.fine_imports) {
+                CHECK(X.at >= base_elems && X.at < face_elems, "an import lands outside the fine bricks' face block");
+                CHECK(X.up >= -1 && X.up < 3 * T.ncell && X.up2 >= -1 && X.up2 < 3 * T.ncell, "an import reads a segment that is not there");
+                if (X.up >= 0) CHECK(F.inside[(size_t)(X.up / 3)], "an import reads a segment outside the forest");
+            }
+            size_t behind = 0;
+            for (int32_t sg : F.order) {
+                CHECK(F.inside[(size_t)(sg / 3)], "a fine cell is listed in the forest");
+                if (F.up[(size_t)sg] == AmrForest::kImport) {
+                    CHECK(F.import_at[(size_t)sg] >= 0 && F.import_at[(size_t)sg] < face_elems, "a forest segment takes its ray from outside the face block: %d of %lld (base %lld), u_is_k %d", F.import_at[(size_t)sg], (long long)face_elems, (long long)base_elems, (int)R.u_is_k);
+                    if (F.import_at[(size_t)sg] >= base_elems) ++behind;
+                }
+            }
+            CHECK(behind > 0, "no forest segment behind the block");
+            // the leaves of the block: q^3 base cells refined once, none of them the forest's
+            int64_t in_forest = 0;
+            for (int64_t l = 0; l < T.ncell; ++l) in_forest += F.inside[(size_t)l];
+            CHECK(in_forest == (int64_t)n * n * (q + 2) - (int64_t)q * q * q, "the forest holds the cells around the block and nothing of it");
             ++cases;
         }
     }
