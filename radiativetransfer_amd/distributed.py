@@ -192,6 +192,23 @@ class Shard2D:
         lo, hi = self.slab(ncell)
         return out[:, :hi - lo]
 
+    def sum_directions(self, J_local, stage_on_host: bool = False):
+        """In-place sum of J_local[groups of this rank][ncell] over the ranks that sweep the same groups for other directions: what
+        a source iteration needs between two sweeps (every rank of a frequency slice needs the complete J of ITS groups for its
+        next source function and nothing of the other slices': with as many ranks as groups, nothing is sent at all).
+        stage_on_host: the collective runs on a host copy (gloo rehearsals with the ranks sharing one card)."""
+        import torch.distributed as dist
+        if self.world == 1 or self.r_dir == 1:
+            return J_local
+        self._groups()
+        if stage_on_host and J_local.device.type != "cpu":
+            host = J_local.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self._dir_group)
+            J_local.copy_(host)
+        else:
+            dist.all_reduce(J_local, op=dist.ReduceOp.SUM, group=self._dir_group)
+        return J_local
+
     def combine(self, J_local, out=None):
         """J_local: torch tensor [groups of this rank][ncell] (partial over directions if they are split).  Returns
         J[nnu][ncell] (`out` if given)."""

@@ -209,3 +209,40 @@ def test_bench_multi_rank_path_rehearsed_on_one_gpu(tmp_path, ranks, exchange):
     assert line["config"]["ndir_total"] == 96 and line["config"]["nnu"] == 8
     assert line["config"]["nnu_this_rank"] * line["config"]["ndir_this_rank"] * ranks >= 8 * 96   # (3 ranks: 32 directions each)
     assert line["value"] > 0 and "cpu_baseline" not in line
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_source_iteration_over_ranks_rehearsed_on_one_gpu(tmp_path, ranks):
+    """BASELINE configs[4] over several ranks (tools/bench_config5.py under torch.distributed.run; the ranks share GPU 0, the
+    collectives run on host copies over gloo): a rank keeps J and S of its frequency groups.  Two ranks split the eight groups
+    -- nothing is summed, every group's J equals the single-process run bit for bit --, three ranks split the directions -- one
+    all-reduce per iteration, equal to the rounding of the sum over directions carried through the iterations."""
+    import subprocess
+    script = os.path.join(ROOT, "tools", "bench_config5.py")
+    one, many = tmp_path / "one", tmp_path / "many"
+    one.mkdir(); many.mkdir()
+    run = subprocess.run([sys.executable, script, "64", "5", f"--dump={one}"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert run.returncode == 0, run.stderr[-3000:]
+    port = 37100 + os.getpid() % 2000 + ranks
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script, "64", "5", "--rehearse-on-one-gpu", f"--dump={many}"]
+    multi = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert multi.returncode == 0, multi.stderr[-3000:]
+    history = lambda out: [ln.split("|dJ|/|J| = ")[1] for ln in out.splitlines() if "|dJ|/|J|" in ln]
+    assert len(history(multi.stdout)) == len(history(run.stdout)) == 4           # iterations 1, 2, 3 and the last
+    J = np.load(one / "J0.npy")
+    from radiativetransfer_amd.distributed import Shard2D
+    for rank in range(ranks):
+        sh = Shard2D(rank, ranks, 8)
+        lo, hi = sh.groups
+        mine = np.load(many / f"J{rank}.npy")
+        assert mine.shape == (hi - lo, 64 ** 3)
+        if sh.r_dir == 1:
+            assert np.array_equal(mine, J[lo:hi])
+        else:
+            assert np.allclose(mine, J[lo:hi], rtol=1e-12, atol=0)
+    if ranks == 2:
+        assert history(multi.stdout) == history(run.stdout)
+    else:
+        assert np.allclose([float(x) for x in history(multi.stdout)], [float(x) for x in history(run.stdout)], rtol=1e-9)
