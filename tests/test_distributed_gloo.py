@@ -246,3 +246,37 @@ def test_source_iteration_over_ranks_rehearsed_on_one_gpu(tmp_path, ranks):
         assert history(multi.stdout) == history(run.stdout)
     else:
         assert np.allclose([float(x) for x in history(multi.stdout)], [float(x) for x in history(run.stdout)], rtol=1e-9)
+
+
+def _worker_sum(rank, world, port, nnu, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from radiativetransfer_amd.distributed import Shard2D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sh = Shard2D(rank, world, nnu)
+    lo, hi = sh.groups
+    J = torch.from_numpy(np.random.default_rng(100 + rank).random((hi - lo, 50)))
+    np.save(os.path.join(out_dir, f"part{rank}.npy"), J.numpy().copy())
+    sh.sum_directions(J)
+    np.save(os.path.join(out_dir, f"sum{rank}.npy"), J.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nnu", [(2, 2), (3, 2), (4, 2)])
+def test_sum_over_direction_slices_only(tmp_path, world, nnu):
+    """Shard2D.sum_directions, what a source iteration over ranks does between two sweeps: a rank's groups summed over the ranks
+    that sweep the SAME groups for other directions, nothing from the other frequency slices (2 ranks x 2 groups: nothing at all)."""
+    import torch.multiprocessing as mp
+    from radiativetransfer_amd.distributed import Shard2D
+    port = 38100 + os.getpid() % 2000 + 5 * world
+    mp.spawn(_worker_sum, args=(world, port, nnu, str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        sh = Shard2D(rank, world, nnu)
+        peers = [r for r in range(world) if Shard2D(r, world, nnu).i_nu == sh.i_nu]
+        want = sum(np.load(tmp_path / f"part{r}.npy") for r in peers)
+        assert len(peers) == sh.r_dir
+        assert np.allclose(np.load(tmp_path / f"sum{rank}.npy"), want, rtol=4 * np.finfo(float).eps, atol=0)
