@@ -354,6 +354,8 @@ long long ftte_counter(const ftte_ctx *ctx, const char *name);
  *                   its side a multiple of 64 -- is swept by bricks of its own on the fine level, the forests keep what lies around it
  *                   (DESIGN.md 3b); 0 = every leaf of a box through the forests.  "fine_chunk": layers per fine brick (0: as "chunk")
  *     "forest_batch" most directions per launch of the segment forests (0: what the path and the device memory allow)
+ *     "forest_fuse" runs of forest levels with at most this many (segment, frequency group) pairs in the fullest direction go in ONE
+ *                   launch, a workgroup per direction and a barrier per level (default 4096; 0: a launch per level).  Same bits.
  *     "forest"      1: use the segment forests on a uniform grid too, for cross-checks
  *   "ldspad"        diagnostic: extra dynamic LDS per workgroup (bytes), to cap residency
  *   "atomic_acc"    bricks: 1 = later visitors of a shared accumulator add with fp64 atomics instead of read-add-store (default 0)

@@ -347,6 +347,9 @@ int ftte_set_option(ftte_ctx *c, const char *key, int value)
     } else if (!std::strcmp(key, "ablate")) {
         if (value < 0 || value > 63) return fail(c, FTTE_ERR_ARG, "ablate is a mask of 6 bits");
         c->ablate = value;
+    } else if (!std::strcmp(key, "forest_fuse")) {
+        if (value < 0 || value > (1 << 24)) return fail(c, FTTE_ERR_ARG, "forest_fuse must be 0 (a launch per level) .. 16777216");
+        c->forest_fuse = value;
     } else if (!std::strcmp(key, "queue_mix")) {
         if (value < 0 || value > 2) return fail(c, FTTE_ERR_ARG, "queue_mix must be 0, 1 or 2");
         c->queue_mix = value;

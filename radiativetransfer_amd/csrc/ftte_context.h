@@ -266,6 +266,7 @@ struct ftte_ctx {
             LayerRec *layers = nullptr; BrickTask *tasks = nullptr; BrickGroup *groups = nullptr; // device
         } fine;
     } hplan;
+    int forest_fuse = 4096;           // option "forest_fuse": levels of a forest with at most this many (segment, group) pairs in one launch (0: a launch per level)
     int fine_bricks = 1, fine_chunk = 0;  // options "fine_bricks", "fine_chunk" (0: the base bricks' chunk)
     double *fine_kappa[3] = {nullptr, nullptr, nullptr};  // the fine block's opacities, dense, in the three layouts
     size_t fine_kappa_cap = 0;

@@ -1063,7 +1063,7 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
     std::vector<uintptr_t> sig = {(uintptr_t)J_dev, (uintptr_t)stream, (uintptr_t)nnu, (uintptr_t)nh, (uintptr_t)c->kappa[0], (uintptr_t)c->amr_kappa,
                                   (uintptr_t)c->d_faces, (uintptr_t)c->amr_Iout, (uintptr_t)c->amr_mean, (uintptr_t)c->d_bgroups, (uintptr_t)c->d_btasks,
                                   (uintptr_t)c->d_amr_dirs, (uintptr_t)c->d_amr_tables, (uintptr_t)c->d_uvb, (uintptr_t)c->d_leaf_of_base, (uintptr_t)H.cells,
-                                  (uintptr_t)c->brick_waves, (uintptr_t)emit, (uintptr_t)c->emis[0], (uintptr_t)c->amr_emis,
+                                  (uintptr_t)c->brick_waves, (uintptr_t)emit, (uintptr_t)c->emis[0], (uintptr_t)c->amr_emis, (uintptr_t)c->forest_fuse,
                                   (uintptr_t)c->base_emis[0], (uintptr_t)c->base_emis[1], (uintptr_t)c->base_emis[2]};
     for (int l = 0; l < 3; ++l) { sig.push_back((uintptr_t)c->base_kappa[l]); for (int s2 = 0; s2 < P.nacc[l]; ++s2) sig.push_back((uintptr_t)c->acc[l][s2]); }
     if (FN.active) for (int l = 0; l < 3; ++l) { sig.push_back((uintptr_t)c->fine_kappa[l]); sig.push_back((uintptr_t)c->fine_emis[l]); for (int s2 = 0; s2 < FN.plan.nacc[l]; ++s2) sig.push_back((uintptr_t)c->fine_acc[l][s2]); }

@@ -37,6 +37,8 @@ int launch_opacity(const double *HI, const double *HeI, const double *HeII, cons
 // refined cell arrays: one depth of the segment forest of up to kAmrBatch directions; then the per-leaf means into J
 int launch_cell_major(const double *src, double *dst, long ncell, int nnu, hipStream_t stream, const int32_t *cells = nullptr, long count = 0);
 int launch_amr_level(const AmrLevelRec &A, hipStream_t stream);
+// levels depth0 .. depth0 + ndepth - 1 in one launch, a workgroup per direction (tables: those levels' [count[ndir], begin[ndir]] pairs)
+int launch_amr_levels(const AmrLevelRec &A, const int64_t *tables, int ndepth, hipStream_t stream);
 int launch_amr_combine(const AmrLevelRec &A, double *J, bool zero_first, hipStream_t stream);
 
 // point sources: table accumulation (P3), logs of user tables, one pixel level of the tracer (P1 + P2)

@@ -573,18 +573,10 @@ int launch_merge(const double *const *acc, const int *layout, int count, double 
 // ------------------------------------------------------------------------------------------------
 // grid: x over the (segment, frequency group) pairs of the fullest direction, y = direction of the batch.
 // NNU_SHIFT >= 0: nnu = 1 << NNU_SHIFT (no division); -1: any nnu.
-template <int NNU_SHIFT>
-__global__ void __launch_bounds__(256) amr_level_kernel(const AmrLevelRec A)
+// segment `e` of the level that starts at `begin` in direction D's list, frequency group nu
+__device__ __forceinline__ void amr_segment(const AmrLevelRec &A, const AmrDirRec &D, int64_t begin, unsigned e, unsigned nu, unsigned nnu)
 {
-    const int d = blockIdx.y;
-    const unsigned count = (unsigned)A.count[d];
-    const unsigned nnu = (unsigned)A.nnu;
-    const unsigned t = blockIdx.x * 256u + threadIdx.x;
-    const unsigned e = NNU_SHIFT >= 0 ? t >> (NNU_SHIFT >= 0 ? NNU_SHIFT : 0) : t / nnu;
-    const unsigned nu = NNU_SHIFT >= 0 ? t & (nnu - 1u) : t - e * nnu;
-    if (e >= count) return;
-    const AmrDirRec &D = A.dir[d];
-    const SegRec R = D.rec[A.begin[d] + e];
+    const SegRec R = D.rec[begin + e];
     const int seg = R.seg, up = R.up, up2 = R.up2;
     const size_t at = (size_t)(unsigned)seg * nnu + nu;
     double I;
@@ -605,6 +597,42 @@ __global__ void __launch_bounds__(256) amr_level_kernel(const AmrLevelRec A)
     }
     D.Iout[at] = I;                              // read again by the segments downstream
     __builtin_nontemporal_store(m, &D.mean[at]); // read once, by the combine kernel
+}
+
+template <int NNU_SHIFT>
+__global__ void __launch_bounds__(256) amr_level_kernel(const AmrLevelRec A)
+{
+    const int d = blockIdx.y;
+    const unsigned count = (unsigned)A.count[d];
+    const unsigned nnu = (unsigned)A.nnu;
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    const unsigned e = NNU_SHIFT >= 0 ? t >> (NNU_SHIFT >= 0 ? NNU_SHIFT : 0) : t / nnu;
+    const unsigned nu = NNU_SHIFT >= 0 ? t & (nnu - 1u) : t - e * nnu;
+    if (e >= count) return;
+    amr_segment(A, A.dir[d], A.begin[d], e, nu, nnu);
+}
+
+// A run of THIN levels in one launch: one workgroup per direction walks levels depth0 .. depth0 + ndepth - 1 of its forest, a
+// barrier between two levels (what a level reads of the one before was written by this workgroup, on this CU: visible behind the
+// barrier).  A level of a few hundred segments is a launch of a few microseconds that the next one has to wait for, and a forest
+// around a refined patch is a hundred of them: here they cost a barrier each.  tables: [depth][count[ndir], begin[ndir]].
+template <int NNU_SHIFT>
+__global__ void __launch_bounds__(1024) amr_levels_kernel(const AmrLevelRec A, const int64_t *__restrict__ tables, int ndepth)
+{
+    const int d = blockIdx.x;
+    const unsigned nnu = (unsigned)A.nnu;
+    const AmrDirRec &D = A.dir[d];
+    for (int k = 0; k < ndepth; ++k) {
+        const int64_t *T = tables + (size_t)k * 2 * (size_t)A.ndir;
+        const unsigned items = (unsigned)T[d] * nnu;
+        const int64_t begin = T[A.ndir + d];
+        for (unsigned t = threadIdx.x; t < items; t += 1024u) {
+            const unsigned e = NNU_SHIFT >= 0 ? t >> (NNU_SHIFT >= 0 ? NNU_SHIFT : 0) : t / nnu;
+            const unsigned nu = NNU_SHIFT >= 0 ? t & (nnu - 1u) : t - e * nnu;
+            amr_segment(A, D, begin, e, nu, nnu);
+        }
+        __syncthreads();
+    }
 }
 
 // J[g][leaf] += (w / nseg) * (mean_xy + mean_xz + mean_yz), one direction after the other in list order
@@ -742,6 +770,21 @@ int launch_amr_level(const AmrLevelRec &A, hipStream_t stream)
     case 8: hipLaunchKernelGGL(amr_level_kernel<3>, grid, dim3(256), 0, stream, A); break;
     case 16: hipLaunchKernelGGL(amr_level_kernel<4>, grid, dim3(256), 0, stream, A); break;
     default: hipLaunchKernelGGL(amr_level_kernel<-1>, grid, dim3(256), 0, stream, A); break;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_amr_levels(const AmrLevelRec &A, const int64_t *tables, int ndepth, hipStream_t stream)
+{
+    if (ndepth <= 0 || A.ndir <= 0) return 0;
+    const dim3 grid((unsigned)A.ndir);
+    switch (A.nnu) {
+    case 1: hipLaunchKernelGGL(amr_levels_kernel<0>, grid, dim3(1024), 0, stream, A, tables, ndepth); break;
+    case 2: hipLaunchKernelGGL(amr_levels_kernel<1>, grid, dim3(1024), 0, stream, A, tables, ndepth); break;
+    case 4: hipLaunchKernelGGL(amr_levels_kernel<2>, grid, dim3(1024), 0, stream, A, tables, ndepth); break;
+    case 8: hipLaunchKernelGGL(amr_levels_kernel<3>, grid, dim3(1024), 0, stream, A, tables, ndepth); break;
+    case 16: hipLaunchKernelGGL(amr_levels_kernel<4>, grid, dim3(1024), 0, stream, A, tables, ndepth); break;
+    default: hipLaunchKernelGGL(amr_levels_kernel<-1>, grid, dim3(1024), 0, stream, A, tables, ndepth); break;
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

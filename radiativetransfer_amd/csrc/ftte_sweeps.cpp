@@ -203,11 +203,24 @@ int launch_forest_pass(ftte_ctx *c, hipStream_t stream, const ForestRun &R, size
     const ForestRun::Pass &P = B.passes[p];
     A.dir = c->d_amr_dirs + R.dir_at + (size_t)B.d0;
     A.ndir = B.nb;
-    for (size_t depth = 0; depth < P.maxdepth; ++depth) {
+    // Runs of thin levels (option "forest_fuse": at most that many (segment, frequency group) pairs in the fullest direction) go in
+    // one launch, a workgroup per direction and a barrier per level; a thick level gets a launch of its own, a thread per pair.
+    const int64_t thin = (int64_t)c->forest_fuse;
+    for (size_t depth = 0; depth < P.maxdepth;) {
+        size_t end = depth;
+        while (end < P.maxdepth && R.most_of[P.most_at + end] * (int64_t)c->nnu <= thin) ++end;
+        if (end > depth + 1) {
+            A.count = A.begin = nullptr; A.most = 0;
+            if (launch_amr_levels(A, c->d_amr_tables + P.table_at + depth * 2 * (size_t)B.nb, (int)(end - depth), stream))
+                return fail(c, FTTE_ERR_NO_DEVICE, "forest level kernel launch failed");
+            depth = end;
+            continue;
+        }
         A.count = c->d_amr_tables + P.table_at + depth * 2 * (size_t)B.nb;
         A.begin = A.count + B.nb;
         A.most = R.most_of[P.most_at + depth];
         if (launch_amr_level(A, stream)) return fail(c, FTTE_ERR_NO_DEVICE, "forest level kernel launch failed");
+        ++depth;
     }
     A.count = c->d_amr_tables + P.export_at;
     A.begin = A.count + B.nb;

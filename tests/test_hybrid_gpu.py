@@ -370,3 +370,38 @@ def test_fine_block_with_emission(which):
             e.set_source_function(np.repeat(uvb[:, None], len(level), 1))
             Jeq = e.transport(phi, theta, w, uvb)
             assert np.allclose(Jeq, uvb[:, None] * w.sum(), rtol=64 * EPS, atol=0)
+
+
+@pytest.mark.parametrize("nnu", [1, 3, 8])
+def test_thin_forest_levels_in_one_launch(nnu):
+    """Option "forest_fuse": runs of thin levels of the segment forests go in one launch, a workgroup per direction and a barrier
+    per level (amr_levels_kernel), thick levels keep a launch of their own.  Same arithmetic, same order: the bits of a launch per
+    level -- the forest path of the whole tree (every level thin on a small tree, thin and thick ones mixed at the default bound
+    on a larger one), the hybrid sweep, with and without a fine block -- and the whole-tree path still equals the oracle."""
+    n = 64
+    blocks = [(28 + a, 30 + b, 31 + c) for a in range(4) for b in range(4) for c in range(3)]
+    level, kappa, uvb = patch_case(n, blocks, 2, nnu, seed=17)
+    phi, theta, w = O.healpix_directions(2)
+    phi, theta, w = phi[::4], theta[::4], w[::4]
+    with rt.DiffuseTransfer() as e:
+        e.set_grid(n, level, 1.0)
+        e.set_opacity(kappa)
+        J = {}
+        for hybrid in (1, 0):
+            e.set_option("hybrid", hybrid)
+            for fuse in (0, 4096, 1 << 24, 600):
+                e.set_option("forest_fuse", fuse)
+                J[hybrid, fuse] = e.transport(phi, theta, w, uvb)
+            for fuse in (4096, 1 << 24, 600):
+                assert np.array_equal(J[hybrid, fuse], J[hybrid, 0]), (hybrid, fuse)
+        assert np.array_equal(J[0, 0], O.sweep_tree(n, level, kappa, 1.0, phi, theta, w, uvb, arith=O.ARITH_DEVICE))
+    level, kappa, uvb = _cube_case(n, 32, (16, 16, 16), nnu, seed=43)
+    with rt.DiffuseTransfer() as e:
+        e.set_grid(n, level, 1.0)
+        e.set_opacity(kappa)
+        e.set_option("forest_fuse", 0)
+        J0 = e.transport(phi, theta, w, uvb)
+        assert e.counter("fine_block") == 64
+        for fuse in (4096, 30000):
+            e.set_option("forest_fuse", fuse)
+            assert np.array_equal(e.transport(phi, theta, w, uvb), J0), fuse

@@ -20,7 +20,7 @@ def flag(name, default=None):
     return default
 
 
-skip = {sys.argv.index(k) + 1 for k in ("--chunk", "--group", "--hybrid", "--pipelines", "--graph", "--hybrid_slots", "--fine_bricks", "--fine_chunk", "--save") if k in sys.argv}
+skip = {sys.argv.index(k) + 1 for k in ("--chunk", "--group", "--hybrid", "--pipelines", "--graph", "--hybrid_slots", "--fine_bricks", "--fine_chunk", "--forest_fuse", "--save") if k in sys.argv}
 args = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and i not in skip]
 n = int(args[0]) if args else 128
 q = n // 4
@@ -31,7 +31,7 @@ ncell = len(level)
 print(f"{ncell} leaves ({n}^3 base, central {q}^3 block refined once); levels built in {time.perf_counter() - t0:.1f} s", flush=True)
 eng = rt.StellarTransfer(device=0)
 t0 = time.perf_counter(); eng.set_grid(n, level, 3.0e22); print(f"set_grid (tree rebuild): {time.perf_counter() - t0:.2f} s", flush=True)
-for key in ("chunk", "group", "hybrid", "pipelines", "graph", "hybrid_slots", "fine_bricks", "fine_chunk"):
+for key in ("chunk", "group", "hybrid", "pipelines", "graph", "hybrid_slots", "fine_bricks", "fine_chunk", "forest_fuse"):
     if flag("--" + key) is not None:
         eng.set_option(key, flag("--" + key))
 
