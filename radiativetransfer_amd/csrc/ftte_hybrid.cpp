@@ -961,6 +961,18 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
         // one batch per pipeline when they run side by side (their scratch must not overlap), else `batch` directions at a time
         if ((rc = prepare_forests(c, stream, sets, slot0, nh > 1 ? ndir : batch, per_dir, &runs))) return rc;
     }
+    // (FTTE_HYBRID_TIMELINE: events at the phase boundaries of every pipeline, printed when the sweep is over -- a timeline without
+    // a tracer, whose own cost per launch changes what overlaps what)
+    static const bool timeline = std::getenv("FTTE_HYBRID_TIMELINE") != nullptr;
+    struct Mark { hipEvent_t e; int pipe; const char *what; };
+    std::vector<Mark> marks;
+    auto mark = [&](hipStream_t q, int pipe, const char *what) {
+        if (!timeline) return;
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        (void)hipEventRecord(e, q);
+        marks.push_back({e, pipe, what});
+    };
     // ---- the launches of one sweep: the same sequence every iteration while plan and buffers stay what they are
     auto issue = [&]() -> int {
         // ---- opacity of the base cells in the three layouts; accumulators and J start from zero
@@ -995,6 +1007,7 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
             for (int s = 0; s < P.nacc[l]; ++s) FTTE_HIP(c, hipMemsetAsync(c->acc[l][s], 0, sizeof(double) * per_base, stream));
         FTTE_HIP(c, hipMemsetAsync(J_dev, 0, sizeof(double) * (size_t)nnu * ncell, stream));
 
+        mark(stream, -1, "layouts and zeroing done");
         if (nh > 1) {
             FTTE_HIP(c, hipEventRecord(c->ev_fork, stream));
             for (int r = 1; r < nh; ++r) FTTE_HIP(c, hipStreamWaitEvent(qs[r], c->ev_fork, 0));
@@ -1008,11 +1021,16 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
                     if ((size_t)H.pass_at[(size_t)h][(size_t)pass] != l || (nh == 1 && h > 0)) continue;
                     hipEvent_t before = (nh > 1 && r > 0) ? c->ev_combine[r - 1] : nullptr, after = (nh > 1 && r + 1 < nh) ? c->ev_combine[r] : nullptr;
                     if (FN.active) { // the forest before the fine block's bricks, those, the forest behind them; the means below
+                        mark(qs[r], r, "bricks before the box done");
                         if ((rc = launch_forest_pass(c, qs[r], runs[(size_t)r], 0, 0, A))) return rc;
+                        mark(qs[r], r, "forest before the fine block done");
                         if ((rc = fine_sweep(h, qs[r], runs[(size_t)r], A))) return rc;
+                        mark(qs[r], r, "fine bricks done");
                         if ((rc = launch_forest_pass(c, qs[r], runs[(size_t)r], 0, 1, A))) return rc;
+                        mark(qs[r], r, "forest behind the fine block done");
                         continue;
                     }
+                    mark(qs[r], r, "bricks before a forest pass done");
                     if (H.npass == 1) { // one pass: batch by batch, each with its means
                         if ((rc = launch_forests(c, qs[r], runs[(size_t)r], A, J_dev, false, false, before, after))) return rc;
                         continue;
@@ -1025,6 +1043,7 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
         }
         // several passes: the means into J when everything is issued, pipeline after pipeline (a pipeline's last pass may come
         // earlier or later than another's, and the events that order the additions must be recorded before they are waited for)
+        for (int r = 0; r < nh; ++r) mark(qs[r], r, "last bricks done");
         if (H.npass > 1 || FN.active)
             for (int r = 0; r < nh; ++r) {
                 if (nh > 1 && r > 0) FTTE_HIP(c, hipStreamWaitEvent(qs[r], c->ev_combine[r - 1], 0));
@@ -1093,6 +1112,18 @@ int hybrid_sweep(ftte_ctx *c, int ndir, const double *phi, const double *theta, 
     }
     if (!replayed && (rc = issue())) return rc;
     FTTE_HIP(c, hipEventRecord(Tm.stop, stream));
+    if (timeline && !marks.empty()) {
+        (void)hipEventSynchronize(Tm.stop);
+        for (const Mark &m : marks) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, Tm.start, m.e);
+            std::fprintf(stderr, "[ftte] hybrid timeline: %8.3f ms  pipeline %2d  %s\n", ms, m.pipe, m.what);
+            (void)hipEventDestroy(m.e);
+        }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, Tm.start, Tm.stop);
+        std::fprintf(stderr, "[ftte] hybrid timeline: %8.3f ms  sweep done (means and merges in)\n", ms);
+    }
     c->timing_used = 1;
     *done = true;
     return mark_sweep(c, stream);
