@@ -283,6 +283,29 @@ static double fo_segment(double *I, double kappa, double eta, double src, int em
     const double Iin = *I;
     const double tau = kappa * dpath;
     double mean;
+    if (arith == FO_ARITH_EXACT) {
+        /* extended precision throughout the segment, one rounding of each result (ftte_oracle.h) */
+        const long double t = (long double)kappa * (long double)dpath;
+        const long double a = expl(-t), one_minus_a = -expm1l(-t);
+        const long double g = t > 0.0L ? one_minus_a / t : 1.0L;
+        if (emitting == 2) {
+            *I = (double)((long double)src + ((long double)Iin - (long double)src) * a);
+            return (double)((long double)src + ((long double)Iin - (long double)src) * g);
+        }
+        if (!emitting) {
+            *I = (double)((long double)Iin * a);
+            return (double)((long double)Iin * g);
+        }
+        const long double emit = (tau > (double)1.e-10f) ? one_minus_a / (long double)kappa : (long double)dpath;
+        const long double Iout = (long double)Iin * a + (long double)eta * emit / (long double)dpath;
+        *I = (double)Iout;
+        if (Iout < (long double)Iin) {
+            /* (Iin - Iout)/log(Iin/Iout) with the logarithm of a ratio near 1 taken through log1p */
+            const long double d = (long double)Iin - Iout;
+            return (double)(d / -log1pl(-d / (long double)Iin));
+        }
+        return (double)(0.5L * ((long double)Iin + Iout));
+    }
     if (emitting == 2) {
         /* a source function S (the build's own extension, not in the reference): the formal solution with S constant along the
          * piece, I(t) = S + (Iin - S) exp(-t), and its exact path mean S + (Iin - S)(1 - exp(-tau))/tau (ftte_math.h:
@@ -335,6 +358,7 @@ static double fo_segment(double *I, double kappa, double eta, double src, int em
 static double fo_cell_mean(double acc, int nseg, double w, int arith)
 {
     if (arith == FO_ARITH_DEVICE) return ftte_cell_mean(acc, nseg, w);
+    if (arith == FO_ARITH_EXACT) return (double)((long double)acc / (long double)nseg * (long double)w);
     return acc / (double)(float)nseg * w; /* Jmean/float(imean) * weight, :953 */
 }
 

@@ -36,7 +36,12 @@ typedef struct {
 /* arithmetic flavour of the sweep */
 enum {
     FO_ARITH_REFERENCE = 0, /* libm exp/log, (Iin-Iout)/log(Iin/Iout): the reference's formulae */
-    FO_ARITH_DEVICE = 1     /* radiativetransfer_amd/csrc/ftte_math.h: what the GPU evaluates    */
+    FO_ARITH_DEVICE = 1,    /* radiativetransfer_amd/csrc/ftte_math.h: what the GPU evaluates    */
+    FO_ARITH_EXACT = 2      /* every segment in extended precision (long double, 64-bit mantissa: expl, expm1l), rounded to double
+                               once: Iout = Iin exp(-tau), mean = Iin (1 - exp(-tau))/tau -- what the reference's log-mean IS when
+                               nothing is emitted --, with a source function the exact path mean, with the reference's emissivity
+                               term its formulae as they stand.  Shares nothing with ftte_math.h: the yardstick both the device
+                               arithmetic and the reference's own double-precision evaluation are measured against in the tests. */
 };
 /* order in which directions are summed into J */
 enum {

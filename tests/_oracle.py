@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB = os.path.join(ORACLE_DIR, "libftte_oracle.so")
 
-ARITH_REFERENCE, ARITH_DEVICE = 0, 1
+ARITH_REFERENCE, ARITH_DEVICE, ARITH_EXACT = 0, 1, 2
 ORDER_SERIAL, ORDER_CLASSED = 0, 1
 
 

@@ -217,6 +217,24 @@ def test_arbitrary_directions_and_weights(engine):
     assert np.all(np.abs(J - ref) <= reference_bound(n, ref, noise))
 
 
+@pytest.mark.parametrize("n,nnu,tau_median", [(64, 3, 0.1), (72, 2, 1.0), (130, 1, 0.01)])
+def test_gpu_within_64_eps_of_the_exact_evaluation(engine, n, nnu, tau_median):
+    """The yardstick that shares nothing with the product (oracle ARITH_EXACT: every segment in extended precision, rounded once;
+    tests/test_exact_arithmetic.py): the GPU's J for 48 directions lies within 64 eps of it cell by cell -- 32 for the segment
+    arithmetic along the rays, the rest for the order of the sum over directions -- on whole-brick and ragged grids, thin and thick
+    fields, where the reference's own double-precision evaluation is off by up to 10^7 eps (the noise of its log-mean)."""
+    phi, theta, w = O.healpix_directions(2)
+    kappa, uvb, box = synthetic.uniform_workload(n, nnu, seed=77, tau_median=tau_median)
+    engine.set_uniform_grid(n, box)
+    engine.set_opacity(kappa)
+    J = engine.transport(phi, theta, w, uvb)
+    exact = O.sweep_uniform(n, kappa, box, phi, theta, w, uvb, arith=O.ARITH_EXACT)
+    assert np.all(np.abs(J - exact) <= 64 * EPS * exact)
+    if tau_median <= 0.1:
+        reference = O.sweep_uniform(n, kappa, box, phi, theta, w, uvb)
+        assert np.max(np.abs(reference - exact) / exact) > 100 * np.max(np.abs(J - exact) / exact)
+
+
 def _foldable(p, t):
     try:
         O.fold_direction(p, t)
