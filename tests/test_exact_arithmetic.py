@@ -42,6 +42,13 @@ def test_device_arithmetic_within_32_eps_of_the_exact_evaluation_with_a_source_f
     exact = O.sweep_uniform(n, kappa, box, phi, theta, w, uvb, src=S, arith=O.ARITH_EXACT)
     device = O.sweep_uniform(n, kappa, box, phi, theta, w, uvb, src=S, arith=O.ARITH_DEVICE)
     assert np.all(np.abs(device - exact) <= 32 * EPS * exact)
+    # the reference's emissivity term (:656-676): its formulae in extended precision, the log-mean through log1p
+    X = np.random.default_rng(2).random(kappa.shape) * uvb[:, None] * kappa.mean()
+    exact = O.sweep_uniform(n, kappa, box, phi, theta, w, uvb, eta=X, arith=O.ARITH_EXACT)
+    device = O.sweep_uniform(n, kappa, box, phi, theta, w, uvb, eta=X, arith=O.ARITH_DEVICE)
+    reference, noise = O.sweep_uniform(n, kappa, box, phi, theta, w, uvb, eta=X, with_noise=True)
+    assert np.all(np.abs(device - exact) <= 32 * EPS * exact)
+    assert np.all(np.abs(reference - exact) <= noise + 64 * EPS * exact)
     # a refined cell array: two levels, the patterns of the sub-layers and the mean-of-two hand-over in play
     n = 16
     level = synthetic.refine_levels(n, [(7, 7, 7), (8, 8, 7), (3, 12, 5)], depth=2)
