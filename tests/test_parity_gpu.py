@@ -581,3 +581,7 @@ def test_baseline_size_several_directions_against_oracle(engine, big):
     Jh = J[[0, 7]].cpu().numpy()
     ref = O.sweep_uniform(n, big["kappa"][[0, 7]], big["box"], phi, theta, w, big["uvb"][[0, 7]], arith=O.ARITH_DEVICE)
     assert np.allclose(Jh, ref, rtol=SUM_RTOL, atol=0)
+    # ... and against the arithmetic that shares nothing with the product (every segment in extended precision, rounded once):
+    # 256 layers of segments along every ray, thickest and thinnest group
+    exact = O.sweep_uniform(n, big["kappa"][[0, 7]], big["box"], phi, theta, w, big["uvb"][[0, 7]], arith=O.ARITH_EXACT)
+    assert np.all(np.abs(Jh - exact) <= 64 * EPS * exact)
