@@ -405,3 +405,25 @@ def test_thin_forest_levels_in_one_launch(nnu):
         for fuse in (4096, 30000):
             e.set_option("forest_fuse", fuse)
             assert np.array_equal(e.transport(phi, theta, w, uvb), J0), fuse
+
+
+def test_refined_cell_arrays_within_64_eps_of_the_exact_evaluation():
+    """The hybrid sweep with a fine block, the hybrid sweep of scattered two-level patches and the forest path of the whole tree
+    against the oracle's arithmetic that shares nothing with the product (every segment in extended precision, rounded once;
+    tests/test_exact_arithmetic.py): J within 64 eps cell by cell, coarse and fine cells alike."""
+    phi, theta, w = O.healpix_directions(2)
+    phi, theta, w = phi[::4], theta[::4], w[::4]
+    n = 64
+    cases = [_cube_case(n, 32, (16, 8, 20), 2, seed=91),
+             patch_case(n, [(30 + a, 31 + b, 33 + c) for a in range(3) for b in range(2) for c in range(4)] + [(5, 50, 9)], 2, 2, seed=92)]
+    for k, (level, kappa, uvb) in enumerate(cases):
+        exact = O.sweep_tree(n, level, kappa, 1.0, phi, theta, w, uvb, arith=O.ARITH_EXACT)
+        with rt.DiffuseTransfer() as e:
+            e.set_grid(n, level, 1.0)
+            e.set_opacity(kappa)
+            J = e.transport(phi, theta, w, uvb)
+            assert (e.counter("fine_block") == 64) == (k == 0)
+            e.set_option("hybrid", 0)
+            J_forest = e.transport(phi, theta, w, uvb)
+        assert np.all(np.abs(J - exact) <= 64 * EPS * exact), k
+        assert np.all(np.abs(J_forest - exact) <= 64 * EPS * exact), k
