@@ -515,7 +515,37 @@ __global__ void __launch_bounds__(256) merge_kernel(const MergeRec M, double *__
         }
         have = true;
     }
-    for (int a = 0; a < M.count; ++a) {
+    // the accumulators that need no transpose (layouts 0 and 1: they come first in the list), eight at a time: all their loads in
+    // flight, then the sums in list order
+    int a0 = 0;
+    while (a0 < M.count && M.layout[a0] != 2) {
+        int nb = 0;
+        while (nb < 8 && a0 + nb < M.count && M.layout[a0 + nb] != 2) ++nb;
+        double v[8][4];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            if (b >= nb) continue;
+            const double *s = M.acc[a0 + b] + g * group_stride;
+            const bool one = M.layout[a0 + b] == 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int jc = j0 + ty + 8 * q, kc = k0 + tx;
+                v[b][q] = 0.0;
+                if (jc >= n || kc >= n) continue;
+                const int x = one ? jc : ic, y = one ? ic : jc;
+                v[b][q] = __builtin_nontemporal_load(&s[tiled ? tiled_index(n, x, y, kc, tchunk) : ((long)x * n + y) * n + kc]);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            if (b >= nb) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sum[q] = have ? sum[q] + v[b][q] : v[b][q];
+            have = true;
+        }
+        a0 += nb;
+    }
+    for (int a = a0; a < M.count; ++a) {
         const double *s = M.acc[a] + g * group_stride;
         if (M.layout[a] == 2) {
             // element (ic, jc, kc) sits at [kc][ic][jc]: read rows along jc, transpose through LDS
