@@ -1278,15 +1278,25 @@ struct ChemEq { double k1, k2, k3, k4, k5, k6, nh, nhe, kr24, kr25, kr26; };
 __device__ __forceinline__ double chem_residual(const ChemEq &q, double de, double &HeI)
 {
     // :3592-3596 (repeated at :3600-3604 and :3618-3622)
+    // (the divisions through FTTE_DIV: the instruction sequence of an IEEE fp64 division without its range handling -- every
+    // denominator here is a positive normal number far from the ends of the range: k de with de >= 1e-30, 1 + ..., -X/Y - 2 --,
+    // same bits, a quarter fewer instructions; six divisions per evaluation, some forty evaluations per cell)
     const double X = q.k3 * de + q.kr26, Y = q.k4 * de;
-    HeI = (de - q.nh / (1. + q.k2 * de / (q.k1 * de + q.kr24)) - 2. * q.nhe) / (X / Y - 2. - 2. * X / Y);
-    return q.k3 * HeI * de + q.k6 * (q.nhe - HeI - HeI * X / Y) * de + q.kr26 * HeI - HeI * X / Y * (q.k4 * de + q.k5 * de + q.kr25);
+    const double XY = FTTE_DIV(X, Y);
+    const double HII = FTTE_DIV(q.nh, 1. + FTTE_DIV(q.k2 * de, q.k1 * de + q.kr24));
+    HeI = FTTE_DIV(de - HII - 2. * q.nhe, XY - 2. - FTTE_DIV(2. * X, Y));
+    const double HeII = FTTE_DIV(HeI * X, Y);
+    return q.k3 * HeI * de + q.k6 * (q.nhe - HeI - HeII) * de + q.kr26 * HeI - HeII * (q.k4 * de + q.k5 * de + q.kr25);
 }
 
 __global__ void __launch_bounds__(256) rate_equations_kernel(const ChemRec R)
 {
-    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= R.ncell) return;
+    // (the sweep's three statistics -- the largest change, the bisection steps, the first cell the reference would stop at -- are
+    // combined per workgroup before they go to their single words in memory: a quarter of a million atomics on ONE address each
+    // cost more than all the arithmetic of the kernel)
+    __shared__ unsigned long long blk_change[4], blk_steps[4], blk_bad[4];
+    unsigned long long my_change = 0ull, my_steps = 0ull, my_bad = ~0ull;
+    for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < R.ncell; c += (long)gridDim.x * blockDim.x) { // (a few cells per thread)
     const double psi = (double)0.76f, mp = (double)1.6726231e-24f, mn = (double)1.67492728e-24f; // definitionsModule.f90:25-28, 261
     const double mh = mp, mhe = 2. * (mp + mn), pi = (double)3.141592654f;
     ChemEq q;
@@ -1354,14 +1364,38 @@ __global__ void __launch_bounds__(256) rate_equations_kernel(const ChemRec R)
     HI = q.k2 * HII * de / (q.k1 * de + q.kr24);
     // where the reference prints the species and stops, :3637-3654
     const bool ok = (HI / q.nh >= 0. && HI / q.nh <= 1.) && (HeI / q.nhe >= 0. && HeI / q.nhe <= 1.) && steps < 4096u;
-    if (!ok) { atomicMin(R.first_bad, (unsigned long long)c); return; }
-    // the reference's (unused) convergence measure, :3671-3674
-    const double c1 = fabs(HI - HI0) * mh / (psi * rho), c2 = fabs(HeI - HeI0) * mhe / ((1. - psi) * rho),
-                 c3 = fabs(HeII - HeII0) * mhe / ((1. - psi) * rho);
-    const double change = fmax(c1, fmax(c2, c3));
-    atomicMax(R.max_change, (unsigned long long)__double_as_longlong(change)); // non-negative doubles order like their bits
-    atomicAdd(R.steps, (unsigned long long)steps);
-    R.HI_out[c] = HI; R.HeI_out[c] = HeI; R.HeII_out[c] = HeII;
+    if (!ok) my_bad = (unsigned long long)c < my_bad ? (unsigned long long)c : my_bad;
+    else {
+        // the reference's (unused) convergence measure, :3671-3674
+        const double c1 = fabs(HI - HI0) * mh / (psi * rho), c2 = fabs(HeI - HeI0) * mhe / ((1. - psi) * rho),
+                     c3 = fabs(HeII - HeII0) * mhe / ((1. - psi) * rho);
+        const double change = fmax(c1, fmax(c2, c3));
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(change); // non-negative doubles order like their bits
+        my_change = bits > my_change ? bits : my_change;
+        my_steps += (unsigned long long)steps;
+        R.HI_out[c] = HI; R.HeI_out[c] = HeI; R.HeII_out[c] = HeII;
+    }
+    }
+    // wavefront, then workgroup, then one atomic each
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long oc = __shfl_xor(my_change, off), os = __shfl_xor(my_steps, off), ob = __shfl_xor(my_bad, off);
+        my_change = oc > my_change ? oc : my_change;
+        my_steps += os;
+        my_bad = ob < my_bad ? ob : my_bad;
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { blk_change[wave] = my_change; blk_steps[wave] = my_steps; blk_bad[wave] = my_bad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) {
+            my_change = blk_change[k] > my_change ? blk_change[k] : my_change;
+            my_steps += blk_steps[k];
+            my_bad = blk_bad[k] < my_bad ? blk_bad[k] : my_bad;
+        }
+        if (my_bad != ~0ull) atomicMin(R.first_bad, my_bad);
+        if (my_change) atomicMax(R.max_change, my_change);
+        if (my_steps) atomicAdd(R.steps, my_steps);
+    }
 }
 
 // assignUvbRadiation, transportRoutinesModule.f90:1056-1093: the optically thin alternative to the sweep.  J_g = uvb_g where the
@@ -1391,7 +1425,9 @@ int launch_thin_limit(const double *HI, const double *HeI, const double *HeII, c
 int launch_rate_equations(const ChemRec &R, hipStream_t stream)
 {
     if (R.ncell <= 0) return 0;
-    hipLaunchKernelGGL(rate_equations_kernel, dim3((unsigned)((R.ncell + 255) / 256)), dim3(256), 0, stream, R);
+    // (enough workgroups to fill the GPU several times over, few enough that their atomics are nothing)
+    const long blocks = (R.ncell + 255) / 256;
+    hipLaunchKernelGGL(rate_equations_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, stream, R);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -179,6 +179,63 @@ def test_baseline_size_properties(golden):
     assert np.array_equal(HI[pick], ref[0]) and np.array_equal(HeI[pick], ref[1]) and np.array_equal(HeII[pick], ref[2])
 
 
+def test_equilibrium_over_wide_ranges_bitwise(golden):
+    """Every cell of a 64^3 grid with densities over five decades, temperatures from 10 K to 3e9 K (the rate table's whole span), mean
+    intensities over three decades, with and without point-source rates: HI, HeI, HeII equal the oracle's statement-by-statement
+    evaluation (IEEE divisions) bit for bit, and so does the number of bisection steps -- the kernel's residual takes its six
+    divisions through the trimmed sequence of ftte_math.h (no range handling), which this pins over the ranges it meets.  Over
+    ranges wider still (ten decades of density) the reference stops at a cell whose fractions leave [0, 1] (:3637-3654): the
+    library stops at the same cell."""
+    import radiativetransfer_amd as rt
+    g = golden("chem_uvb_refined")
+    n = 64
+    nc = n ** 3
+    box = 2.5e23
+    vol = (box / n) ** 3
+    mp, mn, psi = float(np.float32(1.6726231e-24)), float(np.float32(1.67492728e-24)), float(np.float32(0.76))
+    table = (float(g["logtem0"]), float(g["logtem9"]), float(g["dlogtem"]), g["k"])
+
+    def field(rho_range, j_range, seed):
+        rng = np.random.default_rng(seed)
+        rho = 10 ** rng.uniform(*rho_range, nc)
+        nh, nhe = psi * rho / mp, (1 - psi) * rho / (2 * (mp + mn))
+        tgas = 10 ** rng.uniform(1.0, 9.5, nc)
+        J = 10 ** rng.uniform(*j_range, (3, nc))
+        start = (nh * 10 ** rng.uniform(-8, 0, nc), nhe * 10 ** rng.uniform(-8, -0.5, nc), nhe * 10 ** rng.uniform(-8, -0.5, nc))
+        krate = np.zeros((6, nc))
+        lit = rng.random(nc) < 0.3
+        krate[0] = np.where(lit, 10 ** rng.uniform(-16, -11, nc) * vol * start[0], 0.0)
+        krate[1] = np.where(lit, 10 ** rng.uniform(-17, -12, nc) * vol * start[2], 0.0)
+        krate[2] = np.where(lit, 10 ** rng.uniform(-16, -11, nc) * vol * start[1], 0.0)
+        return rho, tgas, J, start, krate
+
+    def device(rho, tgas, J, start, rates):
+        with rt.StellarTransfer() as st:
+            st.set_uniform_grid(n, box)
+            st.set_rate_coefficients(*table)
+            st.set_medium(*start, rho, None, 0)
+            st.set_temperature(tgas)
+            if rates is not None:
+                st.set_rates(rates)
+            st.solve_rate_equations(True, J, g["ksi"], use_point_rates=rates is not None)
+            return st.medium(), st.rate_equation_steps()
+
+    rho, tgas, J, start, krate = field((-27.5, -22.5), (-24.0, -21.0), seed=17)
+    for rates in (None, krate):
+        ref = O.solve_rate_equations(n, np.zeros(nc, np.int32), box, rho, tgas, *start, None if rates is None else rates[:3], True, J,
+                                     g["ksi"], None, 0.0, *table)
+        assert ref[3] == 0
+        (HI, HeI, HeII), steps = device(rho, tgas, J, start, rates)
+        assert np.array_equal(HI, ref[0]) and np.array_equal(HeI, ref[1]) and np.array_equal(HeII, ref[2])
+        assert steps == ref[4]
+    rho, tgas, J, start, krate = field((-31.0, -21.0), (-27.0, -19.0), seed=17)
+    ref = O.solve_rate_equations(n, np.zeros(nc, np.int32), box, rho, tgas, *start, None, True, J, g["ksi"], None, 0.0, *table)
+    assert ref[3] > 0
+    with pytest.raises(rt.FtteError) as err:
+        device(rho, tgas, J, start, None)
+    assert err.value.status == "FTTE_ERR_RATES" and f"cell {ref[3] - 1} " in str(err.value)
+
+
 def test_assign_uvb_radiation_against_reference(stellar, golden):
     g = golden("thin_limit_uvb")
     stellar.set_grid(int(g["n"]), g["level"], float(g["box"]))
