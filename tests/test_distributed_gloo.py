@@ -175,7 +175,8 @@ def _check_2d(tmp_path, world, nnu, n, use_gpu):
 
 
 @pytest.mark.parametrize("world,nnu,expect", [(2, 2, "2 frequency slice(s) x 1 direction"), (3, 2, "1 frequency slice(s) x 3 direction"),
-                                              (4, 2, "2 frequency slice(s) x 2 direction"), (2, 8, "2 frequency slice(s) x 1 direction")])
+                                              (4, 2, "2 frequency slice(s) x 2 direction"), (2, 8, "2 frequency slice(s) x 1 direction"),
+                                              (8, 8, "8 frequency slice(s) x 1 direction")])   # (the layout of the driver's 8-GPU run)
 def test_frequency_by_direction_sharding(tmp_path, world, nnu, expect):
     """bench.py's multi-GPU layout on CPU (gloo): frequency groups first (no reduction, an all-gather), directions split
     only beyond that (all-reduce within a frequency slice, then the all-gather)."""
